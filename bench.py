@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""bench.py -- images/s of the YOLOv3 hot path on MI355X (BASELINE.json metric / configs[1]).
+
+One step = one pass of the hot path over one batch of synthetic images already resident in HBM:
+NCHW float32 images -> Darknet-53-spec backbone + 3-scale YOLO heads (bf16 MFMA, fp32 accumulate)
+-> anchor decode + per-image top-1 (the reference's `predict`, car/YOLO.py:568-597), all on device.
+Batch is sharded across ranks (one process per GPU, weak scaling, no data-path collective:
+SURVEY.md section 8e "inference").
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `roofline` is for the kernel instantiation with the largest
+total time: achieved = algorithmic conv FLOPs of its launches / their HIP-event durations,
+measured live in a second pass over the same K steps (events bracket each launch on the stream the
+kernels run on; the headline `value` pass itself carries no events).  `cpu_baseline` times the
+CPU oracle (torch-CPU fp32 restatement of the reference graph; the reference's MXNet cannot run
+here) on a bounded sample on rank 0 at N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # /opt/skills/guides/MI355X_MICROARCH.md (dense)
+
+
+def cpu_baseline(size, seconds=12.0, batch=2):
+    """Oracle forward + numpy decode/top-1 on the host cores: images/s on a bounded sample."""
+    from oracle import graph as og, forward as of, detect as od
+    spec = og.spec_d53()
+    g = og.build_graph(spec)
+    P = og.init_params(g, seed=0, bn='identity')
+    Pt = {k: torch.from_numpy(v) for k, v in P.items()}
+    x = torch.rand((batch, 3) + tuple(size))
+    steps = od.init_steps(spec['layers'], spec['all_anchors'])
+    syxhw = od.init_syxhw(size, steps, spec['all_anchors'])
+
+    def once():
+        with torch.no_grad():
+            outs = of.forward_torch(g, Pt, x)
+        od.predict([o.numpy() for o in outs], spec['slice_point'], size, syxhw)
+
+    once()                                   # warm-up
+    n, t0 = 0, time.time()
+    while True:
+        once(); n += 1
+        el = time.time() - t0
+        if el >= seconds or n >= 20:
+            break
+    return dict(value=round(n * batch / el, 3), unit='images/s', cores=torch.get_num_threads(), kind='port',
+                sample='oracle.forward_torch (torch-CPU fp32 restatement of the reference graph) + numpy '
+                       'decode/top-1, D53 spec %dx%d, batch %d x %d iterations after 1 warm-up (%.1f s)'
+                       % (size[0], size[1], batch, n, el))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
+    ap.add_argument('--size', type=int, default=416)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('WORLD_SIZE %d != --gpus %d' % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from yolo_amd.net import CarNet
+    from yolo_amd.detect import Detector
+    from yolo_amd.spec import darknet53_spec
+
+    spec = darknet53_spec()
+    size = (args.size, args.size)
+    B = args.batch
+    net = CarNet(spec, dtype=args.dtype, device=dev).initialize(seed=1234)
+    net.prepare()
+    det = Detector(spec, size, net.graph.steps(), device=dev)
+    gen = torch.Generator(device='cpu').manual_seed(100 + rank)
+    x = torch.rand((B, 3) + size, generator=gen).to(dev)            # synthetic images, resident in HBM
+
+    def step():
+        outs = net(x)
+        return det.predict_device(outs)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pred, idx = step()
+    fence()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    ms_per_step = el / args.steps * 1e3
+    value = world * B * args.steps / el
+
+    out = {
+        'metric': 'images/sec at %dx%d bs=%d per GPU (Darknet-53 spec + 3-scale YOLO head forward, anchor '
+                  'decode + top-1)' % (size[0], size[1], B),
+        'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[1]: Darknet-53 spec layers [1,2,8,8,4] channels [32..1024] + '
+                               '3-scale YOLO head (A=3, C=30) forward, random Xavier weights, %dx%d, bs=%d per GPU, '
+                               '+ decode/top-1' % (size[0], size[1], B),
+                   'global_batch': B * world, 'image': list(size),
+                   'parallelism': 'dp%d (batch-sharded, no data-path collective)' % world,
+                   'gflop_per_image': round(net.graph.flops(*size) / 1e9, 2)},
+    }
+    out['net_tflops'] = round(net.graph.flops(*size) * value / 1e12, 1)
+
+    if rank == 0 and not args.no_roofline:
+        kernels = net.plan_kernels(B, *size)
+        info = {n: (k, f) for n, k, f in kernels}
+        agg = {}
+        for _ in range(args.steps):
+            ev = []
+            net.forward_timed(x, ev)
+            torch.cuda.synchronize()
+            for name, e0, e1 in ev:
+                k, f = info[name]
+                a = agg.setdefault(k, [0.0, 0, 0])
+                a[0] += e0.elapsed_time(e1) * 1e-3
+                a[1] += 1
+                a[2] += f
+        dom = max((k for k in agg if agg[k][2] > 0), key=lambda k: agg[k][0])
+        tsec, nl, fl = agg[dom]
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        ach = fl / tsec / 1e12
+        out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s',
+                           'frac': round(ach / peak, 4), 'traffic': None, 'kernel': dom,
+                           'launches_per_step': nl // args.steps,
+                           'avg_launch_us': round(tsec / nl * 1e6, 2),
+                           'flops_per_launch': fl // nl}
+        out['kernels'] = [{'kernel': k, 'launches_per_step': v[1] // args.steps,
+                           'ms_per_step': round(v[0] / args.steps * 1e3, 4),
+                           'tflops': round(v[2] / v[0] / 1e12, 1) if v[2] else None}
+                          for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])]
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(size)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,140 @@
+/* yolo_amd.h -- C ABI of libyolo_amd.so: the MI355X (gfx950) YOLOv3 hot path.
+ *
+ * The reference (n8886919/YOLO) has no FFI/plugin interface: its seam is the Python object
+ * protocol between the task drivers and MXNet operators.  Each entry
+ * point below names the reference call site / MXNet operator it replaces.  All pointers are
+ * DEVICE pointers unless a name ends in _host.  The caller owns every buffer; the library
+ * allocates no persistent device memory.  Every function is asynchronous on `stream`
+ * (a hipStream_t passed as void*), returns 0 on success, <0 on invalid argument /
+ * unsupported shape, >0 = hipError_t from the launch.  Nothing throws across the ABI.
+ *
+ * Layout: activations are NHWC ("pixel-major, channel-contiguous") in HBM, dtype
+ * YOLO_F32 or YOLO_BF16; images enter as NCHW float32 exactly as the reference feeds them
+ * (car/YOLO.py:381, yolo_gluon.py:354) and head logits leave as (B, sum HW, A, C) float32
+ * exactly as CarNet returns them (car/utils.py:95, basic_yolo.py:102-103).
+ */
+#ifndef YOLO_AMD_H
+#define YOLO_AMD_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YOLO_F32 0
+#define YOLO_BF16 1
+
+#define YOLO_OK 0
+#define YOLO_EINVAL (-1)
+#define YOLO_EUNSUPPORTED (-2)
+
+int yolo_version(void);
+
+/* ---- parameter preparation ------------------------------------------------------------- */
+
+/* Bytes of the packed weight image for a conv (Cout, Cin, ksize) in `dtype`. */
+long long yolo_packed_weight_bytes(int Cout, int Cin, int ksize, int dtype);
+
+/* OIHW float32 weights (gluon Conv2D layout, basic_yolo.py:20-26,98) -> the K-chunked,
+ * LDS-swizzled image the implicit-GEMM kernel streams: [chunk][tap][Cout_pad][64 B]. */
+int yolo_pack_conv_weights(const float* w_oihw, void* packed, int Cout, int Cin, int ksize,
+                           int dtype, void* stream);
+
+/* Inference-mode BatchNorm folding (gluon BatchNorm eps=1e-5):
+ * scale = gamma/sqrt(var+eps), bias = beta - mean*scale, both padded with zeros to
+ * yolo_padded_channels(C) floats.  gamma==NULL: scale=1, bias=beta (plain conv bias,
+ * YOLOOutput basic_yolo.py:98; beta may be NULL -> 0). */
+int yolo_padded_channels(int C);
+int yolo_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var,
+                 float eps, float* scale, float* bias, int C, void* stream);
+
+/* ---- image plumbing -------------------------------------------------------------------- */
+
+/* (N,C,H,W) float32 -> (N,H,W,Cpad) dtype, channels C..Cpad-1 zero.  Replaces the implicit
+ * layout the reference hands to its first Convolution (car/YOLO.py:381). */
+int yolo_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int Cpad, int dtype,
+                      void* stream);
+/* (N,H,W,C) uint8 -> (N,C,H,W) float32 / 255: cv_img_2_ndarray, yolo_gluon.py:335-357. */
+int yolo_image_u8_to_nchw(const unsigned char* img, float* y, int N, int H, int W, int C,
+                          void* stream);
+/* NHWC dtype -> NCHW float32 (debug / parity taps). */
+int yolo_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, int W, int dtype, void* stream);
+
+/* ---- convolution ----------------------------------------------------------------------- */
+
+/* Fused Conv(k in {1,3}, stride in {1,2}, pad k/2, no bias) + folded BN + LeakyReLU(slope)
+ * [+ residual add after the activation].  Replaces gluoncv _conv2d (Convolution + BatchNorm
+ * + LeakyReLU, call sites basic_yolo.py:20,24,26,118,121), DarknetBasicBlockV3's elementwise
+ * add, and YOLOOutput's Conv2D+bias+transpose+reshape (basic_yolo.py:98-103) when out_f32=1. */
+typedef struct yolo_conv_desc {
+    const void* x;         /* (N,H,W,Cin) dtype                                               */
+    const void* w_packed;  /* yolo_pack_conv_weights image                                    */
+    const float* scale;    /* [padded Cout] folded BN scale                                   */
+    const float* bias;     /* [padded Cout] folded BN bias / conv bias                        */
+    const void* residual;  /* (N,Ho,Wo,Cout) dtype or NULL; added after the activation        */
+    void* y;               /* (N,Ho,Wo,Cout) dtype, or float32 when out_f32                   */
+    int N, H, W, Cin, Cout;
+    int ksize, stride;
+    int dtype;             /* YOLO_F32 | YOLO_BF16: activations and weights                   */
+    int out_f32;           /* 1: y is float32 (head logits)                                   */
+    float slope;           /* LeakyReLU negative slope; 1.0f = linear                         */
+    long long y_batch_stride; /* elements between images in y; 0 = dense Ho*Wo*Cout           */
+    long long y_pixel_stride; /* elements between pixels in y; 0 = dense Cout                 */
+} yolo_conv_desc;
+
+int yolo_conv_fwd(const yolo_conv_desc* d, void* stream);
+/* Name of the kernel instantiation yolo_conv_fwd would launch for `d` (as rocprofv3 prints it);
+ * used by bench.py to attribute measured time to the dominant kernel.  Host-only, no launch. */
+int yolo_conv_kernel_name(const yolo_conv_desc* d, char* buf, int len);
+
+/* 2x nearest up-sample of `up` (N,H/2,W/2,C1) + channel concat with `route` (N,H,W,C2) ->
+ * (N,H,W,C1+C2), up-sampled channels first: gluoncv _upsample + F.concat, car/utils.py:92-93. */
+int yolo_upsample2x_concat(const void* up, const void* route, void* y, int N, int H, int W,
+                           int C1, int C2, int dtype, void* stream);
+
+/* ---- detection post-processing --------------------------------------------------------- */
+
+/* Anchor-grid description shared by decode / assignment (car/YOLO.py:112-155):
+ * nscale scales fine->coarse; scale i has grid (gh[i], gw[i]), stride step[i] px and A anchors
+ * anchors_hw[(i*A+a)*2+{0,1}] = (h, w) as fractions of the image. */
+typedef struct yolo_grid_desc {
+    int nscale, A;
+    int img_h, img_w;
+    int gh[4], gw[4], step[4];
+    float anchors_hw[4 * 8 * 2];
+} yolo_grid_desc;
+
+/* out (B, N, A, C) float32 logits, channel order [obj, ty, tx, th, tw, rot, cls...]
+ * (slice_point [1,3,5,6,C], car/v1/spec.yaml:6) -> rows (B, N*A, C) float32
+ * [sigmoid(obj), l, t, r, b, rot, cls...]: _yxhw_to_ltrb + the concat in predict,
+ * car/YOLO.py:552-579. */
+int yolo_decode(const float* out, float* rows, int B, int C, const yolo_grid_desc* g, void* stream);
+
+/* Per-image arg-max of sigmoid(obj) over N*A boxes (lowest index among ties, mxnet argmax),
+ * and the reference's output row [score, y, x, h, w, rot, cls...]: car/YOLO.py:581-597.
+ * `out` are the raw logits (B,N,A,C); pred (B,C) float32; best_idx (B) int32. */
+int yolo_predict_top1(const float* out, float* pred, int* best_idx, int B, int C,
+                      const yolo_grid_desc* g, void* stream);
+
+/* get_iou(predict, target, mode=2), yolo_gluon.py:127-168: boxes (n,4) ltrb vs one target
+ * [c,y,x,h,w] (5 floats, device) -> iou (n). */
+int yolo_iou_ltrb_vs_yxhw(const float* boxes, const float* target, float* iou, int n, void* stream);
+
+/* Greedy per-class NMS over decoded rows (not in the reference -- SURVEY.md S1; semantics =
+ * SURVEY App. A.8).  mode 0: score = sigmoid(obj), class-agnostic; mode 1: candidates are
+ * (box, class) pairs scored sigmoid(obj)*softmax(cls)_c, suppression within a class.
+ * kept (B, post_nms) int32 candidate ids in score order padded with -1; kept_scores same
+ * shape; kept_count (B).  workspace: yolo_nms_workspace_bytes(). */
+long long yolo_nms_workspace_bytes(int B, int nbox, int ncls, int mode, int topk);
+/* The two halves of yolo_nms, exposed so the score array can be inspected / injected:
+ * scores (B, nbox) [mode 0] or (B, nbox*ncls) [mode 1]; candidate id = box*cand_per_box + class. */
+int yolo_nms_scores(const float* rows, float* scores, int B, int nbox, int C, int mode, void* stream);
+int yolo_nms_from_scores(const float* rows, const float* scores, int B, int nbox, int C,
+                         int cand_per_box, float valid_thresh, float iou_thresh, int topk,
+                         int post_nms, int* kept, float* kept_scores, int* kept_count, void* stream);
+int yolo_nms(const float* rows, int B, int nbox, int C, int mode, float valid_thresh,
+             float iou_thresh, int topk, int post_nms, int* kept, float* kept_scores,
+             int* kept_count, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -174,26 +174,31 @@ def softmax(x, axis=-1):
     return (e / e.sum(axis=axis, keepdims=True)).astype(f32)
 
 
-def nms(rows, mode='class', valid_thresh=0.01, iou_thresh=0.45, topk=400, post_nms=100):
+def nms(rows, mode='class', valid_thresh=0.01, iou_thresh=0.45, topk=400, post_nms=100, scores=None):
     """Per-image greedy NMS over decoded rows (N*A, 6+ncls) (from decode_all).
     mode 'class': candidates = every (box, class) pair, score = sigmoid(obj)*softmax(cls)_c,
                   candidate id = box*ncls + c; suppression only within the same class.
     mode 'obj'  : candidates = boxes, score = sigmoid(obj), class-agnostic.
     Order: stable sort by score descending (ties -> lower candidate id first); drop score <
     valid_thresh; keep the first topk; greedy: j suppressed by an earlier kept i (same class)
-    iff IoU(i,j) > iou_thresh (strict); at most post_nms kept.  Returns (ids, scores)."""
+    iff IoU(i,j) > iou_thresh (strict); at most post_nms kept.  Returns (ids, scores).
+    `scores`: optional precomputed candidate scores (flat, candidate-id order) used instead of
+    recomputing them, so index parity can be checked on bit-identical inputs."""
     rows = np.asarray(rows, f32)
     nbox = rows.shape[0]
     if mode == 'obj':
-        scores = rows[:, 0].copy()
+        if scores is None:
+            scores = rows[:, 0].copy()
         cls_of = np.zeros(nbox, np.int64)
         box_of = np.arange(nbox)
     else:
-        prob = softmax(rows[:, 6:], axis=-1)
-        ncls = prob.shape[1]
-        scores = (rows[:, 0:1] * prob).astype(f32).reshape(-1)
+        ncls = rows.shape[1] - 6
+        if scores is None:
+            prob = softmax(rows[:, 6:], axis=-1)
+            scores = (rows[:, 0:1] * prob).astype(f32).reshape(-1)
         cls_of = np.tile(np.arange(ncls), nbox)
         box_of = np.repeat(np.arange(nbox), ncls)
+    scores = np.asarray(scores, f32).reshape(-1)
     cand = np.nonzero(scores >= f32(valid_thresh))[0]
     order = cand[np.argsort(-scores[cand], kind='stable')][:topk]
     kept = []

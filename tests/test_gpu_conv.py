@@ -1,0 +1,67 @@
+"""GPU parity of the implicit-GEMM conv kernel (through the C ABI) against a torch-CPU fp32
+restatement of Convolution + folded BatchNorm + LeakyReLU (+ residual)."""
+import numpy as np
+import pytest
+
+from util import run_conv, ref_conv
+
+pytestmark = pytest.mark.gpu
+
+# (N, Cin, H, W, Cout, k, stride, residual)
+CASES = [
+    (2, 8, 16, 24, 16, 3, 1, False),     # stem-like: Cin=8 (one partial K-chunk)
+    (2, 16, 16, 24, 32, 3, 2, False),    # stride-2 down-sample
+    (2, 32, 13, 13, 64, 3, 1, True),     # odd map, residual, batch-crossing tiles
+    (3, 64, 13, 13, 32, 1, 1, False),    # 1x1, TS=2 (bf16) / TS=4 (f32)
+    (2, 128, 26, 26, 256, 3, 1, True),   # 128x128 tile config, 4 K-chunks
+    (1, 256, 13, 13, 128, 1, 1, False),  # 1x1 with 8 chunks (bf16) -> TS=4
+    (2, 64, 26, 26, 128, 3, 2, False),   # stride 2 -> 13x13, 128-wide tile
+    (2, 96, 8, 8, 88, 1, 1, False),      # ragged Cout (not a tile multiple), Cin=96
+    (5, 16, 3, 5, 24, 3, 1, False),      # tiny map: many images per tile
+    (1, 32, 52, 52, 64, 3, 1, True),     # multi-strip? (Wo=52)
+    (1, 16, 40, 104, 32, 3, 1, False),   # wide map: several strips per row
+]
+
+
+def _mk(case, seed):
+    N, Cin, H, W, Cout, k, stride, res = case
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    r = rng.standard_normal((N, Cout, Ho, Wo)).astype(np.float32) if res else None
+    return x, w, scale, bias, r
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv_f32(lib, cuda, case):
+    x, w, scale, bias, r = _mk(case, 1)
+    y = run_conv(lib, cuda, x, w, scale, bias, case[6], 0.1, 'f32', residual=r)
+    ref = ref_conv(x, w, scale, bias, case[6], 0.1, residual=r)
+    assert not np.isnan(y).any()
+    np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-4)      # fp32 path: accumulation-order noise only
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv_bf16(lib, cuda, case):
+    x, w, scale, bias, r = _mk(case, 2)
+    y = run_conv(lib, cuda, x, w, scale, bias, case[6], 0.1, 'bf16', residual=r)
+    ref = ref_conv(x, w, scale, bias, case[6], 0.1, residual=r, bf16=True)
+    assert not np.isnan(y).any()
+    # same bf16-rounded operands, fp32 accumulate: differences are one bf16 ulp of the output at most
+    np.testing.assert_allclose(y, ref, rtol=1.6e-2, atol=2e-2)
+    assert np.mean(np.abs(y - ref) > 1e-3 * (1 + np.abs(ref))) < 0.02
+
+
+def test_conv_out_f32_linear(lib, cuda):
+    """Head-logit mode: bias only, linear, float32 output from bf16 activations."""
+    case = (2, 64, 13, 13, 90, 1, 1, False)
+    x, w, scale, bias, _ = _mk(case, 3)
+    scale[:] = 1.0
+    y = run_conv(lib, cuda, x, w, scale, bias, 1, 1.0, 'bf16', out_f32=True)
+    rb = lambda a: np.asarray(__import__('torch').from_numpy(a).to(__import__('torch').bfloat16).float())
+    ref = ref_conv(rb(x), rb(w), scale, bias, 1, 1.0)
+    np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-4)

@@ -1,0 +1,140 @@
+"""GPU parity of decode / top-1 / IoU / NMS (csrc/detect.hip through the C ABI) against the oracle.
+Index outputs must be bit-exact; float outputs within 1e-5 (libm exp differs by <=1 ulp)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import graph as og, detect as od
+
+pytestmark = pytest.mark.gpu
+
+SPEC = og.spec_d53()
+
+
+def _setup(size, B, seed, cuda, scale=1.0):
+    from yolo_amd.detect import Detector
+    steps = od.init_steps(SPEC['layers'], SPEC['all_anchors'])
+    area = od.init_area(size, steps)
+    rng = np.random.default_rng(seed)
+    outs = [(scale * rng.standard_normal((B, a, 3, 30))).astype(np.float32) for a in area]
+    syxhw = od.init_syxhw(size, steps, SPEC['all_anchors'])
+    det = Detector(SPEC, size, steps, device=cuda)
+    return det, outs, syxhw, steps
+
+
+@pytest.mark.parametrize('size', [(416, 416), (320, 512), (608, 608)])
+def test_decode_and_top1(cuda, size):
+    det, outs, syxhw, _ = _setup(size, 3, 11, cuda)
+    dev = [torch.from_numpy(o).to(cuda) for o in outs]
+    rows = det.decode(dev).cpu().numpy()
+    ref = od.decode_all(outs, SPEC['slice_point'], size, syxhw)
+    np.testing.assert_allclose(rows, ref, rtol=1e-5, atol=1e-6)
+    pred, idx = det.predict_device(dev)
+    rpred, ridx = od.predict(outs, SPEC['slice_point'], size, syxhw)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), ridx)          # bit-exact index
+    np.testing.assert_allclose(pred.cpu().numpy(), rpred, rtol=1e-5, atol=1e-6)
+    assert det.predict(dev).dtype == np.float32
+
+
+def test_top1_tie_lowest_index(cuda):
+    """mxnet argmax returns the lowest index among ties."""
+    det, outs, syxhw, _ = _setup((416, 416), 2, 12, cuda)
+    for o in outs:
+        o[..., 0] = -3.0
+    outs[0][0, 100, 1, 0] = 2.5
+    outs[1][0, 7, 2, 0] = 2.5            # same score, higher flat index
+    outs[2][1, 5, 0, 0] = 1.0
+    dev = [torch.from_numpy(o).to(cuda) for o in outs]
+    _, idx = det.predict_device(dev)
+    _, ridx = od.predict(outs, SPEC['slice_point'], (416, 416), syxhw)
+    assert idx.cpu().tolist() == ridx.tolist() == [100 * 3 + 1, (2704 + 676 + 5) * 3]
+
+
+def test_zero_logits_known_answer(cuda):
+    """logits 0 -> score 0.5, centre = cell + stride/2, size = anchor."""
+    det, outs, syxhw, steps = _setup((416, 416), 1, 13, cuda, scale=0.0)
+    rows = det.decode([torch.from_numpy(o).to(cuda) for o in outs]).cpu().numpy()[0]
+    assert np.all(rows[:, 0] == 0.5)
+    k = (2704 + 5 * 26 + 7) * 3 + 1       # scale 1 (stride 16), cell (5,7), anchor 1
+    l, t, r, b = rows[k, 1:5]
+    ah, aw = SPEC['all_anchors'][1][1]
+    np.testing.assert_allclose([(l + r) / 2, (t + b) / 2, r - l, b - t],
+                               [(7 * 16 + 8) / 416., (5 * 16 + 8) / 416., aw, ah], rtol=1e-5)
+
+
+def test_iou(cuda):
+    from yolo_amd.detect import get_iou
+    steps = od.init_steps(SPEC['layers'], SPEC['all_anchors'])
+    ltrb = od.get_default_ltrb((416, 416), steps, SPEC['all_anchors'])
+    target = np.asarray([3, 0.41, 0.52, 0.33, 0.27], np.float32)
+    got = get_iou(torch.from_numpy(ltrb).to(cuda), torch.from_numpy(target)).cpu().numpy()
+    ref = od.get_iou(ltrb, target, mode=2)
+    np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-7)
+    assert int(np.argmax(got.reshape(-1))) == int(np.argmax(ref.reshape(-1)))
+    # IoU(self) == 1, disjoint == 0
+    box = np.asarray([[0.1, 0.2, 0.4, 0.6]], np.float32)
+    t_self = np.asarray([0, 0.4, 0.25, 0.4, 0.3], np.float32)
+    assert abs(float(get_iou(torch.from_numpy(box).to(cuda), torch.from_numpy(t_self))[0, 0]) - 1.0) < 1e-6
+    t_far = np.asarray([0, 0.9, 0.9, 0.05, 0.05], np.float32)
+    assert float(get_iou(torch.from_numpy(box).to(cuda), torch.from_numpy(t_far))[0, 0]) == 0.0
+
+
+@pytest.mark.parametrize('mode', ['obj', 'class'])
+@pytest.mark.parametrize('size', [(416, 416), (608, 608)])
+def test_nms_indices_bit_exact(cuda, mode, size):
+    det, outs, syxhw, _ = _setup(size, 2, 21, cuda, scale=2.0)
+    dev = [torch.from_numpy(o).to(cuda) for o in outs]
+    rows = det.decode(dev)
+    scores = det.nms_scores(rows, mode)
+    kept, ks, cnt = det.nms(rows, mode, scores=scores)
+    rows_h, scores_h = rows.cpu().numpy(), scores.cpu().numpy()
+    for b in range(rows_h.shape[0]):
+        rk, rs = od.nms(rows_h[b], mode, scores=scores_h[b])
+        n = int(cnt[b])
+        assert n == len(rk)
+        assert kept[b, :n].cpu().tolist() == rk.tolist()                      # bit-exact kept ids
+        assert np.array_equal(ks[b, :n].cpu().numpy(), rs)
+        assert (kept[b, n:] == -1).all()
+    # scores themselves vs the oracle's own softmax / sigmoid
+    ref_rows = od.decode_all(outs, SPEC['slice_point'], size, syxhw)
+    _, rs0 = od.nms(ref_rows[0], mode)
+    np.testing.assert_allclose(ks[0, :len(rs0)].cpu().numpy(), rs0, rtol=2e-5)
+
+
+def test_nms_first_kept_is_top1(cuda):
+    """The one invariant the reference pins: kept[0] == argmax(sigmoid(obj))."""
+    det, outs, syxhw, _ = _setup((416, 416), 4, 22, cuda)
+    dev = [torch.from_numpy(o).to(cuda) for o in outs]
+    rows = det.decode(dev)
+    kept, _, _ = det.nms(rows, 'obj')
+    _, idx = det.predict_device(dev)
+    assert kept[:, 0].cpu().tolist() == idx.cpu().tolist()
+
+
+def test_nms_ties_and_few_candidates(cuda):
+    """Equal scores resolve to the lower candidate id; fewer valid candidates than topk; empty image."""
+    det, outs, syxhw, _ = _setup((416, 416), 3, 23, cuda)
+    for o in outs:
+        o[..., 0] = -20.0                      # sigmoid ~ 2e-9: below valid_thresh
+    outs[0][0, 10:40, :, 0] = 1.25             # image 0: 90 boxes with identical objectness
+    outs[0][1, 3, 0, 0] = 0.5                  # image 1: a single candidate
+    dev = [torch.from_numpy(o).to(cuda) for o in outs]
+    rows = det.decode(dev)
+    scores = det.nms_scores(rows, 'obj')
+    kept, ks, cnt = det.nms(rows, 'obj', scores=scores)
+    rows_h, scores_h = rows.cpu().numpy(), scores.cpu().numpy()
+    for b in range(3):
+        rk, _ = od.nms(rows_h[b], 'obj', scores=scores_h[b])
+        assert kept[b, :int(cnt[b])].cpu().tolist() == rk.tolist()
+    assert int(cnt[1]) == 1 and int(cnt[2]) == 0
+    # many exact ties across a topk boundary
+    kept2, _, cnt2 = det.nms(rows, 'obj', topk=50, post_nms=50, iou_thresh=0.99, scores=scores)
+    rk2, _ = od.nms(rows_h[0], 'obj', topk=50, post_nms=50, iou_thresh=0.99, scores=scores_h[0])
+    assert kept2[0, :int(cnt2[0])].cpu().tolist() == rk2.tolist()
+
+
+def test_cv_img_2_ndarray(cuda):
+    from yolo_amd.detect import cv_img_2_ndarray
+    img = np.random.default_rng(5).integers(0, 256, (246, 560, 3), dtype=np.uint8)   # licence_plate/test.jpg size
+    got = cv_img_2_ndarray(img, cuda).cpu().numpy()
+    np.testing.assert_array_equal(got, od.cv_img_2_ndarray(img))

@@ -1,0 +1,66 @@
+"""Test helpers: drive the C ABI on torch-owned device buffers and compare with the oracle."""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from yolo_amd import lib as L
+
+TDT = {'f32': torch.float32, 'bf16': torch.bfloat16}
+LDT = {'f32': L.F32, 'bf16': L.BF16}
+
+
+def to_nhwc(x_nchw, dtype, dev):
+    return torch.from_numpy(np.ascontiguousarray(x_nchw)).to(dev).permute(0, 2, 3, 1).contiguous().to(TDT[dtype])
+
+
+def from_nhwc(t):
+    return t.float().permute(0, 3, 1, 2).contiguous().cpu().numpy()
+
+
+def run_conv(lib, dev, x, w, scale, bias, stride, slope, dtype, residual=None, out_f32=False):
+    """x (N,Cin,H,W) f32 ndarray; w (Cout,Cin,k,k); scale/bias (Cout,) -> y (N,Cout,Ho,Wo) f32 ndarray."""
+    N, Cin, H, W = x.shape
+    Cout, _, k, _ = w.shape
+    st = torch.cuda.current_stream().cuda_stream
+    dt = LDT[dtype]
+    xd = to_nhwc(x, dtype, dev)
+    wd = torch.from_numpy(w).to(dev)
+    wp = torch.empty(lib.yolo_packed_weight_bytes(Cout, Cin, k, dt), dtype=torch.uint8, device=dev)
+    L.check(lib.yolo_pack_conv_weights(wd.data_ptr(), wp.data_ptr(), Cout, Cin, k, dt, st), 'pack')
+    cp = lib.yolo_padded_channels(Cout)
+    sc = torch.zeros(cp, device=dev); sc[:Cout] = torch.from_numpy(scale).to(dev)
+    bi = torch.zeros(cp, device=dev); bi[:Cout] = torch.from_numpy(bias).to(dev)
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y = torch.full((N, Ho, Wo, Cout), float('nan'), dtype=torch.float32 if out_f32 else TDT[dtype], device=dev)
+    rd = to_nhwc(residual, dtype, dev) if residual is not None else None
+    d = L.ConvDesc()
+    d.x, d.w_packed, d.scale, d.bias = xd.data_ptr(), wp.data_ptr(), sc.data_ptr(), bi.data_ptr()
+    d.residual = rd.data_ptr() if rd is not None else None
+    d.y = y.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride = N, H, W, Cin, Cout, k, stride
+    d.dtype, d.out_f32, d.slope = dt, int(out_f32), slope
+    rc = lib.yolo_conv_fwd(C.byref(d), st)
+    assert rc == 0, 'yolo_conv_fwd rc=%d' % rc
+    torch.cuda.synchronize()
+    return from_nhwc(y)
+
+
+def ref_conv(x, w, scale, bias, stride, slope, residual=None, bf16=False):
+    """Oracle for one fused conv: fp32 conv -> *scale+bias -> leaky -> +residual (bf16: operands and
+    result rounded to bf16 where the HIP path rounds)."""
+    xt, wt = torch.from_numpy(x), torch.from_numpy(w)
+    rb = lambda t: t.to(torch.bfloat16).float()
+    if bf16:
+        xt, wt = rb(xt), rb(wt)
+    y = F.conv2d(xt, wt, None, stride=stride, padding=w.shape[2] // 2)
+    y = y * torch.from_numpy(scale).view(1, -1, 1, 1) + torch.from_numpy(bias).view(1, -1, 1, 1)
+    y = torch.where(y > 0, y, y * slope)
+    if residual is not None:
+        r = torch.from_numpy(residual)
+        y = y + (rb(r) if bf16 else r)
+    if bf16:
+        y = rb(y)
+    return y.numpy()

@@ -1,0 +1,459 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): Conv(k=1|3, stride 1|2, pad k/2) + folded BN +
+// LeakyReLU (+ residual), NHWC activations, MFMA 32x32x16 bf16 / 32x32x2 f32.
+//
+// Replaces gluoncv _conv2d = Convolution + BatchNorm + LeakyReLU (call sites
+// yolo_modules/basic_yolo.py:20,24,26,118,121), DarknetBasicBlockV3's residual add, and
+// YOLOOutput's Conv2D + bias + transpose + reshape (basic_yolo.py:98-103).
+//
+// GEMM view: D[cout][pixel] = sum_k Wp[cout][k] * X[k][pixel], k = (tap, cin).
+//   A operand = packed weights, B operand = activations, both K-contiguous in LDS as rows of
+//   one 64-byte K-chunk (32 bf16 / 16 f32 channels), 16-byte units XOR-swizzled by
+//   (row>>2)&3 so ds_read_b128 of 32 consecutive rows is bank-conflict free.
+//   D rows = cout, so each lane ends with 4 consecutive output channels of one pixel
+//   -> 8/16-byte NHWC stores.
+// No im2col: for a 3x3 conv the block stages ONE zero-padded halo tile of the input per K-chunk
+//   ("padded strip" image: rows of the stacked batch with a zero row between images and zero
+//   columns at the image edges) and the 9 taps read it at uniform slot offsets kh*PW+kw.
+#include "common.h"
+#include <stdio.h>
+
+struct ConvArgs {
+    const char* x;
+    const char* wp;
+    const float* scale;
+    const float* bias;
+    const char* res;
+    char* y;
+    int N, H, W, Cin, Ho, Wo, Cout, Cout_pad;
+    int TWt, nstrips, tiles_per_strip, PW, total_i;
+    int nchunks, tiles_c;
+    int out_f32;
+    float slope;
+    long long y_bs, y_ps;
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<__bf16> {
+    static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                    __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Frag<float> {
+    // 16 bytes = 4 f32 per lane half -> four 32x32x2 steps; step s contracts k = {s, 4+s} of
+    // the 8 channels in this 32-byte sub-chunk (same mapping on A and B, so any order is exact).
+    static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+
+// KS: kernel size; S: stride; block = WAVES_P x WAVES_C waves (=4), wave tile = NI*32 pixels x
+// MI*32 couts; XSLOTS: LDS input slots (64 B each) per plane; TS: K-steps ("taps") per barrier
+// round: the 3 kw taps of one kh row for KS=3, TS consecutive K-chunks for KS=1.
+template <typename T, int KS, int S, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int TS>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+    static_assert(WAVES_P * WAVES_C == 4, "256 threads");
+    static_assert(KS == 1 || TS == 3, "3x3: one kh row per step");
+    constexpr int BP = WAVES_P * NI * 32;
+    constexpr int BC = WAVES_C * MI * 32;
+    constexpr int XPLANES = (KS == 1) ? TS : 1;
+    constexpr int X_UNITS = XPLANES * XSLOTS * 4;
+    constexpr int W_UNITS = TS * BC * 4;
+    constexpr int XP = (X_UNITS + 255) / 256;
+    constexpr int WP = (W_UNITS + 255) / 256;
+    constexpr int KSTEPS = (KS == 3) ? 3 : 1;
+    constexpr int NTAP = (KS == 3) ? 9 : 1;
+    static_assert(KS == 3 || XSLOTS == BP, "1x1: one slot per pixel");
+
+    __shared__ __attribute__((aligned(16))) char smem[(X_UNITS + W_UNITS) * 16];
+    char* Xl = smem;
+    char* Wl = smem + X_UNITS * 16;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wave_p = wave % WAVES_P, wave_c = wave / WAVES_P;
+
+    const int bid = blockIdx.x;
+    const int tile_c = bid % a.tiles_c;
+    const int tile_p = bid / a.tiles_c;
+    const int strip = tile_p / a.tiles_per_strip;
+    const int i0 = (tile_p - strip * a.tiles_per_strip) * BP;
+    const int co0 = tile_c * BC;
+    const int H = a.H, W = a.W, Ho = a.Ho, Wo = a.Wo, TWt = a.TWt, PW = a.PW;
+    const int row_bytes = a.Cin * (int)sizeof(T);
+
+    // ---- geometry of the staged input tile ----------------------------------------------
+    int Rin_lo = 0, HS = XSLOTS, x0 = 0;
+    if constexpr (KS == 3) {
+        const int i_last = min(i0 + BP, a.total_i) - 1;
+        const int r_first = i0 / TWt, r_last = i_last / TWt;
+        const int n_f = r_first / Ho, n_l = r_last / Ho;
+        Rin_lo = n_f * (H + 1) + (r_first - n_f * Ho) * S;
+        const int Rin_hi = n_l * (H + 1) + (r_last - n_l * Ho) * S + 2;
+        HS = (Rin_hi - Rin_lo + 1) * PW;
+        x0 = strip * TWt * S - 1;
+    }
+
+    // ---- per-thread staging descriptors -------------------------------------------------
+    long long xoff[XP];
+    int xlp[XP];
+#pragma unroll
+    for (int j = 0; j < XP; ++j) {
+        const int u = tid + j * 256;
+        if constexpr (KS == 3) {
+            const int slot = u >> 2, part = u & 3;
+            bool valid = slot < HS && u < X_UNITS;
+            const int rr = slot / PW;
+            const int cc = slot - rr * PW;
+            const int Rr = Rin_lo + rr;
+            const int n = Rr / (H + 1);
+            const int yy = Rr - n * (H + 1) - 1;
+            const int xx = x0 + cc;
+            valid = valid && yy >= 0 && n < a.N && xx >= 0 && xx < W;
+            xoff[j] = valid ? ((long long)(n * H + yy) * W + xx) * row_bytes : -1;
+            xlp[j] = (part ^ ((slot >> 2) & 3)) * 16;
+        } else {
+            const int plane = u / (XSLOTS * 4);
+            const int rem = u - plane * (XSLOTS * 4);
+            const int slot = rem >> 2, part = rem & 3;
+            const int i = i0 + slot;
+            const bool valid = (i < a.total_i) && (u < X_UNITS);
+            xoff[j] = valid ? (long long)i * row_bytes : -1;
+            xlp[j] = plane * 64 + (part ^ ((slot >> 2) & 3)) * 16;
+        }
+    }
+
+    // ---- per-lane MFMA operand addresses --------------------------------------------------
+    int addrX[NI][NTAP];
+    long long yoff[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int i = i0 + (wave_p * NI + ni) * 32 + l31;
+        const bool ok = i < a.total_i;
+        const int ii = ok ? i : i0;
+        int n, pix;
+        if constexpr (KS == 3) {
+            const int r = ii / TWt;
+            const int tx = ii - r * TWt;
+            n = r / Ho;
+            const int oy = r - n * Ho;
+            const int slot00 = (n * (H + 1) + oy * S - Rin_lo) * PW + tx * S;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int slot = slot00 + (t / 3) * PW + (t % 3);
+                addrX[ni][t] = slot * 64 + ((h ^ ((slot >> 2) & 3)) << 4);
+            }
+            pix = oy * Wo + strip * TWt + tx;
+        } else {
+            const int slot = ii - i0;
+            addrX[ni][0] = slot * 64 + ((h ^ ((slot >> 2) & 3)) << 4);
+            n = ii / (Ho * Wo);
+            pix = ii - n * (Ho * Wo);
+        }
+        yoff[ni] = ok ? (long long)n * a.y_bs + (long long)pix * a.y_ps : -1;
+    }
+    const int aoff0 = (wave_c * MI * 32 + l31) * 64 + ((h ^ ((l31 >> 2) & 3)) << 4);
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    uint4 xr[XP], wr[WP];
+#define LOAD_X(chunk_base)                                                                      \
+    _Pragma("unroll") for (int j = 0; j < XP; ++j) {                                            \
+        const int byte = (chunk_base) * 64 + xlp[j];                                            \
+        uint4 v = make_uint4(0, 0, 0, 0);                                                       \
+        if (xoff[j] >= 0 && byte < row_bytes) v = *(const uint4*)(a.x + xoff[j] + byte);        \
+        xr[j] = v;                                                                              \
+    }
+    // plane0 = first (chunk*taps + tap) plane of the packed weights for the step
+    const char* wsrc = a.wp + (long long)co0 * 64 + tid * 16;
+    const long long wplane = (long long)a.Cout_pad * 64;
+#define LOAD_W(plane0)                                                                          \
+    _Pragma("unroll") for (int j = 0; j < WP; ++j) {                                            \
+        const int u = tid + j * 256;                                                            \
+        const int t = (j * 256) / (BC * 4);                                                     \
+        uint4 v = make_uint4(0, 0, 0, 0);                                                       \
+        if (W_UNITS % 256 == 0 || u < W_UNITS)                                                  \
+            v = *(const uint4*)(wsrc + ((plane0) + t) * wplane + (j * 256 - t * BC * 4) * 16);  \
+        wr[j] = v;                                                                              \
+    }
+    static_assert((BC * 4) % 256 == 0 || 256 % (BC * 4) == 0, "tap index must be uniform per pass");
+
+    const int nouter = (KS == 3) ? a.nchunks : a.nchunks / TS;
+    LOAD_X(0);
+    LOAD_W(0);
+    for (int c = 0; c < nouter; ++c) {
+#pragma unroll
+        for (int kh = 0; kh < KSTEPS; ++kh) {
+            __syncthreads();
+            if (kh == 0) {
+#pragma unroll
+                for (int j = 0; j < XP; ++j) {
+                    const int u = tid + j * 256;
+                    if (X_UNITS % 256 == 0 || u < X_UNITS) *(uint4*)(Xl + u * 16) = xr[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < WP; ++j) {
+                const int u = tid + j * 256;
+                if (W_UNITS % 256 == 0 || u < W_UNITS) *(uint4*)(Wl + u * 16) = wr[j];
+            }
+            __syncthreads();
+            // prefetch the next step into registers while this one computes
+            if (kh + 1 < KSTEPS) {
+                LOAD_W((c * KSTEPS + kh + 1) * TS);
+            } else if (c + 1 < nouter) {
+                LOAD_W((c + 1) * KSTEPS * TS);
+                LOAD_X((KS == 3) ? (c + 1) : (c + 1) * TS);
+            }
+#pragma unroll
+            for (int t = 0; t < TS; ++t) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    uint4 af[MI], bf[NI];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        af[mi] = *(const uint4*)(Wl + t * BC * 64 + mi * 2048 + (aoff0 ^ (ks * 32)));
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const int ax = (KS == 3) ? addrX[ni][kh * 3 + t] : addrX[ni][0] + t * XSLOTS * 64;
+                        bf[ni] = *(const uint4*)(Xl + (ax ^ (ks * 32)));
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) Frag<T>::mma(af[mi], bf[ni], acc[mi][ni]);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: folded BN, LeakyReLU, residual, store NHWC ------------------------------
+    const float slope = a.slope;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        if (yoff[ni] < 0) continue;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = co0 + (wave_c * MI + mi) * 32 + 8 * g + 4 * h;
+                if (co >= a.Cout) continue;
+                const f32x4 sc = *(const f32x4*)(a.scale + co);
+                const f32x4 bi = *(const f32x4*)(a.bias + co);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[mi][ni][4 * g + e] * sc[e] + bi[e];
+                    v[e] = t > 0.f ? t : t * slope;
+                }
+                const long long o = yoff[ni] + co;
+                if (a.out_f32) {
+                    float* yp = (float*)a.y + o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < a.Cout) yp[e] = v[e];
+                } else if constexpr (sizeof(T) == 2) {
+                    if (a.res) {
+                        const uint2 rv = *(const uint2*)((const uint16_t*)a.res + o);
+                        v[0] += bf16_bits_to_f32(rv.x & 0xffffu);
+                        v[1] += bf16_bits_to_f32(rv.x >> 16);
+                        v[2] += bf16_bits_to_f32(rv.y & 0xffffu);
+                        v[3] += bf16_bits_to_f32(rv.y >> 16);
+                    }
+                    *(uint2*)((uint16_t*)a.y + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                } else {
+                    if (a.res) {
+                        const f32x4 rv = *(const f32x4*)((const float*)a.res + o);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                    }
+                    f32x4 ov = {v[0], v[1], v[2], v[3]};
+                    *(f32x4*)((float*)a.y + o) = ov;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Host side: tile selection and launch
+// ------------------------------------------------------------------------------------------
+constexpr int XSLOTS_S1 = 384;
+constexpr int XSLOTS_S2 = 832;
+
+// Worst-case number of LDS slots for a BP-pixel tile on strips of width d.
+static int halo_slots(int BP, int d, int Ho, int H, int S, long long total_rows) {
+    long long nro = (BP - 1 + d - 1) / d + 1;
+    if (nro > total_rows) nro = total_rows;
+    const long long nb = (nro - 1 + Ho - 1) / Ho;
+    const int extra = H + 1 - Ho * S;
+    const long long NR = (long long)S * (nro - 1) + 3 + nb * (extra > 0 ? extra : 0);
+    const int PW = (d - 1) * S + 3;
+    return (int)(NR * PW);
+}
+
+// `name` != nullptr: write the kernel instantiation that WOULD run (rocprofv3's demangled name) and
+// do not launch.
+struct NameOut { char* buf; int len; };
+
+template <typename T, int KS, int S, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int TS>
+static int launch_cfg(ConvArgs& a, hipStream_t st, const NameOut* name) {
+    constexpr int BP = WAVES_P * NI * 32, BC = WAVES_C * MI * 32;
+    if (name) {
+        snprintf(name->buf, name->len, "void conv_igemm_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d>(ConvArgs)",
+                 sizeof(T) == 2 ? "__bf16" : "float", KS, S, WAVES_P, WAVES_C, MI, NI, XSLOTS, TS);
+        return YOLO_OK;
+    }
+    if (KS == 3) {
+        int best = -1, best_hs = 1 << 30;
+        for (int d = 1; d <= a.Wo; ++d) {
+            if (a.Wo % d) continue;
+            const int hs = halo_slots(BP, d, a.Ho, a.H, S, (long long)a.N * a.Ho);
+            if (hs <= XSLOTS && hs <= best_hs) { best = d; best_hs = hs; }
+        }
+        if (best < 0) return YOLO_EUNSUPPORTED;
+        a.TWt = best;
+        a.PW = (best - 1) * S + 3;
+    } else {
+        a.TWt = a.Wo;
+        a.PW = a.Wo;
+    }
+    a.nstrips = a.Wo / a.TWt;
+    const long long tot = (long long)a.N * a.Ho * a.TWt;
+    if (tot > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
+    a.total_i = (int)tot;
+    a.tiles_per_strip = (a.total_i + BP - 1) / BP;
+    a.tiles_c = (a.Cout + BC - 1) / BC;
+    const long long grid = (long long)a.nstrips * a.tiles_per_strip * a.tiles_c;
+    if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
+    hipLaunchKernelGGL((conv_igemm_kernel<T, KS, S, WAVES_P, WAVES_C, MI, NI, XSLOTS, TS>), dim3((unsigned)grid),
+                       dim3(256), 0, st, a);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}
+
+template <typename T, int WAVES_P, int WAVES_C, int MI, int NI>
+static int launch_shape(ConvArgs& a, int ks, int stride, hipStream_t st, const NameOut* nm) {
+    constexpr int BP = WAVES_P * NI * 32;
+    if (ks == 3 && stride == 1) return launch_cfg<T, 3, 1, WAVES_P, WAVES_C, MI, NI, XSLOTS_S1, 3>(a, st, nm);
+    if (ks == 3 && stride == 2) return launch_cfg<T, 3, 2, WAVES_P, WAVES_C, MI, NI, XSLOTS_S2, 3>(a, st, nm);
+    if (ks == 1 && stride == 1) {
+        if (a.nchunks % 4 == 0) return launch_cfg<T, 1, 1, WAVES_P, WAVES_C, MI, NI, BP, 4>(a, st, nm);
+        if (a.nchunks % 2 == 0) return launch_cfg<T, 1, 1, WAVES_P, WAVES_C, MI, NI, BP, 2>(a, st, nm);
+        return launch_cfg<T, 1, 1, WAVES_P, WAVES_C, MI, NI, BP, 1>(a, st, nm);
+    }
+    return YOLO_EUNSUPPORTED;
+}
+
+template <typename T>
+static int launch_dtype(ConvArgs& a, int ks, int stride, hipStream_t st, const NameOut* nm) {
+    if (a.Cout > 64) return launch_shape<T, 2, 2, 2, 2>(a, ks, stride, st, nm);   // 128 px x 128 cout
+    return launch_shape<T, 2, 2, 1, 2>(a, ks, stride, st, nm);                    // 128 px x  64 cout
+}
+
+static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* nm);
+
+extern "C" int yolo_conv_fwd(const yolo_conv_desc* d, void* stream) { return conv_dispatch(d, stream, nullptr); }
+
+extern "C" int yolo_conv_kernel_name(const yolo_conv_desc* d, char* buf, int len) {
+    if (!buf || len < 16) return YOLO_EINVAL;
+    NameOut nm{buf, len};
+    return conv_dispatch(d, nullptr, &nm);
+}
+
+static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* nm) {
+    if (!d || !d->x || !d->w_packed || !d->scale || !d->bias || !d->y) return YOLO_EINVAL;
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return YOLO_EINVAL;
+    if (d->ksize != 1 && d->ksize != 3) return YOLO_EUNSUPPORTED;
+    if (d->stride != 1 && d->stride != 2) return YOLO_EUNSUPPORTED;
+    if (d->ksize == 1 && d->stride != 1) return YOLO_EUNSUPPORTED;
+    if (d->dtype != YOLO_F32 && d->dtype != YOLO_BF16) return YOLO_EINVAL;
+    const int es = elem_size(d->dtype);
+    if ((d->Cin * es) % 16) return YOLO_EUNSUPPORTED;                 // 16-byte K units
+    if (!d->out_f32 && (d->Cout % 4)) return YOLO_EUNSUPPORTED;       // 4-channel store groups
+    const int pad = d->ksize / 2;
+    ConvArgs a;
+    a.x = (const char*)d->x;
+    a.wp = (const char*)d->w_packed;
+    a.scale = d->scale;
+    a.bias = d->bias;
+    a.res = (const char*)d->residual;
+    a.y = (char*)d->y;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
+    a.Ho = (d->H + 2 * pad - d->ksize) / d->stride + 1;
+    a.Wo = (d->W + 2 * pad - d->ksize) / d->stride + 1;
+    a.Cout_pad = round_up(d->Cout, YOLO_COUT_PAD);
+    a.nchunks = (d->Cin * es + 63) / 64;
+    a.out_f32 = d->out_f32;
+    a.slope = d->slope;
+    a.y_ps = d->y_pixel_stride ? d->y_pixel_stride : d->Cout;
+    a.y_bs = d->y_batch_stride ? d->y_batch_stride : (long long)a.Ho * a.Wo * a.y_ps;
+    if (a.res && (d->y_pixel_stride || d->y_batch_stride || d->out_f32)) return YOLO_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == YOLO_BF16) return launch_dtype<__bf16>(a, d->ksize, d->stride, st, nm);
+    return launch_dtype<float>(a, d->ksize, d->stride, st, nm);
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight packing: OIHW f32 -> [chunk][tap][Cout_pad][64 B], 16-byte units XOR-swizzled
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin,
+                                    int ks, int Cout_pad, int nchunks) {
+    constexpr int CH = 64 / sizeof(T);       // channels per chunk
+    constexpr int UE = 16 / sizeof(T);       // elements per 16-byte unit
+    const long long total = (long long)nchunks * ks * ks * Cout_pad * CH;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx % CH);
+        long long r = idx / CH;
+        const int co = (int)(r % Cout_pad);
+        r /= Cout_pad;
+        const int tap = (int)(r % (ks * ks));
+        const int chunk = (int)(r / (ks * ks));
+        const int punit = e / UE, within = e % UE;
+        const int lunit = punit ^ ((co >> 2) & 3);            // physical unit holds this logical unit
+        const int ci = chunk * CH + lunit * UE + within;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) v = w[((long long)(co * Cin + ci) * ks + tap / ks) * ks + tap % ks];
+        if constexpr (sizeof(T) == 2)
+            ((uint16_t*)out)[idx] = (uint16_t)f32_to_bf16_bits(v);
+        else
+            out[idx] = v;
+    }
+}
+
+extern "C" long long yolo_packed_weight_bytes(int Cout, int Cin, int ksize, int dtype) {
+    if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return YOLO_EINVAL;
+    const int nchunks = (Cin * elem_size(dtype) + 63) / 64;
+    return (long long)nchunks * ksize * ksize * round_up(Cout, YOLO_COUT_PAD) * 64;
+}
+
+extern "C" int yolo_pack_conv_weights(const float* w_oihw, void* packed, int Cout, int Cin, int ksize,
+                                      int dtype, void* stream) {
+    if (!w_oihw || !packed) return YOLO_EINVAL;
+    const long long bytes = yolo_packed_weight_bytes(Cout, Cin, ksize, dtype);
+    if (bytes < 0) return (int)bytes;
+    const int Cout_pad = round_up(Cout, YOLO_COUT_PAD);
+    const int nchunks = (Cin * elem_size(dtype) + 63) / 64;
+    const long long total = bytes / elem_size(dtype);
+    const int grid = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+    if (dtype == YOLO_BF16)
+        hipLaunchKernelGGL(pack_weights_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                           (__bf16*)packed, Cout, Cin, ksize, Cout_pad, nchunks);
+    else
+        hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                           (float*)packed, Cout, Cin, ksize, Cout_pad, nchunks);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}

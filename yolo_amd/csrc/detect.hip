@@ -1,0 +1,434 @@
+// Detection post-processing for gfx950: anchor decode, per-image arg-max (top-1), IoU, greedy NMS.
+// Compiled with -ffp-contract=off so fp32 arithmetic follows the reference's op-by-op NDArray
+// evaluation (no fused multiply-add), which is what makes index parity exact.
+#include "common.h"
+#include <float.h>
+
+struct GridDev {
+    int nscale, A, img_h, img_w;
+    int gw[4], step[4], cum[5];   // cum[i] = first box index of scale i
+    float ah[4][8], aw[4][8];
+};
+
+static int make_grid(const yolo_grid_desc* g, GridDev& d, int* nbox) {
+    if (!g || g->nscale < 1 || g->nscale > 4 || g->A < 1 || g->A > 8) return YOLO_EINVAL;
+    d.nscale = g->nscale; d.A = g->A; d.img_h = g->img_h; d.img_w = g->img_w;
+    int cum = 0;
+    for (int i = 0; i < 4; ++i) {
+        d.cum[i] = cum;
+        if (i < g->nscale) {
+            if (g->gh[i] <= 0 || g->gw[i] <= 0 || g->step[i] <= 0) return YOLO_EINVAL;
+            d.gw[i] = g->gw[i]; d.step[i] = g->step[i];
+            cum += g->gh[i] * g->gw[i] * g->A;
+            for (int a = 0; a < g->A; ++a) {
+                d.ah[i][a] = g->anchors_hw[(i * g->A + a) * 2 + 0];
+                d.aw[i][a] = g->anchors_hw[(i * g->A + a) * 2 + 1];
+            }
+        } else {
+            d.gw[i] = 1; d.step[i] = 1;
+        }
+    }
+    d.cum[4] = cum;
+    for (int i = g->nscale; i < 4; ++i) d.cum[i] = cum;
+    *nbox = cum;
+    return YOLO_OK;
+}
+
+__device__ __forceinline__ float sigmoidf_ref(float x) { return 1.f / (1.f + expf(-x)); }
+
+// Per-box constants of car/YOLO.py:123-155: s (stride px), y, x (cell origin px), h, w (anchor).
+__device__ __forceinline__ void box_consts(const GridDev& g, int k, float& s, float& y, float& x, float& h,
+                                           float& w) {
+    int i = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (q < g.nscale && k >= g.cum[q]) i = q;
+    const int rel = k - g.cum[i];
+    const int cell = rel / g.A, a = rel - cell * g.A;
+    const int row = cell / g.gw[i], col = cell - row * g.gw[i];
+    s = (float)g.step[i];
+    y = (float)(row * g.step[i]);
+    x = (float)(col * g.step[i]);
+    h = g.ah[i][a];
+    w = g.aw[i][a];
+}
+
+// _yxhw_to_ltrb, car/YOLO.py:552-566 (one coordinate pair at a time).
+__device__ __forceinline__ void decode_axis(float tc, float tsz, float s, float origin, float img, float anchor,
+                                            float& lo, float& hi) {
+    const float c = (sigmoidf_ref(tc) * s + origin) / img;
+    const float sz = expf(tsz) * anchor;
+    const float half = sz / 2.f;
+    lo = c - half;
+    hi = c + half;
+}
+
+// ---- decode: (B,N,A,C) logits -> rows [sigmoid(obj), l,t,r,b, rot, cls...] -------------------
+__global__ void decode_kernel(const float* __restrict__ out, float* __restrict__ rows, int C, int nbox,
+                              long long total, GridDev g) {
+    const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long long box = idx / C;
+    const int c = (int)(idx - box * C);
+    float v = out[idx];
+    if (c == 0) {
+        v = sigmoidf_ref(v);
+    } else if (c <= 4) {
+        const int k = (int)(box % nbox);
+        float s, y, x, h, w;
+        box_consts(g, k, s, y, x, h, w);
+        const float* p = out + box * C;
+        float lo, hi;
+        if (c == 1 || c == 3) decode_axis(p[2], p[4], s, x, (float)g.img_w, w, lo, hi);   // l / r from tx, tw
+        else                  decode_axis(p[1], p[3], s, y, (float)g.img_h, h, lo, hi);   // t / b from ty, th
+        v = (c <= 2) ? lo : hi;
+    }
+    rows[idx] = v;
+}
+
+extern "C" int yolo_decode(const float* out, float* rows, int B, int C, const yolo_grid_desc* g, void* stream) {
+    if (!out || !rows || B <= 0 || C < 6) return YOLO_EINVAL;
+    GridDev d; int nbox;
+    int rc = make_grid(g, d, &nbox);
+    if (rc) return rc;
+    const long long total = (long long)B * nbox * C;
+    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out,
+                       rows, C, nbox, total, d);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}
+
+// ---- top-1: arg-max of sigmoid(obj), first index among ties (car/YOLO.py:581-597) ------------
+__device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+__global__ __launch_bounds__(1024) void predict_top1_kernel(const float* __restrict__ out, float* __restrict__ pred,
+                                                            int* __restrict__ best_idx, int C, int nbox, GridDev g) {
+    const int b = blockIdx.x;
+    const float* o = out + (long long)b * nbox * C;
+    float bv = -FLT_MAX; int bi = 0x7fffffff;
+    for (int k = threadIdx.x; k < nbox; k += blockDim.x) {
+        const float s = sigmoidf_ref(o[(long long)k * C]);
+        if (s > bv) { bv = s; bi = k; }          // ascending k per thread: first max wins
+    }
+    // wavefront (64-lane) reduction, then one value per wave through LDS
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(bv, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        argmax_combine(bv, bi, ov, oi);
+    }
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+    __syncthreads();
+    if (wave == 0) {
+        const int nw = blockDim.x >> 6;
+        bv = lane < nw ? sv[lane] : -FLT_MAX;
+        bi = lane < nw ? si[lane] : 0x7fffffff;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            argmax_combine(bv, bi, ov, oi);
+        }
+        if (lane == 0) { si[0] = bi; sv[0] = bv; }
+    }
+    __syncthreads();
+    const int k = si[0];
+    const float* p = o + (long long)k * C;
+    float* q = pred + (long long)b * C;
+    if (threadIdx.x == 0) {
+        best_idx[b] = k;
+        float s, y, x, h, w;
+        box_consts(g, k, s, y, x, h, w);
+        float l, r, t, bt;
+        decode_axis(p[2], p[4], s, x, (float)g.img_w, w, l, r);
+        decode_axis(p[1], p[3], s, y, (float)g.img_h, h, t, bt);
+        q[0] = sv[0];
+        q[1] = (t + bt) / 2.f;     // y
+        q[2] = (l + r) / 2.f;      // x
+        q[3] = bt - t;             // h
+        q[4] = r - l;              // w
+    }
+    for (int c = 5 + threadIdx.x; c < C; c += blockDim.x) q[c] = p[c];
+}
+
+extern "C" int yolo_predict_top1(const float* out, float* pred, int* best_idx, int B, int C,
+                                 const yolo_grid_desc* g, void* stream) {
+    if (!out || !pred || !best_idx || B <= 0 || C < 6) return YOLO_EINVAL;
+    GridDev d; int nbox;
+    int rc = make_grid(g, d, &nbox);
+    if (rc) return rc;
+    hipLaunchKernelGGL(predict_top1_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, out, pred, best_idx, C,
+                       nbox, d);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}
+
+// ---- get_iou(predict, target, mode=2), yolo_gluon.py:127-168 ---------------------------------
+__global__ void iou_kernel(const float* __restrict__ boxes, const float* __restrict__ target,
+                           float* __restrict__ iou, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float ty = target[1], tx = target[2], th = target[3], tw = target[4];
+    const float l2 = tx - tw / 2.f, t2 = ty - th / 2.f, r2 = tx + tw / 2.f, b2 = ty + th / 2.f;
+    const float4 p = ((const float4*)boxes)[i];     // l,t,r,b
+    const float iw = fmaxf(fminf(r2, p.z) - fmaxf(l2, p.x), 0.f);
+    const float ih = fmaxf(fminf(b2, p.w) - fmaxf(t2, p.y), 0.f);
+    const float inter = iw * ih;
+    const float pa = (p.z - p.x) * (p.w - p.y);
+    const float ta = th * tw;
+    iou[i] = inter / (pa + ta - inter);
+}
+
+extern "C" int yolo_iou_ltrb_vs_yxhw(const float* boxes, const float* target, float* iou, int n, void* stream) {
+    if (!boxes || !target || !iou || n <= 0) return YOLO_EINVAL;
+    hipLaunchKernelGGL(iou_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, boxes, target, iou, n);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}
+
+// ---- NMS scores ------------------------------------------------------------------------------
+// mode 0: scores (B, nbox) = sigmoid(obj) column of rows.  mode 1: scores (B, nbox*ncls) =
+// sigmoid(obj) * softmax(cls)_c.  One thread per box.
+__global__ void nms_scores_kernel(const float* __restrict__ rows, float* __restrict__ scores, int C, int ncls,
+                                  int mode, long long nboxes) {
+    const long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (k >= nboxes) return;
+    const float* p = rows + k * C;
+    if (mode == 0) { scores[k] = p[0]; return; }
+    float m = -FLT_MAX;
+    for (int c = 0; c < ncls; ++c) m = fmaxf(m, p[6 + c]);
+    float sum = 0.f;
+    for (int c = 0; c < ncls; ++c) sum += expf(p[6 + c] - m);
+    const float obj = p[0];
+    for (int c = 0; c < ncls; ++c) scores[k * ncls + c] = obj * (expf(p[6 + c] - m) / sum);
+}
+
+extern "C" int yolo_nms_scores(const float* rows, float* scores, int B, int nbox, int C, int mode, void* stream) {
+    if (!rows || !scores || B <= 0 || nbox <= 0 || C < 6) return YOLO_EINVAL;
+    if (mode == 1 && C <= 6) return YOLO_EINVAL;
+    const long long nboxes = (long long)B * nbox;
+    hipLaunchKernelGGL(nms_scores_kernel, dim3((unsigned)((nboxes + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       rows, scores, C, C - 6, mode, nboxes);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}
+
+// ---- NMS ---------------------------------------------------------------------------------------
+// One 1024-thread block per image.
+//   1. exact top-k selection by (score desc, id asc): three histogram passes over the score bits
+//      (11+11+10) find the k-th largest score T; candidates > T are collected, candidates == T are
+//      appended in ascending id order until k is reached (ordered wavefront-ballot compaction).
+//   2. bitonic sort of <=512 composite keys (score_bits<<32 | ~id) descending.
+//   3. suppression bit-matrix over candidate pairs (same class && IoU > thr), then one wavefront
+//      walks the candidates in order OR-ing rows of the matrix (lane w owns 64-bit word w).
+constexpr int NMS_MAXK = 512;
+constexpr int NMS_THREADS = 1024;
+
+__device__ __forceinline__ float box_iou(const float4 a, const float4 b) {
+    const float iw = fmaxf(0.f, fminf(a.z, b.z) - fmaxf(a.x, b.x));
+    const float ih = fmaxf(0.f, fminf(a.w, b.w) - fmaxf(a.y, b.y));
+    const float inter = iw * ih;
+    const float ua = (a.z - a.x) * (a.w - a.y) + (b.z - b.x) * (b.w - b.y) - inter;
+    return ua > 0.f ? inter / ua : 0.f;
+}
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restrict__ rows,
+                                                          const float* __restrict__ scores, int nbox, int C, int cpb,
+                                                          float valid_thresh, float iou_thresh, int topk, int post_nms,
+                                                          int* __restrict__ kept, float* __restrict__ kept_scores,
+                                                          int* __restrict__ kept_count) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned long long keys[NMS_MAXK];
+    __shared__ float4 cbox[NMS_MAXK];
+    __shared__ unsigned long long supp[NMS_MAXK][NMS_MAXK / 64];
+    __shared__ unsigned sh_sel, sh_above, sh_cnt, sh_eqbase;
+    __shared__ unsigned wave_tot[NMS_THREADS / 64];
+
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const long long ncand = (long long)nbox * cpb;
+    const float* sc = scores + (long long)b * ncand;
+    const float* rw = rows + (long long)b * nbox * C;
+    const unsigned vbits = __float_as_uint(fmaxf(valid_thresh, 0.f));
+
+    // ---- 1. k-th largest valid score via 3 histogram passes -------------------------------
+    // scores are >= 0, so their uint bit patterns order like the floats.
+    unsigned prefix = 0;     // bits fixed so far
+    unsigned above = 0;      // candidates strictly above the current bucket
+    unsigned need = (unsigned)topk;
+    bool all_taken = false;  // fewer than topk valid candidates: take everything valid
+    const int shifts[3] = {21, 10, 0};
+    const int widths[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = shifts[pass], nb = 1 << widths[pass];
+        for (int i = tid; i < 2048; i += NMS_THREADS) hist[i] = 0;
+        __syncthreads();
+        const unsigned himask = pass == 0 ? 0u : (0xffffffffu << (shift + widths[pass]));
+        for (long long i = tid; i < ncand; i += NMS_THREADS) {
+            const unsigned u = __float_as_uint(sc[i]);
+            if (u >= vbits && !(u & 0x80000000u) && ((u & himask) == (prefix & himask)))
+                atomicAdd(&hist[(u >> shift) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned cum = 0; int sel = -1;
+            for (int q = nb - 1; q >= 0; --q) {
+                if (cum + hist[q] >= need) { sel = q; break; }
+                cum += hist[q];
+            }
+            if (sel < 0) { sh_sel = 0xffffffffu; sh_above = cum; }
+            else { sh_sel = (unsigned)sel; sh_above = cum; }
+        }
+        __syncthreads();
+        if (sh_sel == 0xffffffffu) { all_taken = true; break; }
+        prefix |= sh_sel << shift;
+        above += sh_above;
+        need -= sh_above;
+        __syncthreads();
+    }
+    // now: candidates with bits > prefix are all selected (`above` of them); `need` more with bits == prefix
+    // (lowest ids first).  all_taken: every valid candidate selected (count < topk).
+    const unsigned T = all_taken ? vbits : prefix;
+    if (tid == 0) { sh_cnt = 0; sh_eqbase = 0; }
+    __syncthreads();
+    const unsigned need_eq = all_taken ? 0xffffffffu : need;
+    // strictly-above candidates (or all valid when all_taken): unordered append
+    for (long long i = tid; i < ncand; i += NMS_THREADS) {
+        const unsigned u = __float_as_uint(sc[i]);
+        const bool valid = u >= vbits && !(u & 0x80000000u);
+        const bool take = valid && (all_taken ? true : (u > T));
+        if (take) {
+            const unsigned pos = atomicAdd(&sh_cnt, 1u);
+            if (pos < NMS_MAXK) keys[pos] = ((unsigned long long)u << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+        }
+    }
+    __syncthreads();
+    // equal-to-T candidates in ascending id order (ordered compaction, NMS_THREADS ids per round)
+    if (!all_taken) {
+        for (long long base = 0; base < ncand; base += NMS_THREADS) {
+            if (sh_eqbase >= need_eq) break;
+            const long long i = base + tid;
+            const bool eq = i < ncand && __float_as_uint(sc[i]) == T;
+            const unsigned long long bal = __ballot(eq);
+            const unsigned before = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_tot[wave] = __popcll(bal);
+            __syncthreads();
+            unsigned woff = 0, tot = 0;
+            for (int w = 0; w < NMS_THREADS / 64; ++w) {
+                if (w < wave) woff += wave_tot[w];
+                tot += wave_tot[w];
+            }
+            const unsigned rank = sh_eqbase + woff + before;
+            if (eq && rank < need_eq) {
+                const unsigned pos = above + rank;
+                if (pos < NMS_MAXK) keys[pos] = ((unsigned long long)T << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+            }
+            __syncthreads();
+            if (tid == 0) sh_eqbase += tot;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    unsigned n = all_taken ? min(sh_cnt, (unsigned)NMS_MAXK) : (unsigned)topk;
+    if (!all_taken) n = min(n, above + min(sh_eqbase, need_eq));
+    n = min(n, (unsigned)topk);
+
+    // ---- 2. bitonic sort, descending ---------------------------------------------------------
+    for (int i = tid; i < NMS_MAXK; i += NMS_THREADS)
+        if ((unsigned)i >= n) keys[i] = 0ull;
+    __syncthreads();
+    for (int k = 2; k <= NMS_MAXK; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (tid < NMS_MAXK) {
+                const int ixj = tid ^ j;
+                if (ixj > tid) {
+                    const unsigned long long a = keys[tid], c = keys[ixj];
+                    const bool desc = (tid & k) == 0;
+                    if (desc ? (a < c) : (a > c)) { keys[tid] = c; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- 3. suppression matrix -----------------------------------------------------------------
+    for (int i = tid; i < (int)n; i += NMS_THREADS) {
+        const unsigned id = 0xffffffffu - (unsigned)(keys[i] & 0xffffffffull);
+        const float* p = rw + (long long)(id / cpb) * C + 1;
+        cbox[i] = make_float4(p[0], p[1], p[2], p[3]);
+    }
+    __syncthreads();
+    const int nwords = ((int)n + 63) / 64;
+    for (int e = tid; e < (int)n * nwords; e += NMS_THREADS) {
+        const int i = e / nwords, w = e - i * nwords;
+        const unsigned idi = 0xffffffffu - (unsigned)(keys[i] & 0xffffffffull);
+        const unsigned ci = idi % cpb;
+        const float4 bi = cbox[i];
+        unsigned long long m = 0;
+        for (int q = 0; q < 64; ++q) {
+            const int j = w * 64 + q;
+            if (j > i && j < (int)n) {
+                const unsigned idj = 0xffffffffu - (unsigned)(keys[j] & 0xffffffffull);
+                if (idj % cpb == ci && box_iou(bi, cbox[j]) > iou_thresh) m |= 1ull << q;
+            }
+        }
+        supp[i][w] = m;
+    }
+    __syncthreads();
+    // ---- 4. greedy walk by one wavefront ---------------------------------------------------------
+    if (wave == 0) {
+        unsigned long long removed = 0;     // lane w owns word w (nwords <= 8)
+        int nk = 0;
+        for (int i = 0; i < (int)n && nk < post_nms; ++i) {
+            const unsigned long long wd = __shfl(removed, i >> 6, 64);
+            if (!((wd >> (i & 63)) & 1ull)) {
+                if (lane < nwords) removed |= supp[i][lane];
+                if (lane == 0) {
+                    const unsigned long long key = keys[i];
+                    kept[(long long)b * post_nms + nk] = (int)(0xffffffffu - (unsigned)(key & 0xffffffffull));
+                    kept_scores[(long long)b * post_nms + nk] = __uint_as_float((unsigned)(key >> 32));
+                }
+                ++nk;
+            }
+        }
+        for (int q = nk + lane; q < post_nms; q += 64) {
+            kept[(long long)b * post_nms + q] = -1;
+            kept_scores[(long long)b * post_nms + q] = 0.f;
+        }
+        if (lane == 0) kept_count[b] = nk;
+    }
+}
+
+extern "C" long long yolo_nms_workspace_bytes(int B, int nbox, int ncls, int mode, int topk) {
+    (void)topk;
+    if (B <= 0 || nbox <= 0) return YOLO_EINVAL;
+    return (long long)B * nbox * (mode == 1 ? ncls : 1) * 4;
+}
+
+extern "C" int yolo_nms_from_scores(const float* rows, const float* scores, int B, int nbox, int C,
+                                    int cand_per_box, float valid_thresh, float iou_thresh, int topk, int post_nms,
+                                    int* kept, float* kept_scores, int* kept_count, void* stream) {
+    if (!rows || !scores || !kept || !kept_scores || !kept_count) return YOLO_EINVAL;
+    if (B <= 0 || nbox <= 0 || C < 5 || cand_per_box < 1 || post_nms < 1) return YOLO_EINVAL;
+    if (topk < 1 || topk > NMS_MAXK) return YOLO_EUNSUPPORTED;
+    if ((long long)nbox * cand_per_box > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
+    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NMS_THREADS), 0, (hipStream_t)stream, rows, scores, nbox, C,
+                       cand_per_box, valid_thresh, iou_thresh, topk, post_nms, kept, kept_scores, kept_count);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}
+
+extern "C" int yolo_nms(const float* rows, int B, int nbox, int C, int mode, float valid_thresh, float iou_thresh,
+                        int topk, int post_nms, int* kept, float* kept_scores, int* kept_count, void* workspace,
+                        void* stream) {
+    if (!workspace) return YOLO_EINVAL;
+    if (mode != 0 && mode != 1) return YOLO_EINVAL;
+    int rc = yolo_nms_scores(rows, (float*)workspace, B, nbox, C, mode, stream);
+    if (rc) return rc;
+    return yolo_nms_from_scores(rows, (const float*)workspace, B, nbox, C, mode == 1 ? C - 6 : 1, valid_thresh,
+                                iou_thresh, topk, post_nms, kept, kept_scores, kept_count, stream);
+}

@@ -1,0 +1,97 @@
+"""ctypes binding of libyolo_amd.so (include/yolo_amd.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails,
+an exception is raised.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libyolo_amd.so')
+
+F32, BF16 = 0, 1
+
+
+class YoloError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('w_packed', C.c_void_p), ('scale', C.c_void_p), ('bias', C.c_void_p),
+                ('residual', C.c_void_p), ('y', C.c_void_p),
+                ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int),
+                ('ksize', C.c_int), ('stride', C.c_int), ('dtype', C.c_int), ('out_f32', C.c_int),
+                ('slope', C.c_float), ('y_batch_stride', C.c_longlong), ('y_pixel_stride', C.c_longlong)]
+
+
+class GridDesc(C.Structure):
+    _fields_ = [('nscale', C.c_int), ('A', C.c_int), ('img_h', C.c_int), ('img_w', C.c_int),
+                ('gh', C.c_int * 4), ('gw', C.c_int * 4), ('step', C.c_int * 4),
+                ('anchors_hw', C.c_float * 64)]
+
+
+# name -> (restype, argtypes); must list every symbol include/yolo_amd.h declares
+_vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+SIGNATURES = {
+    'yolo_version': (_i, []),
+    'yolo_packed_weight_bytes': (_ll, [_i, _i, _i, _i]),
+    'yolo_pack_conv_weights': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'yolo_padded_channels': (_i, [_i]),
+    'yolo_fold_bn': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
+    'yolo_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'yolo_image_u8_to_nchw': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'yolo_nhwc_to_nchw': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'yolo_conv_fwd': (_i, [C.POINTER(ConvDesc), _vp]),
+    'yolo_conv_kernel_name': (_i, [C.POINTER(ConvDesc), C.c_char_p, _i]),
+    'yolo_upsample2x_concat': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'yolo_decode': (_i, [_vp, _vp, _i, _i, C.POINTER(GridDesc), _vp]),
+    'yolo_predict_top1': (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(GridDesc), _vp]),
+    'yolo_iou_ltrb_vs_yxhw': (_i, [_vp, _vp, _vp, _i, _vp]),
+    'yolo_nms_workspace_bytes': (_ll, [_i, _i, _i, _i, _i]),
+    'yolo_nms_scores': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'yolo_nms_from_scores': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp]),
+    'yolo_nms': (_i, [_vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile libyolo_amd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(['make', '-C', CSRC, 'clean'])
+    subprocess.check_call(['make', '-C', CSRC, '-j4'])
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise YoloError('libyolo_amd.so not found at %s: build it with yolo_amd.lib.build() '
+                        '(no CPU fallback exists)' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise YoloError('%s failed with status %d' % (what, rc))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,257 @@
+"""CarNet: host-side mirror of the reference's network object.
+
+Same call contract as `CarNet(spec, num_sync_bn_devices=-1)` + `net(x)` (car/utils.py:64-95,
+car/YOLO.py:96,381): input (B,3,H,W) float32 NCHW on the device, output a list of 3 tensors
+fine->coarse, each (B, H_i*W_i, A, C) float32.  Every arithmetic op runs in libyolo_amd.so
+(hand-written HIP for gfx950); torch only owns device memory and the stream.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .spec import NetGraph, BN_EPS, LEAKY_SLOPE, xavier_bound
+
+_TORCH_DT = {'bf16': torch.bfloat16, 'f32': torch.float32}
+_LIB_DT = {'bf16': L.BF16, 'f32': L.F32}
+
+
+class _Plan(object):
+    """Launch list for one input shape: prebuilt descriptors over cached activation buffers."""
+    def __init__(self):
+        self.ops = []        # (kind, payload)
+        self.buffers = []    # keeps tensors alive
+        self.x_nhwc = None
+        self.merged = None
+        self.offsets = None
+        self.act = {}        # name -> (tensor, (N,H,W,C)) for parity taps
+
+
+class CarNet(object):
+    def __init__(self, spec, num_sync_bn_devices=-1, dtype='bf16', device='cuda:0'):
+        # num_sync_bn_devices is accepted for signature parity; the reference always passes -1
+        # (no SyncBN, car/YOLO.py:94-96).
+        if dtype not in _TORCH_DT:
+            raise ValueError('dtype must be bf16 or f32')
+        self.graph = NetGraph(spec)
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self.params = {}
+        self._prepared = {}
+        self._plans = {}
+        self._lib = L.load()
+
+    # ---- parameters (gluon collect_params().save/load seam, car/YOLO.py:549, yolo_gluon.py:190) --
+    def initialize(self, seed=0):
+        """init_NN's Xavier branch (yolo_gluon.py:198): weights U(+-bound), gamma 1, beta/mean 0, var 1."""
+        gen = torch.Generator(device='cpu').manual_seed(seed)
+        for c in self.graph.convs():
+            a = xavier_bound(c.cin, c.cout, c.k)
+            w = (torch.rand((c.cout, c.cin, c.k, c.k), generator=gen) * 2 - 1) * a
+            self.params[c.name + '.weight'] = w.to(self.device)
+            if c.bn:
+                self.params[c.name + '.gamma'] = torch.ones(c.cout, device=self.device)
+                self.params[c.name + '.beta'] = torch.zeros(c.cout, device=self.device)
+                self.params[c.name + '.running_mean'] = torch.zeros(c.cout, device=self.device)
+                self.params[c.name + '.running_var'] = torch.ones(c.cout, device=self.device)
+            else:
+                self.params[c.name + '.bias'] = torch.zeros(c.cout, device=self.device)
+        self._prepared = {}
+        return self
+
+    def load_params(self, params):
+        """params: dict name -> ndarray / tensor, gluon-style names (see ConvSpec.param_names)."""
+        for c in self.graph.convs():
+            for n in c.param_names():
+                if n not in params:
+                    raise KeyError('missing parameter %s' % n)
+                v = params[n]
+                t = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v
+                self.params[n] = t.detach().to(self.device, torch.float32).contiguous()
+        self._prepared = {}
+        return self
+
+    def collect_params(self):
+        return self.params
+
+    def save_state(self, path):
+        np.savez(path, **{k: v.detach().cpu().numpy() for k, v in self.params.items()})
+
+    def load_state(self, path):
+        with np.load(path) as z:
+            return self.load_params({k: z[k] for k in z.files})
+
+    # ---- one-off preparation: BN folding + weight packing (all on device, HIP kernels) ------------
+    def prepare(self):
+        lib, st, dt = self._lib, L.stream_ptr(), _LIB_DT[self.dtype]
+        for c in self.graph.convs():
+            w = self.params[c.name + '.weight']
+            nbytes = lib.yolo_packed_weight_bytes(c.cout, c.cin, c.k, dt)
+            if nbytes < 0:
+                raise L.YoloError('unsupported conv %s' % c.name)
+            wp = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            L.check(lib.yolo_pack_conv_weights(L.ptr(w), L.ptr(wp), c.cout, c.cin, c.k, dt, st), 'pack ' + c.name)
+            cp = lib.yolo_padded_channels(c.cout)
+            scale = torch.empty(cp, dtype=torch.float32, device=self.device)
+            bias = torch.empty(cp, dtype=torch.float32, device=self.device)
+            if c.bn:
+                p = lambda s: L.ptr(self.params[c.name + s])
+                L.check(lib.yolo_fold_bn(p('.gamma'), p('.beta'), p('.running_mean'), p('.running_var'),
+                                         BN_EPS, L.ptr(scale), L.ptr(bias), c.cout, st), 'fold ' + c.name)
+            else:
+                L.check(lib.yolo_fold_bn(None, L.ptr(self.params[c.name + '.bias']), None, None, BN_EPS,
+                                         L.ptr(scale), L.ptr(bias), c.cout, st), 'bias ' + c.name)
+            self._prepared[c.name] = (wp, scale, bias)
+        self._plans = {}
+        return self
+
+    # ---- plan construction --------------------------------------------------------------------------
+    def _conv_op(self, plan, c, x, xshape, residual=None, out=None, out_f32=False, y_bs=0, y_ps=0, cin=None):
+        N, H, W, _ = xshape
+        ho, wo = c.out_hw(H, W)
+        wp, scale, bias = self._prepared[c.name]
+        if out is None:
+            out = torch.empty((N, ho, wo, c.cout), dtype=_TORCH_DT[self.dtype], device=self.device)
+            plan.buffers.append(out)
+        d = L.ConvDesc()
+        d.x, d.w_packed, d.scale, d.bias = L.ptr(x), L.ptr(wp), L.ptr(scale), L.ptr(bias)
+        d.residual = L.ptr(residual)
+        d.y = out if isinstance(out, int) else L.ptr(out)
+        d.N, d.H, d.W, d.Cin, d.Cout = N, H, W, (cin or c.cin), c.cout
+        d.ksize, d.stride, d.dtype = c.k, c.stride, _LIB_DT[self.dtype]
+        d.out_f32 = 1 if out_f32 else 0
+        d.slope = LEAKY_SLOPE if c.bn else 1.0
+        d.y_batch_stride, d.y_pixel_stride = y_bs, y_ps
+        plan.ops.append(('conv', d, c.name))
+        if not isinstance(out, int):
+            plan.act[c.name] = (out, (N, ho, wo, c.cout))
+        return out, (N, ho, wo, c.cout)
+
+    def _build_plan(self, B, H, W):
+        g = self.graph
+        plan = _Plan()
+        tdt = _TORCH_DT[self.dtype]
+        plan.x_nhwc = torch.empty((B, H, W, 8), dtype=tdt, device=self.device)
+        x, shp = self._conv_op(plan, g.stem, plan.x_nhwc, (B, H, W, 8), cin=8)
+        routes = []
+        nst = len(g.stages)
+        for i, (down, res) in enumerate(g.stages):
+            x, shp = self._conv_op(plan, down, x, shp)
+            for c1, c2 in res:
+                mid, mshp = self._conv_op(plan, c1, x, shp)
+                x, shp = self._conv_op(plan, c2, mid, mshp, residual=x)
+            if i >= nst - g.num_pyramid:
+                routes.append((x, shp))
+        # merged head buffer (B, sum HW, A*C) float32, scales fine->coarse (car/utils.py:95, car/YOLO.py:841)
+        hw = [r[1][1] * r[1][2] for r in routes]            # fine -> coarse
+        per = [h[3] * g.per_anchor for h in g.heads][::-1]
+        if len(set(per)) != 1:
+            raise L.YoloError('all scales must have the same number of anchors')
+        AC = per[0]
+        tot = sum(hw)
+        plan.merged = torch.empty((B, tot, AC), dtype=torch.float32, device=self.device)
+        offs = [sum(hw[:k]) for k in range(len(hw))]
+        plan.offsets = list(zip(offs, hw))
+        for i, (body, tip, outc, nA) in enumerate(g.heads):
+            for c in body:
+                x, shp = self._conv_op(plan, c, x, shp)
+            route, rshp = x, shp
+            t, tshp = self._conv_op(plan, tip, route, rshp)
+            k = len(g.heads) - 1 - i                        # position of this scale in fine->coarse order
+            yptr = plan.merged.data_ptr() + offs[k] * AC * 4
+            self._conv_op(plan, outc, t, tshp, out=yptr, out_f32=True, y_bs=tot * AC, y_ps=AC)
+            if i >= len(g.heads) - 1:
+                break
+            x, shp = self._conv_op(plan, g.transitions[i], route, rshp)
+            r, rs = routes[::-1][i + 1]
+            cat = torch.empty((rs[0], rs[1], rs[2], shp[3] + rs[3]), dtype=tdt, device=self.device)
+            plan.buffers.append(cat)
+            plan.ops.append(('upcat', (L.ptr(x), L.ptr(r), L.ptr(cat), rs[0], rs[1], rs[2], shp[3], rs[3]),
+                             'upcat.%d' % i))
+            x, shp = cat, (rs[0], rs[1], rs[2], shp[3] + rs[3])
+        return plan
+
+    # ---- forward ------------------------------------------------------------------------------------
+    def forward(self, x, training=False):
+        if training:
+            raise NotImplementedError('training-mode forward is not built yet')
+        if not self._prepared:
+            self.prepare()
+        if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or not x.is_cuda:
+            raise ValueError('expected a (B,3,H,W) float32 CUDA tensor')
+        x = x.contiguous()
+        B, _, H, W = x.shape
+        key = (B, H, W)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = self._build_plan(B, H, W)
+        lib, st, dt = self._lib, L.stream_ptr(), _LIB_DT[self.dtype]
+        L.check(lib.yolo_nchw_to_nhwc(x.data_ptr(), L.ptr(plan.x_nhwc), B, 3, H, W, 8, dt, st), 'nchw_to_nhwc')
+        for kind, payload, name in plan.ops:
+            if kind == 'conv':
+                rc = lib.yolo_conv_fwd(C.byref(payload), st)
+            else:
+                rc = lib.yolo_upsample2x_concat(*payload, dt, st)
+            if rc:
+                raise L.YoloError('%s (%s) failed with status %d' % (kind, name, rc))
+        self._last_plan = plan
+        A = self.graph.heads[0][3]
+        return [plan.merged[:, o:o + n].view(B, n, A, self.graph.per_anchor) for o, n in plan.offsets]
+
+    __call__ = forward
+
+    def plan_kernels(self, B, H, W):
+        """[(op name, kernel instantiation name, algorithmic FLOPs)] for the launch list of one input
+        shape (FLOPs = 2*Cin*k^2*Cout*Ho*Wo*B per conv; 0 for non-conv ops)."""
+        if not self._prepared:
+            self.prepare()
+        plan = self._plans.get((B, H, W))
+        if plan is None:
+            plan = self._plans[(B, H, W)] = self._build_plan(B, H, W)
+        by_name = {c.name: c for c in self.graph.convs()}
+        out = []
+        buf = C.create_string_buffer(256)
+        for kind, payload, name in plan.ops:
+            if kind != 'conv':
+                out.append((name, kind, 0))
+                continue
+            L.check(self._lib.yolo_conv_kernel_name(C.byref(payload), buf, 256), 'kernel_name')
+            c = by_name[name]
+            ho, wo = c.out_hw(payload.H, payload.W)
+            out.append((name, buf.value.decode(), 2 * c.cin * c.k * c.k * c.cout * ho * wo * payload.N))
+        return out
+
+    def forward_timed(self, x, events):
+        """forward() that brackets every launch with a pair of torch CUDA events (recorded on the
+        stream the kernels run on).  events: list that receives (op name, start, end)."""
+        B, _, H, W = x.shape
+        plan = self._plans[(B, H, W)]
+        lib, st, dt = self._lib, L.stream_ptr(), _LIB_DT[self.dtype]
+        L.check(lib.yolo_nchw_to_nhwc(x.data_ptr(), L.ptr(plan.x_nhwc), B, 3, H, W, 8, dt, st), 'nchw_to_nhwc')
+        for kind, payload, name in plan.ops:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if kind == 'conv':
+                rc = lib.yolo_conv_fwd(C.byref(payload), st)
+            else:
+                rc = lib.yolo_upsample2x_concat(*payload, dt, st)
+            e1.record()
+            if rc:
+                raise L.YoloError('%s (%s) failed with status %d' % (kind, name, rc))
+            events.append((name, e0, e1))
+        self._last_plan = plan
+
+    def merged_output(self):
+        """(B, sum HW, A, C) view of the last forward: the concat of merge_and_slice (car/YOLO.py:841-849)."""
+        m = self._last_plan.merged
+        A = self.graph.heads[0][3]
+        return m.view(m.shape[0], m.shape[1], A, self.graph.per_anchor)
+
+    def activation_nchw(self, name):
+        """float32 NCHW copy of a named conv output of the last forward (parity taps)."""
+        t, (N, H, W, Cc) = self._last_plan.act[name]
+        out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=self.device)
+        L.check(self._lib.yolo_nhwc_to_nchw(L.ptr(t), L.ptr(out), N, Cc, H, W, _LIB_DT[self.dtype], L.stream_ptr()),
+                'nhwc_to_nchw')
+        return out
