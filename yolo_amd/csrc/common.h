@@ -8,6 +8,13 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
+// hipGetLastError() is per-thread sticky state shared with every other HIP user in the process
+// (torch): YOLO_LAUNCH() drops whatever was pending so YOLO_LAUNCH_CHECK() reports only ours.
+#define YOLO_LAUNCH(...)                                     \
+    do {                                                     \
+        (void)hipGetLastError();                             \
+        hipLaunchKernelGGL(__VA_ARGS__);                     \
+    } while (0)
 #define YOLO_LAUNCH_CHECK()                                  \
     do {                                                     \
         hipError_t e__ = hipGetLastError();                  \

@@ -336,7 +336,7 @@ static int launch_cfg(ConvArgs& a, hipStream_t st, const NameOut* name) {
     a.tiles_c = (a.Cout + BC - 1) / BC;
     const long long grid = (long long)a.nstrips * a.tiles_per_strip * a.tiles_c;
     if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, KS, S, WAVES_P, WAVES_C, MI, NI, XSLOTS, TS>), dim3((unsigned)grid),
+    YOLO_LAUNCH((conv_igemm_kernel<T, KS, S, WAVES_P, WAVES_C, MI, NI, XSLOTS, TS>), dim3((unsigned)grid),
                        dim3(256), 0, st, a);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
@@ -449,10 +449,10 @@ extern "C" int yolo_pack_conv_weights(const float* w_oihw, void* packed, int Cou
     const long long total = bytes / elem_size(dtype);
     const int grid = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
     if (dtype == YOLO_BF16)
-        hipLaunchKernelGGL(pack_weights_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
+        YOLO_LAUNCH(pack_weights_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
                            (__bf16*)packed, Cout, Cin, ksize, Cout_pad, nchunks);
     else
-        hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
+        YOLO_LAUNCH(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
                            (float*)packed, Cout, Cin, ksize, Cout_pad, nchunks);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;

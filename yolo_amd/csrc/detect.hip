@@ -92,7 +92,7 @@ extern "C" int yolo_decode(const float* out, float* rows, int B, int C, const yo
     int rc = make_grid(g, d, &nbox);
     if (rc) return rc;
     const long long total = (long long)B * nbox * C;
-    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out,
+    YOLO_LAUNCH(decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out,
                        rows, C, nbox, total, d);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
@@ -162,7 +162,7 @@ extern "C" int yolo_predict_top1(const float* out, float* pred, int* best_idx, i
     GridDev d; int nbox;
     int rc = make_grid(g, d, &nbox);
     if (rc) return rc;
-    hipLaunchKernelGGL(predict_top1_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, out, pred, best_idx, C,
+    YOLO_LAUNCH(predict_top1_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, out, pred, best_idx, C,
                        nbox, d);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
@@ -186,7 +186,7 @@ __global__ void iou_kernel(const float* __restrict__ boxes, const float* __restr
 
 extern "C" int yolo_iou_ltrb_vs_yxhw(const float* boxes, const float* target, float* iou, int n, void* stream) {
     if (!boxes || !target || !iou || n <= 0) return YOLO_EINVAL;
-    hipLaunchKernelGGL(iou_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, boxes, target, iou, n);
+    YOLO_LAUNCH(iou_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, boxes, target, iou, n);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
@@ -212,7 +212,7 @@ extern "C" int yolo_nms_scores(const float* rows, float* scores, int B, int nbox
     if (!rows || !scores || B <= 0 || nbox <= 0 || C < 6) return YOLO_EINVAL;
     if (mode == 1 && C <= 6) return YOLO_EINVAL;
     const long long nboxes = (long long)B * nbox;
-    hipLaunchKernelGGL(nms_scores_kernel, dim3((unsigned)((nboxes + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    YOLO_LAUNCH(nms_scores_kernel, dim3((unsigned)((nboxes + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        rows, scores, C, C - 6, mode, nboxes);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
@@ -416,7 +416,7 @@ extern "C" int yolo_nms_from_scores(const float* rows, const float* scores, int 
     if (B <= 0 || nbox <= 0 || C < 5 || cand_per_box < 1 || post_nms < 1) return YOLO_EINVAL;
     if (topk < 1 || topk > NMS_MAXK) return YOLO_EUNSUPPORTED;
     if ((long long)nbox * cand_per_box > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
-    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NMS_THREADS), 0, (hipStream_t)stream, rows, scores, nbox, C,
+    YOLO_LAUNCH(nms_kernel, dim3(B), dim3(NMS_THREADS), 0, (hipStream_t)stream, rows, scores, nbox, C,
                        cand_per_box, valid_thresh, iou_thresh, topk, post_nms, kept, kept_scores, kept_count);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;

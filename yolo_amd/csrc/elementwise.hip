@@ -29,7 +29,7 @@ extern "C" int yolo_fold_bn(const float* gamma, const float* beta, const float* 
     if (!scale || !bias || C <= 0) return YOLO_EINVAL;
     if (gamma && (!beta || !mean || !var)) return YOLO_EINVAL;
     const int Cpad = round_up(C, YOLO_COUT_PAD);
-    hipLaunchKernelGGL(fold_bn_kernel, dim3((Cpad + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+    YOLO_LAUNCH(fold_bn_kernel, dim3((Cpad + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
                        mean, var, eps, scale, bias, C, Cpad);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
@@ -71,10 +71,10 @@ extern "C" int yolo_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, i
     const long long HW = (long long)H * W, total = HW * N;
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (dtype == YOLO_BF16)
-        hipLaunchKernelGGL((nchw_to_nhwc_kernel<__bf16, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
+        YOLO_LAUNCH((nchw_to_nhwc_kernel<__bf16, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
                            (__bf16*)y, C, HW, total);
     else if (dtype == YOLO_F32)
-        hipLaunchKernelGGL((nchw_to_nhwc_kernel<float, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
+        YOLO_LAUNCH((nchw_to_nhwc_kernel<float, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
                            (float*)y, C, HW, total);
     else
         return YOLO_EINVAL;
@@ -95,7 +95,7 @@ extern "C" int yolo_image_u8_to_nchw(const unsigned char* img, float* y, int N, 
                                      void* stream) {
     if (!img || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return YOLO_EINVAL;
     const long long HW = (long long)H * W, total = HW * N;
-    hipLaunchKernelGGL(image_u8_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+    YOLO_LAUNCH(image_u8_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, img, y, C, HW, total);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
@@ -122,10 +122,10 @@ extern "C" int yolo_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, i
     const long long HW = (long long)H * W, total = HW * N * C;
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (dtype == YOLO_BF16)
-        hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+        YOLO_LAUNCH(nhwc_to_nchw_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const __bf16*)x, y, C, HW, total);
     else if (dtype == YOLO_F32)
-        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+        YOLO_LAUNCH(nhwc_to_nchw_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const float*)x, y, C, HW, total);
     else
         return YOLO_EINVAL;
@@ -162,7 +162,7 @@ extern "C" int yolo_upsample2x_concat(const void* up, const void* route, void* y
     if ((C1 * es) % 16 || (C2 * es) % 16) return YOLO_EUNSUPPORTED;
     const int U1 = C1 * es / 16, U2 = C2 * es / 16;
     const long long total = (long long)N * H * W * (U1 + U2);
-    hipLaunchKernelGGL(upsample_concat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+    YOLO_LAUNCH(upsample_concat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, (const uint4*)up, (const uint4*)route, (uint4*)y, H, W, U1, U2, total);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;

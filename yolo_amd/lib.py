@@ -70,6 +70,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64: it must be in the process BEFORE libyolo_amd.so so both
+    # share one HIP runtime (kernels launched through a second runtime fail with hipErrorNoDevice).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise YoloError('libyolo_amd.so not found at %s: build it with yolo_amd.lib.build() '
                         '(no CPU fallback exists)' % LIB_PATH)
