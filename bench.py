@@ -95,7 +95,7 @@ def main():
     spec = darknet53_spec()
     size = (args.size, args.size)
     B = args.batch
-    net = CarNet(spec, dtype=args.dtype, device=dev).initialize(seed=1234)
+    net = CarNet(spec, dtype=args.dtype, device=dev, tune='measure').initialize(seed=1234)
     net.prepare()
     det = Detector(spec, size, net.graph.steps(), device=dev)
     gen = torch.Generator(device='cpu').manual_seed(100 + rank)

@@ -78,6 +78,8 @@ typedef struct yolo_conv_desc {
     float slope;           /* LeakyReLU negative slope; 1.0f = linear                         */
     long long y_batch_stride; /* elements between images in y; 0 = dense Ho*Wo*Cout           */
     long long y_pixel_stride; /* elements between pixels in y; 0 = dense Cout                 */
+    int algo;              /* 0 = library heuristic; 1 = generic kernel; >= 2 = a specific pipelined
+                              tile variant (csrc/conv_pipe.hip), YOLO_EUNSUPPORTED if not eligible    */
 } yolo_conv_desc;
 
 int yolo_conv_fwd(const yolo_conv_desc* d, void* stream);

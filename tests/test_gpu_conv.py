@@ -65,3 +65,41 @@ def test_conv_out_f32_linear(lib, cuda):
     rb = lambda a: np.asarray(__import__('torch').from_numpy(a).to(__import__('torch').bfloat16).float())
     ref = ref_conv(rb(x), rb(w), scale, bias, 1, 1.0)
     np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-4)
+
+
+# ---- pipelined variants (csrc/conv_pipe.hip): every algo id on shapes it is eligible for ----------
+PIPE_CASES = [
+    (2, 128, 26, 26, 256, 3, 1, True),
+    (4, 64, 52, 52, 256, 3, 1, True),      # several strips per row
+    (8, 256, 13, 13, 512, 3, 1, True),     # tiles crossing image boundaries
+    (3, 128, 19, 19, 256, 3, 1, False),    # 608-family odd map
+    (1, 64, 13, 13, 96, 3, 1, False),      # fewer pixels than one tile, ragged Cout
+    (1, 256, 13, 13, 128, 1, 1, False),
+    (4, 256, 26, 26, 512, 1, 1, True),
+    (2, 512, 13, 13, 88, 1, 1, False),
+    (2, 64, 26, 26, 128, 3, 1, False),     # Cout smaller than the widest cout tile
+]
+
+
+@pytest.mark.parametrize('algo', [2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', PIPE_CASES)
+def test_conv_pipe(lib, cuda, case, dtype, algo):
+    if algo in (6, 7) and case[5] != 3:
+        pytest.skip('3x3-only variant')
+    x, w, scale, bias, r = _mk(case, 4)
+    y = run_conv(lib, cuda, x, w, scale, bias, case[6], 0.1, dtype, residual=r, algo=algo)
+    ref = ref_conv(x, w, scale, bias, case[6], 0.1, residual=r, bf16=(dtype == 'bf16'))
+    assert not np.isnan(y).any()
+    if dtype == 'f32':
+        np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-4)
+    else:
+        np.testing.assert_allclose(y, ref, rtol=1.6e-2, atol=2e-2)
+        assert np.mean(np.abs(y - ref) > 1e-3 * (1 + np.abs(ref))) < 0.02
+
+
+def test_conv_pipe_rejects_ineligible(lib, cuda):
+    """A pinned pipelined algo on a shape it cannot run must fail loudly, not fall back."""
+    case = (2, 16, 16, 24, 32, 3, 2, False)          # stride 2
+    x, w, scale, bias, r = _mk(case, 5)
+    run_conv(lib, cuda, x, w, scale, bias, 2, 0.1, 'bf16', algo=2, expect_rc=-2)

@@ -13,12 +13,12 @@ from oracle import graph as og, forward as of
 pytestmark = pytest.mark.gpu
 
 
-def _run(spec, size, B, dtype, bn, cuda):
+def _run(spec, size, B, dtype, bn, cuda, tune='auto'):
     from yolo_amd.net import CarNet
     g = og.build_graph(spec)
     P = og.init_params(g, seed=0, bn=bn)
     x = np.random.default_rng(2).random((B, 3) + size, dtype=np.float32)
-    net = CarNet(spec, dtype=dtype, device=cuda).load_params(P)
+    net = CarNet(spec, dtype=dtype, device=cuda, tune=tune).load_params(P)
     outs = net(torch.from_numpy(x).to(cuda))
     torch.cuda.synchronize()
     return g, P, x, net, [o.cpu().numpy() for o in outs]
@@ -84,6 +84,25 @@ def test_d53_416_bf16_vs_sim(cuda):
         rms = lambda a: float(np.sqrt(np.mean(a * a)))
         e_hip, e_sim, e_pair = rms(o - r) / r.std(), rms(s - r) / r.std(), rms(o - s) / r.std()
         assert e_hip < 1.5 * e_sim + 1e-3 and e_hip < 0.015 and e_pair < 0.015, (e_hip, e_sim, e_pair)
+
+
+def test_d53_416_f32_measured_tuning(cuda):
+    """North-star bar on the benchmark geometry: fp32 path, per-layer variants pinned by measurement
+    (the configuration bench.py runs), logits within 1e-3 of the fp32 oracle; decoded boxes within 1e-3."""
+    from oracle import detect as od
+    from yolo_amd.detect import Detector
+    spec, size = og.spec_d53(), (416, 416)
+    g, P, x, net, outs = _run(spec, size, 2, 'f32', 'random', cuda, tune='measure')
+    assert any(op[1].algo > 1 for op in net._last_plan.ops if op[0] == 'conv')     # pipelined variants in use
+    ref = [r.numpy() for r in of.forward_torch(g, P, x)]
+    for o, r in zip(outs, ref):
+        np.testing.assert_allclose(o, r, rtol=0, atol=1e-3)
+    steps = od.init_steps(spec['layers'], spec['all_anchors'])
+    syxhw = od.init_syxhw(size, steps, spec['all_anchors'])
+    det = Detector(spec, size, steps, device=cuda)
+    rows = det.decode([torch.from_numpy(o).to(cuda) for o in outs]).cpu().numpy()
+    ref_rows = od.decode_all(ref, spec['slice_point'], size, syxhw)
+    assert np.abs(rows[..., :5] - ref_rows[..., :5]).max() < 1e-3               # score + ltrb
 
 
 def test_zero_input_known_answer(cuda):

@@ -19,7 +19,8 @@ def from_nhwc(t):
     return t.float().permute(0, 3, 1, 2).contiguous().cpu().numpy()
 
 
-def run_conv(lib, dev, x, w, scale, bias, stride, slope, dtype, residual=None, out_f32=False):
+def run_conv(lib, dev, x, w, scale, bias, stride, slope, dtype, residual=None, out_f32=False, algo=0,
+             expect_rc=0):
     """x (N,Cin,H,W) f32 ndarray; w (Cout,Cin,k,k); scale/bias (Cout,) -> y (N,Cout,Ho,Wo) f32 ndarray."""
     N, Cin, H, W = x.shape
     Cout, _, k, _ = w.shape
@@ -41,9 +42,13 @@ def run_conv(lib, dev, x, w, scale, bias, stride, slope, dtype, residual=None, o
     d.residual = rd.data_ptr() if rd is not None else None
     d.y = y.data_ptr()
     d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride = N, H, W, Cin, Cout, k, stride
-    d.dtype, d.out_f32, d.slope = dt, int(out_f32), slope
+    d.dtype, d.out_f32, d.slope, d.algo = dt, int(out_f32), slope, algo
     rc = lib.yolo_conv_fwd(C.byref(d), st)
-    assert rc == 0, 'yolo_conv_fwd rc=%d' % rc
+    if expect_rc is None:
+        if rc != 0:
+            return None
+    else:
+        assert rc == expect_rc, 'yolo_conv_fwd rc=%d' % rc
     torch.cuda.synchronize()
     return from_nhwc(y)
 

@@ -12,9 +12,10 @@ ap.add_argument('--batch', type=int, default=32)
 ap.add_argument('--size', type=int, default=416)
 ap.add_argument('--dtype', default='bf16')
 ap.add_argument('--iters', type=int, default=10)
+ap.add_argument('--tune', default='measure')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
-net = CarNet(darknet53_spec(), dtype=a.dtype, device=dev).initialize(1)
+net = CarNet(darknet53_spec(), dtype=a.dtype, device=dev, tune=a.tune).initialize(1)
 x = torch.rand((a.batch, 3, a.size, a.size), device=dev)
 for _ in range(3):
     net(x)
@@ -43,6 +44,6 @@ for (kind, payload, name), (_, kname, fl) in zip(plan.ops, kern):
     mf_us = fl / (2.5e15 if a.dtype == 'bf16' else 157e12) * 1e6
     roof = max(hbm_us, mf_us)
     sum_us += us; sum_roof += roof
-    print('%-22s %-14s %5d %5d %4d %4d %8.1f %8.1f %8.1f %6s %5.0f%%' % (name, '%dx%dx%d' % (d.N, d.H, d.W), d.Cin, d.Cout, d.ksize, d.stride,
-          us, fl / us / 1e6, hbm_us, 'hbm' if hbm_us > mf_us else 'mfma', 100 * roof / us))
+    print('%-22s %-14s %5d %5d %4d %4d %8.1f %8.1f %8.1f %6s %5.0f%% a%d' % (name, '%dx%dx%d' % (d.N, d.H, d.W), d.Cin, d.Cout, d.ksize, d.stride,
+          us, fl / us / 1e6, hbm_us, 'hbm' if hbm_us > mf_us else 'mfma', 100 * roof / us, d.algo))
 print('total %.1f us; sum of per-layer rooflines %.1f us' % (sum_us, sum_roof))

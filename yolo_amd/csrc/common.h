@@ -40,4 +40,4 @@ static inline int elem_size(int dtype) { return dtype == YOLO_BF16 ? 2 : 4; }
 // channels held by one 64-byte K-chunk
 static inline int chunk_channels(int dtype) { return 64 / elem_size(dtype); }
 // packed weights / scale / bias are padded to a multiple of this many output channels
-#define YOLO_COUT_PAD 128
+#define YOLO_COUT_PAD 256

@@ -1,0 +1,141 @@
+// Shared epilogue of the implicit-GEMM convolutions: folded BN (scale, bias), LeakyReLU, residual
+// add, one rounding to the activation dtype, NHWC store.
+//
+// The MFMA accumulator holds, per lane, 4 consecutive couts of ONE pixel (D rows = cout), which
+// as a direct store is an 8-byte write at a pixel-strided address and makes every residual load a
+// dependent round trip.  Instead each wave transposes its 32-pixel x (MI*32)-cout slab through a
+// private LDS scratch (fp32, row stride padded by 16 B: conflict-free b128 writes and reads) so
+// that afterwards a lane owns 16 contiguous output bytes of a pixel row:
+//   * scale/bias are loaded once per wave tile (the lane's couts do not change across rows),
+//   * all residual loads of a slab are issued back-to-back (one latency, not 16),
+//   * loads and stores are 16 B per lane, LPR lanes covering one contiguous cout run of a pixel.
+// Rounding order is unchanged: fp32 (acc*scale+bias) -> LeakyReLU -> + residual (fp32) -> round.
+#pragma once
+#include "conv_args.h"
+
+// bytes of LDS scratch one wave needs (max over MI in {1,2}): 32 rows x (64*4+16) + 32 x 8
+#define YOLO_EPI_WAVE_BYTES 9216
+
+template <typename T, int MI, int NI>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long long (&yoff)[NI], char* wsm,
+                                              const ConvArgs& a, int co_w, int lane) {
+    constexpr int WN = MI * 32;                 // couts of the wave tile
+    constexpr int RS = WN * 4 + 16;             // fp32 row stride in the scratch (bytes)
+    constexpr int ES = (int)sizeof(T);
+    constexpr int CPL = 16 / ES;                // couts per lane after the transpose
+    constexpr int LPR = WN / CPL;               // lanes per pixel row
+    constexpr int RPP = 64 / LPR;               // rows per pass
+    constexpr int NPASS = 32 / RPP;
+    static_assert(32 * RS + 32 * 8 <= YOLO_EPI_WAVE_BYTES, "scratch size");
+    const int l31 = lane & 31, h = lane >> 5;
+    const float slope = a.slope;
+
+    if (a.out_f32 || (a.Cout % CPL) != 0 || ((a.y_ps * ES) % 16) != 0 || ((a.y_bs * ES) % 16) != 0) {
+        // ---- generic path: arbitrary Cout / strides / fp32 logits (small head-output layers) -----
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            if (yoff[ni] < 0) continue;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = co_w + mi * 32 + 8 * g + 4 * h;
+                    if (co >= a.Cout) continue;
+                    const f32x4 sc = *(const f32x4*)(a.scale + co);
+                    const f32x4 bi = *(const f32x4*)(a.bias + co);
+                    const long long o = yoff[ni] + co;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (co + e >= a.Cout) continue;
+                        float t = acc[mi][ni][4 * g + e] * sc[e] + bi[e];
+                        t = t > 0.f ? t : t * slope;
+                        if (a.out_f32) {
+                            ((float*)a.y)[o + e] = t;
+                        } else if constexpr (ES == 2) {
+                            if (a.res) t += bf16_bits_to_f32(((const uint16_t*)a.res)[o + e]);
+                            ((uint16_t*)a.y)[o + e] = (uint16_t)f32_to_bf16_bits(t);
+                        } else {
+                            if (a.res) t += ((const float*)a.res)[o + e];
+                            ((float*)a.y)[o + e] = t;
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- transposed path ---------------------------------------------------------------------------
+    const int col = lane % LPR;
+    const int row0 = lane / LPR;
+    const int co = co_w + col * CPL;
+    const bool co_ok = co < a.Cout;
+    float sc[CPL], bi[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL / 4; ++q) {
+        const f32x4 s4 = *(const f32x4*)(a.scale + co + 4 * q);     // arrays are padded to the cout tile
+        const f32x4 b4 = *(const f32x4*)(a.bias + co + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc[4 * q + e] = s4[e]; bi[4 * q + e] = b4[e]; }
+    }
+    long long* ytab = (long long*)(wsm + 32 * RS);
+    const bool has_res = a.res != nullptr;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        if (h == 0) ytab[l31] = yoff[ni];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+                *(f32x4*)(wsm + l31 * RS + (mi * 32 + 8 * g + 4 * h) * 4) = v;
+            }
+        long long yo[NPASS];
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) yo[k] = co_ok ? ytab[row0 + k * RPP] : -1;
+        uint4 rv[NPASS];
+        if (has_res) {
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k) {
+                rv[k] = make_uint4(0, 0, 0, 0);
+                if (yo[k] >= 0) rv[k] = *(const uint4*)(a.res + (yo[k] + co) * ES);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+            float v[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL / 4; ++q) {
+                const f32x4 t4 = *(const f32x4*)(wsm + (row0 + k * RPP) * RS + (col * CPL + 4 * q) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * q + e] = t4[e];
+            }
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) {
+                const float t = v[e] * sc[e] + bi[e];
+                v[e] = t > 0.f ? t : t * slope;
+            }
+            uint4 ov;
+            if constexpr (ES == 2) {
+                if (has_res) {
+                    const uint32_t w[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v[2 * q] += bf16_bits_to_f32(w[q] & 0xffffu);
+                        v[2 * q + 1] += bf16_bits_to_f32(w[q] >> 16);
+                    }
+                }
+                ov = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                pack_bf16x2(v[6], v[7]));
+            } else {
+                if (has_res) {
+                    v[0] += __uint_as_float(rv[k].x); v[1] += __uint_as_float(rv[k].y);
+                    v[2] += __uint_as_float(rv[k].z); v[3] += __uint_as_float(rv[k].w);
+                }
+                ov = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                                __float_as_uint(v[3]));
+            }
+            if (yo[k] >= 0) *(uint4*)(a.y + (yo[k] + co) * ES) = ov;
+        }
+    }
+}

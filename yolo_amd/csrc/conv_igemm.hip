@@ -15,22 +15,11 @@
 //   ("padded strip" image: rows of the stacked batch with a zero row between images and zero
 //   columns at the image edges) and the 9 taps read it at uniform slot offsets kh*PW+kw.
 #include "common.h"
+#include "conv_args.h"
+#include "conv_epilogue.h"
 #include <stdio.h>
+#include <stdlib.h>
 
-struct ConvArgs {
-    const char* x;
-    const char* wp;
-    const float* scale;
-    const float* bias;
-    const char* res;
-    char* y;
-    int N, H, W, Cin, Ho, Wo, Cout, Cout_pad;
-    int TWt, nstrips, tiles_per_strip, PW, total_i;
-    int nchunks, tiles_c;
-    int out_f32;
-    float slope;
-    long long y_bs, y_ps;
-};
 
 template <typename T> struct Frag;
 template <> struct Frag<__bf16> {
@@ -68,7 +57,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     constexpr int NTAP = (KS == 3) ? 9 : 1;
     static_assert(KS == 3 || XSLOTS == BP, "1x1: one slot per pixel");
 
-    __shared__ __attribute__((aligned(16))) char smem[(X_UNITS + W_UNITS) * 16];
+    constexpr int STAGE_BYTES = (X_UNITS + W_UNITS) * 16;
+    constexpr int EPI_BYTES = 4 * YOLO_EPI_WAVE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES];
     char* Xl = smem;
     char* Wl = smem + X_UNITS * 16;
 
@@ -237,52 +228,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         }
     }
 
-    // ---- epilogue: folded BN, LeakyReLU, residual, store NHWC ------------------------------
-    const float slope = a.slope;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        if (yoff[ni] < 0) continue;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = co0 + (wave_c * MI + mi) * 32 + 8 * g + 4 * h;
-                if (co >= a.Cout) continue;
-                const f32x4 sc = *(const f32x4*)(a.scale + co);
-                const f32x4 bi = *(const f32x4*)(a.bias + co);
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = acc[mi][ni][4 * g + e] * sc[e] + bi[e];
-                    v[e] = t > 0.f ? t : t * slope;
-                }
-                const long long o = yoff[ni] + co;
-                if (a.out_f32) {
-                    float* yp = (float*)a.y + o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (co + e < a.Cout) yp[e] = v[e];
-                } else if constexpr (sizeof(T) == 2) {
-                    if (a.res) {
-                        const uint2 rv = *(const uint2*)((const uint16_t*)a.res + o);
-                        v[0] += bf16_bits_to_f32(rv.x & 0xffffu);
-                        v[1] += bf16_bits_to_f32(rv.x >> 16);
-                        v[2] += bf16_bits_to_f32(rv.y & 0xffffu);
-                        v[3] += bf16_bits_to_f32(rv.y >> 16);
-                    }
-                    *(uint2*)((uint16_t*)a.y + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                } else {
-                    if (a.res) {
-                        const f32x4 rv = *(const f32x4*)((const float*)a.res + o);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
-                    }
-                    f32x4 ov = {v[0], v[1], v[2], v[3]};
-                    *(f32x4*)((float*)a.y + o) = ov;
-                }
-            }
-        }
-    }
+    // ---- epilogue (conv_epilogue.h): every wave transposes its slab through its own LDS scratch ------
+    __syncthreads();                     // all waves are done reading the staged tiles
+    conv_epilogue<T, MI, NI>(acc, yoff, smem + wave * YOLO_EPI_WAVE_BYTES, a, co0 + wave_c * MI * 32, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -291,20 +239,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 constexpr int XSLOTS_S1 = 384;
 constexpr int XSLOTS_S2 = 832;
 
-// Worst-case number of LDS slots for a BP-pixel tile on strips of width d.
-static int halo_slots(int BP, int d, int Ho, int H, int S, long long total_rows) {
-    long long nro = (BP - 1 + d - 1) / d + 1;
-    if (nro > total_rows) nro = total_rows;
-    const long long nb = (nro - 1 + Ho - 1) / Ho;
-    const int extra = H + 1 - Ho * S;
-    const long long NR = (long long)S * (nro - 1) + 3 + nb * (extra > 0 ? extra : 0);
-    const int PW = (d - 1) * S + 3;
-    return (int)(NR * PW);
-}
-
-// `name` != nullptr: write the kernel instantiation that WOULD run (rocprofv3's demangled name) and
-// do not launch.
-struct NameOut { char* buf; int len; };
 
 template <typename T, int KS, int S, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int TS>
 static int launch_cfg(ConvArgs& a, hipStream_t st, const NameOut* name) {
@@ -318,7 +252,7 @@ static int launch_cfg(ConvArgs& a, hipStream_t st, const NameOut* name) {
         int best = -1, best_hs = 1 << 30;
         for (int d = 1; d <= a.Wo; ++d) {
             if (a.Wo % d) continue;
-            const int hs = halo_slots(BP, d, a.Ho, a.H, S, (long long)a.N * a.Ho);
+            const int hs = conv_halo_slots(BP, d, a.Ho, a.H, S, (long long)a.N * a.Ho);
             if (hs <= XSLOTS && hs <= best_hs) { best = d; best_hs = hs; }
         }
         if (best < 0) return YOLO_EUNSUPPORTED;
@@ -363,6 +297,30 @@ static int launch_dtype(ConvArgs& a, int ks, int stride, hipStream_t st, const N
 
 static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* nm);
 
+// Heuristic choice of the pipelined variant for algo == 0 (1 = stay on the generic kernel): minimise
+// rounds x tile work, where rounds = ceil(tiles / (256 CUs x resident blocks per CU)) -- at the
+// reference's batch sizes tile quantisation on the 13x13 / 26x26 maps costs more than any difference
+// between the variants' inner loops.  The per-variant factors are measured (tools/conv_bench.py).
+static int conv_auto_algo(const ConvArgs& a, int ks, int stride, int dtype) {
+    if (stride != 1 || (a.Cin * elem_size(dtype)) % 64 || a.nchunks < 2) return 1;
+    struct V { int algo, bp, bc, bpc; float f; bool k1; };
+    static const V vs[] = {{2, 256, 256, 1, 1.00f, true}, {3, 256, 128, 1, 1.10f, true}, {4, 128, 128, 2, 1.05f, true},
+                           {6, 192, 256, 1, 1.00f, false}, {8, 192, 128, 2, 1.05f, true}};
+    const long long px = (long long)a.N * a.Ho * a.Wo;
+    int best = 1;
+    double best_cost = 1e30;
+    for (const V& v : vs) {
+        if (ks == 1 && !v.k1) continue;
+        const long long tiles = ((px + v.bp - 1) / v.bp) * ((a.Cout + v.bc - 1) / v.bc);
+        const long long slots = 256LL * v.bpc;
+        const long long rounds = (tiles + slots - 1) / slots;
+        // a partially filled last round still costs a full block time; blocks co-resident on a CU share it
+        const double cost = (double)rounds * v.bp * v.bc * v.bpc * v.f;
+        if (cost < best_cost) { best_cost = cost; best = v.algo; }
+    }
+    return best;
+}
+
 extern "C" int yolo_conv_fwd(const yolo_conv_desc* d, void* stream) { return conv_dispatch(d, stream, nullptr); }
 
 extern "C" int yolo_conv_kernel_name(const yolo_conv_desc* d, char* buf, int len) {
@@ -395,11 +353,23 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     a.Cout_pad = round_up(d->Cout, YOLO_COUT_PAD);
     a.nchunks = (d->Cin * es + 63) / 64;
     a.out_f32 = d->out_f32;
+    a.dbg = 0;
+    if (const char* e = getenv("YOLO_DBG")) a.dbg = atoi(e);
     a.slope = d->slope;
     a.y_ps = d->y_pixel_stride ? d->y_pixel_stride : d->Cout;
     a.y_bs = d->y_batch_stride ? d->y_batch_stride : (long long)a.Ho * a.Wo * a.y_ps;
     if (a.res && (d->y_pixel_stride || d->y_batch_stride || d->out_f32)) return YOLO_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    if (d->algo < 0) return YOLO_EINVAL;
+    if (d->algo >= 2) return conv_pipe_dispatch(a, d->ksize, d->stride, d->dtype, d->algo, st, nm);
+    if (d->algo == 0) {
+        const int pick = conv_auto_algo(a, d->ksize, d->stride, d->dtype);
+        if (pick >= 2) {
+            ConvArgs b = a;
+            const int rc = conv_pipe_dispatch(b, d->ksize, d->stride, d->dtype, pick, st, nm);
+            if (rc != YOLO_EUNSUPPORTED) return rc;
+        }
+    }
     if (d->dtype == YOLO_BF16) return launch_dtype<__bf16>(a, d->ksize, d->stride, st, nm);
     return launch_dtype<float>(a, d->ksize, d->stride, st, nm);
 }

@@ -1,0 +1,379 @@
+// Pipelined implicit-GEMM convolution for gfx950: the fast path for 3x3 stride-1 and 1x1 layers
+// whose K-chunks are whole (Cin*sizeof(T) % 64 == 0).  Same math, data layout, packed-weight
+// image and epilogue as conv_igemm.hip (the generic path); what differs is the memory pipeline:
+//
+//   * global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR
+//     staging, no ds_write pass).  The LDS image is lane-linear, so the bank-conflict XOR swizzle
+//     is applied to the per-lane SOURCE address (weights: at pack time) and again on the read.
+//   * weights stream through a 3-deep ring, one ring slot per "phase" (PT taps of a 3x3, or one
+//     K-chunk of a 1x1); the zero-padded input halo tile is double-buffered per K-chunk and read
+//     by all 9 taps.  Loads for phase p+2 are issued at the top of phase p; the only wait is a
+//     COUNTED s_waitcnt vmcnt(N) (N = loads issued in this phase) in front of ONE raw s_barrier per
+//     phase, so DMA stays in flight across barriers.  Zero padding / image edges are DMA'd from a
+//     zero page: no predication anywhere in the main loop.
+//   * XCD-aware block order: the blocks that share an input tile (different cout tiles) are
+//     consecutive on one XCD so its L2 serves the re-reads.
+#include "common.h"
+#include "conv_args.h"
+#include "conv_epilogue.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+
+__device__ __attribute__((aligned(64))) unsigned int yolo_zero_page[16];
+
+typedef __attribute__((address_space(3))) char lds_char;
+
+// One 16-byte-per-lane LDS-DMA: LDS[lds_dst + lane*16 .. +16) = *gsrc (per-lane source).
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst_uniform) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst_uniform)
+                 : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T> struct FragP;
+template <> struct FragP<__bf16> {
+    static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                    0, 0);
+    }
+};
+template <> struct FragP<float> {
+    static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+
+// bijective XCD remap (8 XCDs, block b runs on XCD b % 8): logical ids are contiguous per XCD
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// KS=3 (stride 1): phase = one tap; X halo tile of XSLOTS slots, double-buffered per K-chunk.
+// KS=1           : phase = one K-chunk; X tile = BP slots, 3-deep ring like the weights.
+// The LDS-DMAs of a phase are NOT issued in a burst after the barrier (that stalls both waves of a
+// SIMD in the VMEM issue queue at the same moment and idles the matrix pipe: measured -25..-35 %):
+// they are interleaved between the MFMAs, and the second half of the waves (which shares SIMDs with
+// the first half) issues them at shifted positions, so a wave stuck in a DMA issue is covered by its
+// SIMD partner's MFMAs.
+template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS>
+__global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvArgs a) {
+    constexpr int PT = 1;
+    constexpr int NW = WAVES_P * WAVES_C;
+    constexpr int NT = NW * 64;
+    constexpr int BP = WAVES_P * NI * 32;
+    constexpr int BC = WAVES_C * MI * 32;
+    constexpr int NTAP = KS * KS;
+    constexpr int PPC = NTAP / PT;                       // phases per K-chunk
+    static_assert(NTAP % PT == 0 && (KS == 3 || PT == 1), "phase shape");
+    constexpr int W_STAGE = PT * BC * 64;                // bytes per weight ring slot
+    constexpr int WL = W_STAGE / (NT * 16);              // LDS-DMAs per thread per phase (weights)
+    static_assert(W_STAGE % (NT * 16) == 0, "weight stage must be whole DMAs");
+    constexpr int X_STAGE = XSLOTS * 64;
+    constexpr int XL = X_STAGE / (NT * 16);              // LDS-DMAs per thread per X tile
+    static_assert(X_STAGE % (NT * 16) == 0, "input stage must be whole DMAs");
+    constexpr int XBUFS = (KS == 3) ? 2 : 3;
+    static_assert(KS == 3 || XSLOTS == BP, "1x1: one slot per pixel");
+    constexpr int W_OFF = XBUFS * X_STAGE;
+    // 3x3: the X DMAs of the next chunk are spread over the phases of this chunk (phase q issues
+    // j = q, q+PPC, ...)
+
+    constexpr int PIPE_BYTES = XBUFS * X_STAGE + 3 * W_STAGE;
+    constexpr int EPI_BYTES = NW * YOLO_EPI_WAVE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wave_p = wave % WAVES_P, wave_c = wave / WAVES_P;
+
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_c = lid % a.tiles_c;
+    const int tile_p = lid / a.tiles_c;
+    const int strip = tile_p / a.tiles_per_strip;
+    const int i0 = (tile_p - strip * a.tiles_per_strip) * BP;
+    const int co0 = tile_c * BC;
+    const int H = a.H, W = a.W, Ho = a.Ho, Wo = a.Wo, TWt = a.TWt, PW = a.PW;
+    const int row_bytes = a.Cin * (int)sizeof(T);
+
+    int Rin_lo = 0, HS = XSLOTS, x0 = 0;
+    if constexpr (KS == 3) {
+        const int i_last = min(i0 + BP, a.total_i) - 1;
+        const int r_first = i0 / TWt, r_last = i_last / TWt;
+        const int n_f = r_first / Ho, n_l = r_last / Ho;
+        Rin_lo = n_f * (H + 1) + (r_first - n_f * Ho);
+        const int Rin_hi = n_l * (H + 1) + (r_last - n_l * Ho) + 2;
+        HS = (Rin_hi - Rin_lo + 1) * PW;
+        x0 = strip * TWt - 1;
+    }
+
+    // ---- per-thread DMA sources: byte offset of the slot's 16-byte unit for chunk 0 (32-bit: the host
+    //      checks the activation tensor is < 4 GiB), or ~0 for a zero-padding slot (DMA'd from the zero page)
+    unsigned xo[XL];
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+        const int u = tid + j * NT;
+        const int slot = u >> 2, part = u & 3;
+        bool valid;
+        long long off;
+        if constexpr (KS == 3) {
+            const int rr = slot / PW, cc = slot - rr * PW;
+            const int Rr = Rin_lo + rr;
+            const int n = Rr / (H + 1);
+            const int yy = Rr - n * (H + 1) - 1;
+            const int xx = x0 + cc;
+            valid = slot < HS && yy >= 0 && n < a.N && xx >= 0 && xx < W;
+            off = ((long long)(n * H + yy) * W + xx) * row_bytes;
+        } else {
+            const int i = i0 + slot;
+            valid = i < a.total_i;
+            off = (long long)i * row_bytes;
+        }
+        const int lp = (part ^ ((slot >> 2) & 3)) * 16;
+        xo[j] = valid ? (unsigned)(off + lp) : 0xffffffffu;
+    }
+    const char* wsrc = a.wp + (long long)co0 * 64 + tid * 16;
+    const long long wplane = (long long)a.Cout_pad * 64;
+    static_assert((BC * 4) % NT == 0 || NT % (BC * 4) == 0, "tap index must be uniform per DMA");
+
+    // ---- per-lane MFMA operand bases ------------------------------------------------------------
+    int slot00[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int i = i0 + (wave_p * NI + ni) * 32 + l31;
+        const int ii = (i < a.total_i) ? i : i0;
+        if constexpr (KS == 3) {
+            const int r = ii / TWt;
+            const int tx = ii - r * TWt;
+            const int n = r / Ho;
+            slot00[ni] = (n * (H + 1) + (r - n * Ho) - Rin_lo) * PW + tx;
+        } else {
+            slot00[ni] = ii - i0;
+        }
+    }
+    const int aoff0 = (wave_c * MI * 32 + l31) * 64 + ((h ^ ((l31 >> 2) & 3)) << 4);
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int nchunks = a.nchunks;
+    const int nphase = nchunks * PPC;
+    const uint32_t wave_lds = lds0 + wave * 1024;        // this wave's 1 KiB lane-linear window per DMA
+
+    // weights of global phase gp (clamped: the tail re-loads the last plane into a dead ring slot so
+    // every phase issues the same number of DMAs and the counted waits stay exact)
+    // weight DMA j (of WL) of global phase gp; the tail is clamped: it re-loads the last plane into a
+    // dead ring slot so every phase issues the same number of DMAs and the counted waits stay exact
+    auto issue_w1 = [&](int gp, int j) {
+        const int g = min(gp, nphase - 1);
+        glds16(wsrc + (long long)g * wplane + (long long)j * NT * 16,
+               wave_lds + W_OFF + (gp % 3) * W_STAGE + j * NT * 16);
+    };
+    auto issue_w = [&](int gp) {
+#pragma unroll
+        for (int j = 0; j < WL; ++j) issue_w1(gp, j);
+    };
+    // input DMA j of chunk c into X buffer `buf`
+    auto issue_x = [&](int j, int c, int buf) {
+        const int cc = min(c, nchunks - 1);
+        const char* src = (xo[j] != 0xffffffffu) ? a.x + ((size_t)xo[j] + (size_t)cc * 64) : (const char*)yolo_zero_page;
+        glds16(src, wave_lds + buf * X_STAGE + j * NT * 16);
+    };
+    static_assert(KS == 1 || XL <= PPC, "3x3: at most one input DMA per phase");
+    static_assert(BC * 4 >= NT, "one weight DMA covers rows of a single tap plane");
+
+    // ---- prologue ------------------------------------------------------------------------------
+    if constexpr (KS == 3) {
+#pragma unroll
+        for (int j = 0; j < XL; ++j) issue_x(j, 0, 0);
+        issue_w(0);
+        issue_w(1);
+        wait_vmcnt<WL>();
+    } else {
+#pragma unroll
+        for (int j = 0; j < XL; ++j) issue_x(j, 0, 0);
+        issue_w(0);
+#pragma unroll
+        for (int j = 0; j < XL; ++j) issue_x(j, 1, 1);
+        issue_w(1);
+        wait_vmcnt<WL + XL>();
+    }
+    __builtin_amdgcn_s_barrier();
+
+    constexpr int NM = 2 * MI * NI;                     // MFMA "steps" per phase (one 16-byte operand pair each)
+    // one phase; SHIFT = first MFMA step after which a DMA is issued (differs between the wave halves)
+    auto phase = [&](auto shift_c, int c, int q, int gp) {
+        constexpr int SHIFT = decltype(shift_c)::value;
+        const int nx = (KS == 3) ? (q < XL ? 1 : 0) : XL;          // input DMAs of this phase
+        const int nd = nx + WL;
+        const int stride = (NM - SHIFT) / (nd > 0 ? nd : 1) > 0 ? (NM - SHIFT) / (nd > 0 ? nd : 1) : 1;
+        auto issue_item = [&](int k) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (k < nx) {
+                if constexpr (KS == 3) issue_x(q, c + 1, (c + 1) & 1);
+                else issue_x(k, gp + 2, (gp + 2) % 3);
+            } else {
+                issue_w1(gp + 2, k - nx);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        const char* Wl = smem + W_OFF + (gp % 3) * W_STAGE;
+        const char* Xl = smem + ((KS == 3) ? (c & 1) : (gp % 3)) * X_STAGE;
+        int bx[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int slot = (KS == 3) ? slot00[ni] + (q / 3) * PW + (q % 3) : slot00[ni];
+            bx[ni] = slot * 64 + ((h ^ ((slot >> 2) & 3)) << 4);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 af[MI], bf[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) af[mi] = *(const uint4*)(Wl + mi * 2048 + (aoff0 ^ (ks * 32)));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bf[ni] = *(const uint4*)(Xl + (bx[ni] ^ (ks * 32)));
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    FragP<T>::mma(af[mi], bf[ni], acc[mi][ni]);
+                    const int m = (ks * MI + mi) * NI + ni;
+#pragma unroll
+                    for (int k = 0; k < XL + WL; ++k)
+                        if (k < nd && m == min(SHIFT + k * stride, NM - 1)) issue_item(k);
+                }
+        }
+        // phase gp+1's data must have landed: everything except what this phase issued for gp+2 (the
+        // input DMAs are issued before the weight DMAs, so leaving WL outstanding covers them too)
+        if constexpr (KS == 3) wait_vmcnt<WL>();
+        else wait_vmcnt<WL + XL>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);      // keep the next phase's address math out of this phase (VGPR pressure)
+    };
+    for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+        for (int q = 0; q < PPC; ++q) {
+            const int gp = c * PPC + q;
+            phase(std::integral_constant<int, 1>{}, c, q, gp);
+        }
+    }
+    wait_vmcnt<0>();     // the tail's dead DMAs must land before the block's LDS is released
+
+    // ---- epilogue (conv_epilogue.h): every wave transposes its slab through its own LDS scratch ------
+    __builtin_amdgcn_s_barrier();        // all waves are done reading the pipeline's LDS
+    long long yoff[NI];                  // output element offset of each lane's pixels (-1: none)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int i = i0 + (wave_p * NI + ni) * 32 + l31;
+        int n, pix;
+        if constexpr (KS == 3) {
+            const int r = i / TWt;
+            const int tx = i - r * TWt;
+            n = r / Ho;
+            pix = (r - n * Ho) * Wo + strip * TWt + tx;
+        } else {
+            n = i / (Ho * Wo);
+            pix = i - n * (Ho * Wo);
+        }
+        yoff[ni] = (i < a.total_i) ? (long long)n * a.y_bs + (long long)pix * a.y_ps : -1;
+    }
+    conv_epilogue<T, MI, NI>(acc, yoff, smem + wave * YOLO_EPI_WAVE_BYTES, a, co0 + wave_c * MI * 32, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS>
+static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
+    constexpr int BP = WAVES_P * NI * 32, BC = WAVES_C * MI * 32;
+    if (KS == 3) {
+        int best = -1, best_hs = 1 << 30;
+        for (int d = 1; d <= a.Wo; ++d) {
+            if (a.Wo % d) continue;
+            const int hs = conv_halo_slots(BP, d, a.Ho, a.H, 1, (long long)a.N * a.Ho);
+            if (hs <= XSLOTS && hs <= best_hs) { best = d; best_hs = hs; }
+        }
+        if (const char* e = getenv("YOLO_FORCE_TWT")) {     // experiment knob: force the strip width
+            const int d = atoi(e);
+            if (d > 0 && a.Wo % d == 0 && conv_halo_slots(BP, d, a.Ho, a.H, 1, (long long)a.N * a.Ho) <= XSLOTS) best = d;
+        }
+        if (best < 0) return YOLO_EUNSUPPORTED;
+        a.TWt = best;
+        a.PW = best + 2;
+    } else {
+        a.TWt = a.Wo;
+        a.PW = a.Wo;
+    }
+    a.nstrips = a.Wo / a.TWt;
+    const long long tot = (long long)a.N * a.Ho * a.TWt;
+    if (tot > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
+    a.total_i = (int)tot;
+    a.tiles_per_strip = (a.total_i + BP - 1) / BP;
+    a.tiles_c = (a.Cout + BC - 1) / BC;
+    const long long grid = (long long)a.nstrips * a.tiles_per_strip * a.tiles_c;
+    if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
+    if (name) {
+        snprintf(name->buf, name->len, "void conv_pipe_kernel<%s, %d, %d, %d, %d, %d, %d>(ConvArgs)",
+                 sizeof(T) == 2 ? "__bf16" : "float", KS, WAVES_P, WAVES_C, MI, NI, XSLOTS);
+        return YOLO_OK;
+    }
+    YOLO_LAUNCH((conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS>), dim3((unsigned)grid),
+                dim3(WAVES_P * WAVES_C * 64), 0, st, a);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}
+
+// algo ids (yolo_conv_desc.algo): 1 = generic (conv_igemm.hip); pipelined variants:
+//   2: 8 waves, 256 px x 256 cout (wave tile 128x64)   3: 8 waves, 256 px x 128 cout (wave tile 64x64)
+//   4: 4 waves, 128 px x 128 cout (wave tile 64x64)    5: 8 waves, 128 px x 256 cout (wave tile 128x32)
+//   6: 8 waves, 192 px x 256 cout (wave tile 96x64)    7: 8 waves, 192 px x 128 cout (wave tile 96x32)
+//   8: 4 waves, 192 px x 128 cout (wave tile 96x64)    -- 192-pixel tiles exist to cut tile quantisation
+template <typename T>
+static int pipe_dispatch_t(ConvArgs& a, int ks, int algo, hipStream_t st, const NameOut* nm) {
+    if (ks == 3) {
+        switch (algo) {
+            case 2: return launch_pipe<T, 3, 2, 4, 2, 4, 512>(a, st, nm);
+            case 3: return launch_pipe<T, 3, 4, 2, 2, 2, 512>(a, st, nm);
+            case 4: return launch_pipe<T, 3, 2, 2, 2, 2, 256>(a, st, nm);
+            case 5: return launch_pipe<T, 3, 1, 8, 1, 4, 256>(a, st, nm);
+            case 6: return launch_pipe<T, 3, 2, 4, 2, 3, 384>(a, st, nm);
+            case 7: return launch_pipe<T, 3, 2, 4, 1, 3, 384>(a, st, nm);
+            case 8: return launch_pipe<T, 3, 2, 2, 2, 3, 320>(a, st, nm);
+        }
+    } else {
+        switch (algo) {
+            case 2: return launch_pipe<T, 1, 2, 4, 2, 4, 256>(a, st, nm);
+            case 3: return launch_pipe<T, 1, 4, 2, 2, 2, 256>(a, st, nm);
+            case 4: return launch_pipe<T, 1, 2, 2, 2, 2, 128>(a, st, nm);
+            case 5: return launch_pipe<T, 1, 1, 8, 1, 4, 128>(a, st, nm);
+            case 8: return launch_pipe<T, 1, 2, 2, 2, 3, 192>(a, st, nm);
+        }
+    }
+    return YOLO_EUNSUPPORTED;
+}
+
+int conv_pipe_dispatch(ConvArgs& a, int ks, int stride, int dtype, int algo, hipStream_t st, const NameOut* nm) {
+    if (stride != 1 || (ks != 1 && ks != 3)) return YOLO_EUNSUPPORTED;
+    if ((a.Cin * elem_size(dtype)) % 64) return YOLO_EUNSUPPORTED;
+    if (a.nchunks < 2) return YOLO_EUNSUPPORTED;
+    if ((long long)a.N * a.H * a.W * a.Cin * elem_size(dtype) >= 0xffffff00LL) return YOLO_EUNSUPPORTED;
+    if (dtype == YOLO_BF16) return pipe_dispatch_t<__bf16>(a, ks, algo, st, nm);
+    return pipe_dispatch_t<float>(a, ks, algo, st, nm);
+}

@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-LIB_PATH = os.path.join(CSRC, 'libyolo_amd.so')
+LIB_PATH = os.environ.get('YOLO_AMD_LIB') or os.path.join(CSRC, 'libyolo_amd.so')   # override: experiment builds
 
 F32, BF16 = 0, 1
 
@@ -23,7 +23,8 @@ class ConvDesc(C.Structure):
                 ('residual', C.c_void_p), ('y', C.c_void_p),
                 ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int),
                 ('ksize', C.c_int), ('stride', C.c_int), ('dtype', C.c_int), ('out_f32', C.c_int),
-                ('slope', C.c_float), ('y_batch_stride', C.c_longlong), ('y_pixel_stride', C.c_longlong)]
+                ('slope', C.c_float), ('y_batch_stride', C.c_longlong), ('y_pixel_stride', C.c_longlong),
+                ('algo', C.c_int)]
 
 
 class GridDesc(C.Structure):

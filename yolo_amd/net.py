@@ -29,7 +29,9 @@ class _Plan(object):
 
 
 class CarNet(object):
-    def __init__(self, spec, num_sync_bn_devices=-1, dtype='bf16', device='cuda:0'):
+    ALGOS = (1, 2, 3, 4, 5, 6, 7, 8)     # yolo_conv_desc.algo ids tried by tune='measure'
+
+    def __init__(self, spec, num_sync_bn_devices=-1, dtype='bf16', device='cuda:0', tune='auto'):
         # num_sync_bn_devices is accepted for signature parity; the reference always passes -1
         # (no SyncBN, car/YOLO.py:94-96).
         if dtype not in _TORCH_DT:
@@ -37,6 +39,12 @@ class CarNet(object):
         self.graph = NetGraph(spec)
         self.dtype = dtype
         self.device = torch.device(device)
+        # tune: 'auto' = the library's heuristic picks the conv tile variant; 'measure' = time every
+        # variant once per distinct layer shape when a plan is built (HIP events) and pin the fastest
+        if tune not in ('auto', 'measure'):
+            raise ValueError("tune must be 'auto' or 'measure'")
+        self.tune = tune
+        self._algo_cache = {}
         self.params = {}
         self._prepared = {}
         self._plans = {}
@@ -123,10 +131,38 @@ class CarNet(object):
         d.out_f32 = 1 if out_f32 else 0
         d.slope = LEAKY_SLOPE if c.bn else 1.0
         d.y_batch_stride, d.y_pixel_stride = y_bs, y_ps
+        if self.tune == 'measure':
+            d.algo = self._measure_algo(d)
         plan.ops.append(('conv', d, c.name))
         if not isinstance(out, int):
             plan.act[c.name] = (out, (N, ho, wo, c.cout))
         return out, (N, ho, wo, c.cout)
+
+    def _measure_algo(self, d, iters=5):
+        """Fastest conv variant for this layer shape (cached).  Outputs are overwritten while timing,
+        which is harmless: the plan has not run yet."""
+        key = (d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.out_f32, bool(d.residual), d.dtype)
+        if key in self._algo_cache:
+            return self._algo_cache[key]
+        lib, st = self._lib, L.stream_ptr()
+        best, best_t = 1, float('inf')
+        for algo in self.ALGOS:
+            d.algo = algo
+            if lib.yolo_conv_fwd(C.byref(d), st) != 0:
+                continue
+            lib.yolo_conv_fwd(C.byref(d), st)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                lib.yolo_conv_fwd(C.byref(d), st)
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if t < best_t:
+                best, best_t = algo, t
+        d.algo = 0
+        self._algo_cache[key] = best
+        return best
 
     def _build_plan(self, B, H, W):
         g = self.graph
