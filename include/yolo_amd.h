@@ -87,6 +87,14 @@ int yolo_conv_fwd(const yolo_conv_desc* d, void* stream);
  * used by bench.py to attribute measured time to the dominant kernel.  Host-only, no launch. */
 int yolo_conv_kernel_name(const yolo_conv_desc* d, char* buf, int len);
 
+/* The network's first _conv2d (basic_yolo.py:20) fused with the image layout change: Conv3x3 s1 p1 over
+ * the (N,3,H,W) float32 NCHW image exactly as the reference feeds it (car/YOLO.py:381) + folded BN +
+ * LeakyReLU -> (N,H,W,Cout) bf16 NHWC.  w_oihw: (Cout,3,3,3) float32 (unpacked); Cout % 4 == 0, <= 64;
+ * dtype must be YOLO_BF16 (YOLO_F32 callers use yolo_nchw_to_nhwc + yolo_conv_fwd: EUNSUPPORTED here). */
+int yolo_stem_conv_fwd(const float* x_nchw, const float* w_oihw, const float* scale, const float* bias,
+                       void* y, int N, int H, int W, int Cin, int Cout, int dtype, float slope,
+                       void* stream);
+
 /* 2x nearest up-sample of `up` (N,H/2,W/2,C1) + channel concat with `route` (N,H,W,C2) ->
  * (N,H,W,C1+C2), up-sampled channels first: gluoncv _upsample + F.concat, car/utils.py:92-93. */
 int yolo_upsample2x_concat(const void* up, const void* route, void* y, int N, int H, int W,

@@ -102,7 +102,9 @@ def test_d53_416_f32_measured_tuning(cuda):
     det = Detector(spec, size, steps, device=cuda)
     rows = det.decode([torch.from_numpy(o).to(cuda) for o in outs]).cpu().numpy()
     ref_rows = od.decode_all(ref, spec['slice_point'], size, syxhw)
-    assert np.abs(rows[..., :5] - ref_rows[..., :5]).max() < 1e-3               # score + ltrb
+    # boxes are exp(th)*anchor: with random weights |th| reaches ~18, so the 1e-3 bar is relative there
+    err = np.abs(rows[..., :5] - ref_rows[..., :5]) / (1.0 + np.abs(ref_rows[..., :5]))
+    assert err.max() < 1e-3                                                      # score + ltrb
 
 
 def test_zero_input_known_answer(cuda):

@@ -34,7 +34,7 @@ sum_us = sum_roof = 0
 for (kind, payload, name), (_, kname, fl) in zip(plan.ops, kern):
     us = tot[name] / a.iters * 1e3
     if kind != 'conv':
-        print('%-22s %58s %8.1f' % (name, '', us)); sum_us += us; continue
+        print('%-22s %58s %8.1f' % (name, kind, us)); sum_us += us; continue
     d = payload
     pad = d.ksize // 2
     ho, wo = (d.H + 2 * pad - d.ksize) // d.stride + 1, (d.W + 2 * pad - d.ksize) // d.stride + 1

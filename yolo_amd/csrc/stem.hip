@@ -1,0 +1,142 @@
+// Stem: the network's first _conv2d (basic_yolo.py:20) -- Conv3x3 s1 p1 over the (N,3,H,W) float32
+// NCHW image + folded BN + LeakyReLU -> (N,H,W,Cout) bf16 NHWC -- as one HBM-bound kernel.
+//
+// Cin = 3 makes K = 27, too thin for the generic implicit GEMM (one 64-byte K-chunk would be 3/32
+// full).  Here the block stages a 6-row x 68-column halo tile of the image into LDS as NHWC4 bf16
+// (channel 3 = 0; NCHW reads are coalesced along W in each plane), and K is re-ordered (kh | kw, c4):
+// one MFMA k-step of 16 = one kernel row = [kw0 c0..3 | kw1 c0..3 || kw2 c0..3 | 0000], which for a
+// pixel is 16 + 8 contiguous LDS bytes -- no gather.  3 MFMA 32x32x16 per 32 pixels x 32 couts.
+// D rows = cout, so a lane ends with 4 consecutive channels of one pixel (8-byte NHWC stores).
+#include "common.h"
+
+constexpr int STEM_TW = 64;            // output pixels per tile row
+constexpr int STEM_RW = 4;             // output rows per wave
+constexpr int STEM_TH = 4 * STEM_RW;   // output rows per tile (4 waves)
+constexpr int STEM_PW = STEM_TW + 4;   // LDS row pitch in pixels (halo + over-read slack)
+
+template <int MI>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ bias, uint16_t* __restrict__ y,
+                                                        int N, int H, int W, int Cout, float slope, int tiles_x,
+                                                        int tiles_y) {
+    __shared__ __attribute__((aligned(16))) uint2 tile[(STEM_TH + 2) * STEM_PW];
+    __shared__ __attribute__((aligned(16))) uint2 obuf[4 * 64 * (MI * 32 * 2 + 8) / 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    const int x0 = tx * STEM_TW, y0 = ty * STEM_TH;
+    const long long HW = (long long)H * W;
+    const float* xn = x + (long long)n * 3 * HW;
+
+    // ---- stage the halo tile: NCHW f32 -> LDS NHWC4 bf16 ------------------------------------------
+    for (int s = tid; s < (STEM_TH + 2) * STEM_PW; s += 256) {
+        const int r = s / STEM_PW, c = s - r * STEM_PW;
+        const int iy = y0 + r - 1, ix = x0 + c - 1;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const long long o = (long long)min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1);
+        const float c0 = xn[o], c1 = xn[HW + o], c2 = xn[2 * HW + o];
+        tile[s] = ok ? make_uint2(pack_bf16x2(c0, c1), pack_bf16x2(c2, 0.f)) : make_uint2(0u, 0u);
+    }
+    // ---- weight fragments: lane (cout = mi*32 + l31, k-half h), one per kernel row -----------------
+    uint4 wf[3][MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int co = mi * 32 + l31;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            float v[2][3];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const int kw = 2 * h + q;          // h=0: kw 0,1 ; h=1: kw 2,(3 = padding)
+                    v[q][ci] = (co < Cout && kw < 3) ? w[((co * 3 + ci) * 3 + kh) * 3 + min(kw, 2)] : 0.f;
+                }
+            wf[kh][mi] = make_uint4(pack_bf16x2(v[0][0], v[0][1]), pack_bf16x2(v[0][2], 0.f),
+                                    pack_bf16x2(v[1][0], v[1][1]), pack_bf16x2(v[1][2], 0.f));
+        }
+    }
+    __syncthreads();
+
+    constexpr int OP = (MI * 32 * 2 + 8);              // LDS pitch per output pixel: bf16 couts + 8 B (conflict-free b64)
+    char* ot = (char*)obuf + wave * (64 * OP);
+    const int upp = Cout / 4;                          // 8-byte units per output pixel
+    const int npx = min(STEM_TW, W - x0);
+#pragma unroll 1
+    for (int rw = 0; rw < STEM_RW; ++rw) {
+        const int lr = wave * STEM_RW + rw;            // output row within the tile
+        const int oy = y0 + lr;
+        if (oy >= H) break;
+        f32x16 acc[MI][2];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int s = (lr + kh) * STEM_PW + ni * 32 + l31 + 2 * h;
+                const uint2 lo = tile[s], hi = tile[s + 1];
+                const uint4 bf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[kh][mi]),
+                                                                          __builtin_bit_cast(bf16x8, bf), acc[mi][ni],
+                                                                          0, 0, 0);
+            }
+        }
+        // BN + LeakyReLU, then transpose through this wave's LDS scratch so each lane stores 8 contiguous
+        // bytes of a contiguous NHWC run (a wave's 64 pixels x Cout channels are one run of the output row)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = mi * 32 + 8 * g + 4 * h;
+                f32x4 sc = {0.f, 0.f, 0.f, 0.f}, bi = {0.f, 0.f, 0.f, 0.f};
+                if (co < Cout) { sc = *(const f32x4*)(scale + co); bi = *(const f32x4*)(bias + co); }
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = acc[mi][ni][4 * g + e] * sc[e] + bi[e];
+                        v[e] = t > 0.f ? t : t * slope;
+                    }
+                    *(uint2*)(ot + (ni * 32 + l31) * OP + co * 2) =
+                        make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                }
+            }
+        }
+        uint16_t* yrow = y + (((long long)n * H + oy) * W + x0) * Cout;
+        for (int u = lane; u < npx * upp; u += 64) {   // same-wave LDS write -> read -> (next row's) write: in order
+            const int px = u / upp, q = u - px * upp;
+            *(uint2*)(yrow + (long long)px * Cout + q * 4) = *(const uint2*)(ot + px * OP + q * 8);
+        }
+    }
+}
+
+extern "C" int yolo_stem_conv_fwd(const float* x_nchw, const float* w_oihw, const float* scale, const float* bias,
+                                  void* y, int N, int H, int W, int Cin, int Cout, int dtype, float slope,
+                                  void* stream) {
+    if (!x_nchw || !w_oihw || !scale || !bias || !y || N <= 0 || H <= 0 || W <= 0) return YOLO_EINVAL;
+    if (Cin != 3 || Cout <= 0 || (Cout % 4) || Cout > 64) return YOLO_EUNSUPPORTED;
+    if (dtype != YOLO_BF16) return YOLO_EUNSUPPORTED;      // the fp32 path goes through the generic kernel
+    const int tiles_x = (W + STEM_TW - 1) / STEM_TW, tiles_y = (H + STEM_TH - 1) / STEM_TH;
+    const long long grid = (long long)N * tiles_x * tiles_y;
+    if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
+    if (Cout <= 32)
+        YOLO_LAUNCH(stem_mfma_kernel<1>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x_nchw, w_oihw, scale,
+                    bias, (uint16_t*)y, N, H, W, Cout, slope, tiles_x, tiles_y);
+    else
+        YOLO_LAUNCH(stem_mfma_kernel<2>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x_nchw, w_oihw, scale,
+                    bias, (uint16_t*)y, N, H, W, Cout, slope, tiles_x, tiles_y);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}

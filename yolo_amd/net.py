@@ -168,8 +168,18 @@ class CarNet(object):
         g = self.graph
         plan = _Plan()
         tdt = _TORCH_DT[self.dtype]
-        plan.x_nhwc = torch.empty((B, H, W, 8), dtype=tdt, device=self.device)
-        x, shp = self._conv_op(plan, g.stem, plan.x_nhwc, (B, H, W, 8), cin=8)
+        if g.stem.cin == 3 and g.stem.cout % 4 == 0 and g.stem.cout <= 64 and self.dtype == 'bf16':
+            # fused image-layout change + first conv (yolo_stem_conv_fwd): reads the NCHW image directly
+            _, sscale, sbias = self._prepared[g.stem.name]
+            x = torch.empty((B, H, W, g.stem.cout), dtype=tdt, device=self.device)
+            shp = (B, H, W, g.stem.cout)
+            plan.buffers.append(x)
+            plan.ops.append(('stem', (L.ptr(self.params[g.stem.name + '.weight']), L.ptr(sscale), L.ptr(sbias),
+                                      L.ptr(x), B, H, W, 3, g.stem.cout), g.stem.name))
+            plan.act[g.stem.name] = (x, shp)
+        else:
+            plan.x_nhwc = torch.empty((B, H, W, 8), dtype=tdt, device=self.device)
+            x, shp = self._conv_op(plan, g.stem, plan.x_nhwc, (B, H, W, 8), cin=8)
         routes = []
         nst = len(g.stages)
         for i, (down, res) in enumerate(g.stages):
@@ -223,12 +233,10 @@ class CarNet(object):
         if plan is None:
             plan = self._plans[key] = self._build_plan(B, H, W)
         lib, st, dt = self._lib, L.stream_ptr(), _LIB_DT[self.dtype]
-        L.check(lib.yolo_nchw_to_nhwc(x.data_ptr(), L.ptr(plan.x_nhwc), B, 3, H, W, 8, dt, st), 'nchw_to_nhwc')
+        if plan.x_nhwc is not None:
+            L.check(lib.yolo_nchw_to_nhwc(x.data_ptr(), L.ptr(plan.x_nhwc), B, 3, H, W, 8, dt, st), 'nchw_to_nhwc')
         for kind, payload, name in plan.ops:
-            if kind == 'conv':
-                rc = lib.yolo_conv_fwd(C.byref(payload), st)
-            else:
-                rc = lib.yolo_upsample2x_concat(*payload, dt, st)
+            rc = self._launch(kind, payload, x, st, dt)
             if rc:
                 raise L.YoloError('%s (%s) failed with status %d' % (kind, name, rc))
         self._last_plan = plan
@@ -236,6 +244,15 @@ class CarNet(object):
         return [plan.merged[:, o:o + n].view(B, n, A, self.graph.per_anchor) for o, n in plan.offsets]
 
     __call__ = forward
+
+    def _launch(self, kind, payload, x, st, dt):
+        lib = self._lib
+        if kind == 'conv':
+            return lib.yolo_conv_fwd(C.byref(payload), st)
+        if kind == 'stem':
+            w, sc, bi, y, B, H, W, cin, cout = payload
+            return lib.yolo_stem_conv_fwd(x.data_ptr(), w, sc, bi, y, B, H, W, cin, cout, dt, LEAKY_SLOPE, st)
+        return lib.yolo_upsample2x_concat(*payload, dt, st)
 
     def plan_kernels(self, B, H, W):
         """[(op name, kernel instantiation name, algorithmic FLOPs)] for the launch list of one input
@@ -249,6 +266,10 @@ class CarNet(object):
         out = []
         buf = C.create_string_buffer(256)
         for kind, payload, name in plan.ops:
+            if kind == 'stem':
+                c = by_name[name]
+                out.append((name, 'stem_conv_kernel', 2 * c.cin * 9 * c.cout * payload[4] * payload[5] * payload[6]))
+                continue
             if kind != 'conv':
                 out.append((name, kind, 0))
                 continue
@@ -264,14 +285,12 @@ class CarNet(object):
         B, _, H, W = x.shape
         plan = self._plans[(B, H, W)]
         lib, st, dt = self._lib, L.stream_ptr(), _LIB_DT[self.dtype]
-        L.check(lib.yolo_nchw_to_nhwc(x.data_ptr(), L.ptr(plan.x_nhwc), B, 3, H, W, 8, dt, st), 'nchw_to_nhwc')
+        if plan.x_nhwc is not None:
+            L.check(lib.yolo_nchw_to_nhwc(x.data_ptr(), L.ptr(plan.x_nhwc), B, 3, H, W, 8, dt, st), 'nchw_to_nhwc')
         for kind, payload, name in plan.ops:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            if kind == 'conv':
-                rc = lib.yolo_conv_fwd(C.byref(payload), st)
-            else:
-                rc = lib.yolo_upsample2x_concat(*payload, dt, st)
+            rc = self._launch(kind, payload, x, st, dt)
             e1.record()
             if rc:
                 raise L.YoloError('%s (%s) failed with status %d' % (kind, name, rc))
