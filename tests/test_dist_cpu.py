@@ -1,0 +1,56 @@
+"""N>1 path on CPU: world_size-2 gloo.  Inference shards the batch with no data-path collective
+(split_render_data, yolo_gluon.py:100-124); the only exchange bench.py makes is the MAX-reduce of the
+step time, plus (training, next) the SUM all-reduce of the flat gradient bucket."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from yolo_amd import parallel as P
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    batch = torch.arange(10 * 3, dtype=torch.float32).view(10, 3)
+    shard = P.shard_batch(batch, rank, world)
+    # every rank "processes" its shard (here: a row sum) and rank 0 gathers the per-image results
+    res = shard.sum(dim=1)
+    gathered = P.gather_rows(res, batch.shape[0], rank, world)
+    t = P.max_over_ranks(float(rank + 1))
+    # gradient bucket: SUM all-reduce then 1/global_batch rescale (trainer.step(batch_size), car/YOLO.py:396)
+    g = torch.full((7,), float(rank + 1))
+    P.allreduce_sum_(g)
+    q.put((rank, shard.shape[0], gathered.tolist() if rank == 0 else None, t, g.tolist()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_reductions():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(timeout=60) for p in ps]
+    assert [o[1] for o in out] == [5, 5]
+    expect = torch.arange(30, dtype=torch.float32).view(10, 3).sum(1).tolist()
+    assert out[0][2] == expect
+    assert out[0][3] == out[1][3] == 2.0
+    assert out[0][4] == out[1][4] == [3.0] * 7
+
+
+def test_shard_bounds_match_reference_formula():
+    # yolo_gluon.py:118-119: start=int(i*B/n), end=int((i+1)*B/n)
+    for B in (1, 7, 32, 33, 256):
+        for n in (1, 2, 3, 8):
+            got = [P.shard_bounds(B, i, n) for i in range(n)]
+            assert got == [(int(i * B / n), int((i + 1) * B / n)) for i in range(n)]
+            assert got[0][0] == 0 and got[-1][1] == B

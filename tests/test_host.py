@@ -1,0 +1,101 @@
+"""CPU tests of the host-side mirror (no GPU, no compute calls): spec graph, grid descriptors, the
+C-ABI library loads and exports every symbol include/yolo_amd.h declares, argument validation."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import graph as og, detect as od
+from yolo_amd import spec as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_graph_matches_oracle_graph():
+    for sp in (og.spec_d53(), og.spec_car_v1(), og.spec_test_yaml(), og.spec_micro()):
+        ng = S.NetGraph(sp)
+        ref = og.conv_list(og.build_graph(sp))
+        got = ng.convs()
+        assert [(c.name, c.cin, c.cout, c.k, c.stride, c.bn) for c in got] == \
+               [(c['name'], c['cin'], c['cout'], c['k'], c['stride'], c['bn']) for c in ref]
+    ng = S.NetGraph(og.spec_d53())
+    assert ng.flops(416, 416) == og.conv_flops(og.build_graph(og.spec_d53()), 416, 416)
+    assert ng.steps() == [8, 16, 32]
+    with pytest.raises(ValueError):
+        S.NetGraph(dict(layers=[1, 2], channels=[8, 16], all_anchors=og.CAR_ANCHORS, slice_point=[1, 3, 5, 6, 10]))
+
+
+def test_abi_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, 'include', 'yolo_amd.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(yolo_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 18
+    from yolo_amd import lib as L
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.yolo_version() >= 1
+
+
+def test_abi_host_only_queries(lib):
+    from yolo_amd import lib as L
+    assert lib.yolo_padded_channels(90) % 128 == 0 and lib.yolo_padded_channels(90) >= 90
+    # packed image: [chunk][tap][Cout_pad][64 B]
+    assert lib.yolo_packed_weight_bytes(64, 32, 3, L.BF16) == 1 * 9 * lib.yolo_padded_channels(64) * 64
+    assert lib.yolo_packed_weight_bytes(64, 32, 3, L.F32) == 2 * 9 * lib.yolo_padded_channels(64) * 64
+    assert lib.yolo_packed_weight_bytes(64, 32, 5, L.BF16) < 0
+    assert lib.yolo_nms_workspace_bytes(2, 10647, 24, 1, 400) == 2 * 10647 * 24 * 4
+    # argument validation happens before any launch: NULL pointers / bad shapes are rejected on CPU too
+    d = L.ConvDesc()
+    assert lib.yolo_conv_fwd(C.byref(d), None) == -1
+    assert lib.yolo_decode(None, None, 1, 30, None, None) == -1
+    assert lib.yolo_nms_from_scores(None, None, 1, 1, 30, 1, 0.01, 0.45, 400, 100, None, None, None, None) == -1
+    # kernel-name query is host-only
+    d.x = d.w_packed = d.scale = d.bias = d.y = 1
+    d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.dtype = 32, 13, 13, 1024, 2048, 3, 1, L.BF16
+    buf = C.create_string_buffer(256)
+    assert lib.yolo_conv_kernel_name(C.byref(d), buf, 256) == 0
+    assert b'conv_' in buf.value and b'__bf16' in buf.value
+    d.stride = 3
+    assert lib.yolo_conv_kernel_name(C.byref(d), buf, 256) == -2
+
+
+def test_grid_descriptor_matches_oracle():
+    from yolo_amd.detect import make_grid
+    sp = og.spec_d53()
+    for size in ((416, 416), (320, 512), (608, 608)):
+        steps = od.init_steps(sp['layers'], sp['all_anchors'])
+        g, nbox = make_grid(sp['all_anchors'], size, steps)
+        assert nbox == sum(od.init_area(size, steps)) * 3
+        s, y, x, h, w = od.init_syxhw(size, steps, sp['all_anchors'])
+        k = nbox // 2
+        cell, a = divmod(k, 3)
+        cum = 0
+        for i in range(3):
+            n = g.gh[i] * g.gw[i]
+            if cell < cum + n:
+                row, col = divmod(cell - cum, g.gw[i])
+                assert (g.step[i], row * g.step[i], col * g.step[i]) == (s[0, cell, a, 0], y[0, cell, a, 0], x[0, cell, a, 0])
+                assert abs(g.anchors_hw[(i * 3 + a) * 2] - h[0, cell, a, 0]) < 1e-7
+                break
+            cum += n
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under yolo_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'yolo_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+                assert 'oracle.' not in src and 'oracle/' not in src, f
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from yolo_amd import lib as L
+    monkeypatch.setattr(L, '_lib', None)
+    monkeypatch.setattr(L, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(L.YoloError):
+        L.load()
