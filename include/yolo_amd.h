@@ -144,6 +144,63 @@ int yolo_nms(const float* rows, int B, int nbox, int C, int mode, float valid_th
              float iou_thresh, int topk, int post_nms, int* kept, float* kept_scores,
              int* kept_count, void* workspace, void* stream);
 
+/* ---- training step (fp32 parity path) ------------------------------------------------------- */
+
+/* Packed weight image of the data-gradient convolution of a forward conv (Cout_f, Cin_f, k): dx =
+ * conv_stride1(dy [dilated 2x for stride 2], W'), W'[ci][co][a][b] = W[co][ci][k-1-a][k-1-b]; run it with
+ * yolo_conv_fwd (scale 1, bias 0, slope 1, residual = gradient to accumulate into).  Bytes:
+ * yolo_packed_weight_bytes(Cin_f, Cout_f, k, dtype).  Replaces the autograd backward of Convolution
+ * (sum(losses).backward(), car/YOLO.py:394). */
+int yolo_pack_conv_weights_dgrad(const float* w_oihw, void* packed, int Cout_f, int Cin_f, int ksize,
+                                 int dtype, void* stream);
+
+/* Gluon BatchNorm in training mode fused with LeakyReLU (+ residual add):
+ * batch mean / biased variance over (N,H,W) of the NHWC fp32 conv output y (npix x C),
+ * z = lrelu(gamma*(y-mean)*invstd + beta) [+ residual]; running stats r = momentum*r + (1-momentum)*batch
+ * (running_var takes the biased variance).  workspace: 2*C doubles. */
+int yolo_bn_train_fwd(const float* y, const float* gamma, const float* beta, const float* residual,
+                      float* z, float* mean, float* invstd, float* running_mean, float* running_var,
+                      double* workspace, long long npix, int C, float eps, float momentum, float slope,
+                      void* stream);
+/* Backward of the above w.r.t. y, gamma, beta given dz (the residual branch receives dz unchanged). */
+int yolo_bn_train_bwd(const float* dz, const float* y, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta,
+                      double* workspace, long long npix, int C, float slope, void* stream);
+
+/* Weight gradient of Conv(k, stride, pad k/2): dw (Cout,Cin,k,k) float32 += sum over pixels of
+ * dy (N,Ho,Wo,[dy_pixel_stride]) x (N,H,W,Cin), NHWC fp32.  The caller zero-fills dw. */
+int yolo_conv_wgrad_f32(const float* dy, const float* x, float* dw_oihw, int N, int H, int W, int Cin,
+                        int Cout, int ksize, int stride, long long dy_pixel_stride, void* stream);
+/* db[c] += sum over npix rows of dy (row stride pixel_stride, 0 = C): YOLOOutput's bias gradient. */
+int yolo_bias_grad(const float* dy, float* db, long long npix, int C, long long pixel_stride, void* stream);
+/* (B, rows, [src strides]) C floats per row -> dense (B*rows, Cpad), zero padded. */
+int yolo_gather_rows(const float* src, float* dst, int B, long long rows_per_batch, int C, int Cpad,
+                     long long src_batch_stride, long long src_row_stride, void* stream);
+/* D (N,H,W,C): D[n,2y,2x,:] = dy[n,y,x,:] (dy is (N,Ho,Wo,C)), zeros elsewhere: turns the stride-2 data
+ * gradient into a stride-1 convolution. */
+int yolo_dilate2x(const float* dy, float* d, int N, int H, int W, int Ho, int Wo, int C, void* stream);
+/* Backward of yolo_upsample2x_concat: dcat (N,H,W,C1+C2) -> dup (N,H/2,W/2,C1), droute (N,H,W,C2);
+ * accumulate_* != 0 adds into the destination. */
+int yolo_upsample2x_concat_bwd(const float* dcat, float* dup, float* droute, int N, int H, int W, int C1,
+                               int C2, int accumulate_up, int accumulate_route, void* stream);
+int yolo_add(const float* a, const float* b, float* y, long long n, void* stream);
+
+/* _find_best + the scatter of _loss_mask (car/YOLO.py:401-480): labels (B,nobj,6+ncls)
+ * [cls,y,x,h,w,rot,dist...] (cls < 0 = no object), anchors_ltrb (nbox,4) = _get_default_ltrb
+ * (car/YOLO.py:209-240) -> records (B,nobj,7+ncls) [valid, box index, ty,tx,th,tw, rot, cls...]. */
+int yolo_assign_targets(const float* labels, const float* anchors_ltrb, float* records, int B, int nobj,
+                        int ncls, const yolo_grid_desc* g, void* stream);
+/* _score_weight + _get_loss + the backward of sum(losses) (car/YOLO.py:482-498, :394): logits
+ * (B,nbox,C) -> dlogits (B,nbox,C), losses (5,B) [score, box_yx, box_hw, rotate, class].
+ * scales5_host: 5 floats on the HOST (spec `scale`; rotate is 0 unless car_rotate). */
+int yolo_loss_fwd_bwd(const float* logits, const float* records, float* dlogits, float* losses, int B,
+                      int nbox, int C, int nobj, const float* scales5_host, float pos_w, float neg_w,
+                      void* stream);
+/* mxnet Adam, t = 1-based update count, rescale = 1/global batch
+ * (trainer.step(batch_size), car/YOLO.py:396). */
+int yolo_adam_step(float* w, const float* grad, float* m, float* v, long long n, int t, float lr,
+                   float beta1, float beta2, float eps, float rescale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,3 +103,25 @@ def test_conv_pipe_rejects_ineligible(lib, cuda):
     case = (2, 16, 16, 24, 32, 3, 2, False)          # stride 2
     x, w, scale, bias, r = _mk(case, 5)
     run_conv(lib, cuda, x, w, scale, bias, 2, 0.1, 'bf16', algo=2, expect_rc=-2)
+
+
+S2_CASES = [
+    (2, 64, 26, 26, 128, 3, 2, False),      # -> 13x13
+    (4, 128, 52, 52, 256, 3, 2, False),     # -> 26x26, tiles crossing images
+    (3, 64, 38, 38, 96, 3, 2, False),       # 608 family -> 19x19, ragged Cout
+    (2, 128, 16, 40, 64, 3, 2, False),
+]
+
+
+@pytest.mark.parametrize('algo', [9, 10])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', S2_CASES)
+def test_conv_pipe_stride2(lib, cuda, case, dtype, algo):
+    x, w, scale, bias, r = _mk(case, 6)
+    y = run_conv(lib, cuda, x, w, scale, bias, 2, 0.1, dtype, algo=algo)
+    ref = ref_conv(x, w, scale, bias, 2, 0.1, bf16=(dtype == 'bf16'))
+    assert not np.isnan(y).any()
+    if dtype == 'f32':
+        np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-4)
+    else:
+        np.testing.assert_allclose(y, ref, rtol=1.6e-2, atol=2e-2)

@@ -1,0 +1,129 @@
+"""GPU parity of the training step (yolo_amd.train.Trainer, fp32 path) against the oracle's torch-autograd
+restatement of _train_batch (car/YOLO.py:350-399): train-mode BN forward, target assignment, the five
+losses, every parameter gradient, and the MXNet-formula Adam update."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import graph as og, train as ot, detect as od
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(cuda, B=2, seed_lab=1, render_rate=0.0):
+    from yolo_amd.net import CarNet
+    from yolo_amd.train import Trainer
+    spec, size = og.spec_micro(), (64, 96)
+    g = og.build_graph(spec)
+    P = og.init_params(g, seed=0, bn='random')
+    x = np.random.default_rng(2).random((B, 3) + size, dtype=np.float32)
+    lab = ot.synthetic_labels(B, seed=seed_lab, render_rate=render_rate, num_class=4)
+    net = CarNet(spec, dtype='f32', device=cuda).load_params(P)
+    tr = Trainer(net, size)
+    return spec, size, g, P, x, lab, net, tr
+
+
+def _close(a, b, rtol, name):
+    scale = np.abs(b).max() + 1e-12
+    err = np.abs(a - b).max() / scale
+    assert err < rtol, '%s: max err %.3g of scale %.3g' % (name, err * scale, scale)
+
+
+def test_assign_targets(cuda):
+    spec, size, g, P, x, lab, net, tr = _setup(cuda, B=6, seed_lab=5)
+    lab[3] = -1                                                   # an image without object
+    steps = od.init_steps(spec['layers'], spec['all_anchors'])
+    area = od.init_area(size, steps)
+    ltrb = od.get_default_ltrb(size, steps, spec['all_anchors'])
+    np.testing.assert_array_equal(tr.anchors_ltrb.cpu().numpy(), ltrb)      # bit-identical anchor boxes
+    tr.train_step(torch.from_numpy(x[:1].repeat(6, 0)).to(cuda), torch.from_numpy(lab).to(cuda), update=False)
+    rec = tr._last[1].cpu().numpy()
+    for b in range(6):
+        if lab[b, 0, 0] < 0:
+            assert rec[b, 0, 0] == 0
+            continue
+        px, anc, box = ot.find_best(lab[b, 0], ltrb, spec['all_anchors'], size, steps, area)
+        assert rec[b, 0, 0] == 1 and int(rec[b, 0, 1]) == px * 3 + anc       # bit-exact index
+        np.testing.assert_allclose(rec[b, 0, 2:6], box, rtol=1e-5, atol=1e-6)
+        np.testing.assert_array_equal(rec[b, 0, 6:], lab[b, 0, 5:])
+
+
+def test_train_step_losses_and_grads(cuda):
+    spec, size, g, P, x, lab, net, tr = _setup(cuda)
+    losses = tr.train_step(torch.from_numpy(x).to(cuda), torch.from_numpy(lab).to(cuda), update=False)
+    rl, rg, rmerged = ot.train_step_reference(g, P, x, lab, spec, size)
+    _close(tr.merged_logits().cpu().numpy(), rmerged, 1e-4, 'train-mode logits')
+    np.testing.assert_allclose(losses.cpu().numpy(), np.stack(rl), rtol=1e-3, atol=1e-7)
+    grads = tr.grads()
+    assert set(grads) == set(rg)
+    # LeakyReLU' is discontinuous: the two forwards differ by ~1e-5 relative (fp32 accumulation order), which
+    # flips the sign of a handful of near-zero pre-activations and moves individual gradient entries by
+    # percents (measured: feeding the oracle's own backward with the HIP forward's activations reproduces
+    # the HIP gradients to 1e-6).  So the whole-step bar is an L2 one; the strict element-wise parity of
+    # every backward building block is in tests/test_gpu_train_ops.py.
+    rel = {}
+    for name in sorted(rg):
+        a, b = grads[name].cpu().numpy().astype(np.float64), rg[name].astype(np.float64)
+        rel[name] = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
+    worst = max(rel, key=rel.get)
+    assert rel[worst] < 0.1, (worst, rel[worst])
+    assert np.median(list(rel.values())) < 2e-3, np.median(list(rel.values()))
+    assert np.mean([v < 1e-2 for v in rel.values()]) > 0.8
+
+
+def test_loss_grad_wrt_logits(cuda):
+    """d(sum of losses)/d(logits) alone, on random logits (isolates loss.hip from the network)."""
+    from yolo_amd import lib as L
+    import ctypes as C
+    spec, size, g, P, x, lab, net, tr = _setup(cuda, B=3, seed_lab=9)
+    merged = (1.5 * np.random.default_rng(3).standard_normal((3, tr.nbox // 3, 3, 10))).astype(np.float32)
+    rl, gout, _ = ot.loss_and_grad_wrt_output(merged, lab, spec, size)
+    lib = tr.lib
+    logits = torch.from_numpy(merged).to(cuda).contiguous()
+    labels = torch.from_numpy(lab).to(cuda)
+    rec = torch.empty((3, 1, 7 + 4), device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.yolo_assign_targets(labels.data_ptr(), tr.anchors_ltrb.data_ptr(), rec.data_ptr(), 3, 1, 4, C.byref(tr.grid), st) == 0
+    dl = torch.empty_like(logits); ls = torch.empty((5, 3), device=cuda)
+    s5 = (C.c_float * 5)(0.1, 0.01, 10.0, 0.0, 0.3)
+    assert lib.yolo_loss_fwd_bwd(logits.data_ptr(), rec.data_ptr(), dl.data_ptr(), ls.data_ptr(), 3, tr.nbox, 10, 1, s5, 1.0, 0.1, st) == 0
+    np.testing.assert_allclose(ls.cpu().numpy(), np.stack(rl), rtol=1e-4, atol=1e-8)
+    _close(dl.cpu().numpy().reshape(gout.shape), gout, 1e-4, 'dlogits')
+
+
+def test_adam_update_and_second_step(cuda):
+    spec, size, g, P, x, lab, net, tr = _setup(cuda)
+    xt, lt = torch.from_numpy(x).to(cuda), torch.from_numpy(lab).to(cuda)
+    tr.train_step(xt, lt)                                           # step 1 with the update (global batch 2)
+    _, rg, _ = ot.train_step_reference(g, P, x, lab, spec, size)
+    P2 = {k: v.copy() for k, v in P.items()}
+    for name, gr in rg.items():
+        w = P2[name]; m = np.zeros_like(w); v = np.zeros_like(w)
+        ot.adam_step(w, gr, m, v, 1, lr=1e-3, rescale=1.0 / 2)
+    for name in rg:
+        got = net.params[name].cpu().numpy()
+        # first Adam step moves every weight by ~lr*sign(g); compare the step, not the weight
+        step_ref, step_got = P2[name] - P[name], got - P[name]
+        bad = np.abs(step_got - step_ref) > 2e-4 * 1e-3 + 0.05 * np.abs(step_ref)
+        assert bad.sum() <= max(2, 0.03 * bad.size), name     # the first Adam step is ~lr*sign(g): it only
+        #                                                       differs where the gradient is ~0 (|g| ~ eps)
+    # running statistics: 0.9*r + 0.1*batch (biased variance)
+    st = {}
+    from oracle import forward as of
+    of.forward_torch(g, P, x, training=True, bn_stats=st)
+    for cname, (mean, var) in list(st.items())[:6]:
+        np.testing.assert_allclose(net.params[cname + '.running_mean'].cpu().numpy(),
+                                   0.9 * P[cname + '.running_mean'] + 0.1 * mean.numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(net.params[cname + '.running_var'].cpu().numpy(),
+                                   0.9 * P[cname + '.running_var'] + 0.1 * var.numpy(), rtol=1e-4, atol=1e-6)
+    l2 = tr.train_step(xt, lt)                                      # the re-packed weights are in use
+    assert torch.isfinite(l2).all() and tr.t == 2
+
+
+def test_training_reduces_loss(cuda):
+    spec, size, g, P, x, lab, net, tr = _setup(cuda, B=4, seed_lab=3)
+    xt, lt = torch.from_numpy(x).to(cuda), torch.from_numpy(lab).to(cuda)
+    first = float(tr.train_step(xt, lt).sum())
+    for _ in range(30):
+        last = float(tr.train_step(xt, lt).sum())
+    assert last < 0.7 * first, (first, last)

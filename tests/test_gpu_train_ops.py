@@ -1,0 +1,121 @@
+"""Unit parity of the backward building blocks against torch-CPU autograd: weight gradient (MFMA f32),
+data gradient (forward kernel on the flipped weight image, dilation for stride 2), train-mode BatchNorm
+forward/backward, up-sample/concat backward."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from yolo_amd import lib as L
+from util import to_nhwc, from_nhwc
+
+pytestmark = pytest.mark.gpu
+
+# (N, Cin, H, W, Cout, k, stride)
+SHAPES = [(2, 64, 8, 12, 128, 3, 1), (2, 128, 8, 12, 64, 1, 1), (3, 32, 13, 13, 64, 3, 1), (2, 16, 16, 24, 32, 3, 2),
+          (2, 64, 4, 6, 30, 1, 1), (1, 8, 20, 20, 16, 3, 1), (2, 96, 2, 3, 128, 3, 1), (2, 32, 26, 26, 64, 3, 2)]
+
+
+def _ref(case, seed):
+    N, Cin, H, W, Cout, k, s = case
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(rng.standard_normal((N, Cin, H, W)).astype(np.float32)).requires_grad_(True)
+    w = torch.from_numpy((rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=s, padding=k // 2)
+    dy = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+    y.backward(dy)
+    return x.detach().numpy(), w.detach().numpy(), dy.numpy(), x.grad.numpy(), w.grad.numpy()
+
+
+@pytest.mark.parametrize('case', SHAPES)
+def test_wgrad(lib, cuda, case):
+    N, Cin, H, W, Cout, k, s = case
+    x, w, dy, dx_ref, dw_ref = _ref(case, 1)
+    xd, dyd = to_nhwc(x, 'f32', cuda), to_nhwc(dy, 'f32', cuda)
+    dw = torch.zeros((Cout, Cin, k, k), device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.yolo_conv_wgrad_f32(dyd.data_ptr(), xd.data_ptr(), dw.data_ptr(), N, H, W, Cin, Cout, k, s, 0, st) == 0
+    np.testing.assert_allclose(dw.cpu().numpy(), dw_ref, rtol=1e-3, atol=1e-3 * np.abs(dw_ref).max())
+
+
+@pytest.mark.parametrize('case', SHAPES)
+def test_dgrad(lib, cuda, case):
+    N, Cin, H, W, Cout, k, s = case
+    if Cout % 4:
+        pytest.skip('dy channel count must be a multiple of 4 (the trainer pads the head logits)')
+    x, w, dy, dx_ref, dw_ref = _ref(case, 2)
+    st = torch.cuda.current_stream().cuda_stream
+    wd = torch.empty(lib.yolo_packed_weight_bytes(Cin, Cout, k, L.F32), dtype=torch.uint8, device=cuda)
+    assert lib.yolo_pack_conv_weights_dgrad(torch.from_numpy(w).to(cuda).data_ptr(), wd.data_ptr(), Cout, Cin, k, L.F32, st) == 0
+    dyd = to_nhwc(dy, 'f32', cuda)
+    if s == 2:
+        dil = torch.empty((N, H, W, Cout), device=cuda)
+        assert lib.yolo_dilate2x(dyd.data_ptr(), dil.data_ptr(), N, H, W, dy.shape[2], dy.shape[3], Cout, st) == 0
+        dyd = dil
+    cp = lib.yolo_padded_channels(Cin)
+    ones = torch.ones(cp, device=cuda); zeros = torch.zeros(cp, device=cuda)
+    out = torch.full((N, H, W, Cin), float('nan'), device=cuda)
+    d = L.ConvDesc()
+    d.x, d.w_packed, d.scale, d.bias, d.y = dyd.data_ptr(), wd.data_ptr(), ones.data_ptr(), zeros.data_ptr(), out.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.dtype, d.slope = N, H, W, Cout, Cin, k, 1, L.F32, 1.0
+    assert lib.yolo_conv_fwd(C.byref(d), st) == 0
+    np.testing.assert_allclose(from_nhwc(out), dx_ref, rtol=1e-3, atol=1e-3 * np.abs(dx_ref).max())
+    # accumulate into an existing gradient (residual = y, in place)
+    d.residual = out.data_ptr()
+    assert lib.yolo_conv_fwd(C.byref(d), st) == 0
+    np.testing.assert_allclose(from_nhwc(out), 2 * dx_ref, rtol=1e-3, atol=2e-3 * np.abs(dx_ref).max())
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 12, 128), (3, 13, 13, 64), (1, 4, 6, 30), (4, 32, 48, 16)])
+@pytest.mark.parametrize('with_res', [False, True])
+def test_bn_train_fwd_bwd(lib, cuda, shape, with_res):
+    N, H, W, Cc = shape
+    rng = np.random.default_rng(3)
+    y = torch.from_numpy((2 * rng.standard_normal((N, Cc, H, W)) + 0.5).astype(np.float32)).requires_grad_(True)
+    gamma = torch.from_numpy(rng.uniform(.5, 1.5, Cc).astype(np.float32)).requires_grad_(True)
+    beta = torch.from_numpy((.1 * rng.standard_normal(Cc)).astype(np.float32)).requires_grad_(True)
+    res = torch.from_numpy(rng.standard_normal((N, Cc, H, W)).astype(np.float32)) if with_res else None
+    mean = y.mean(dim=(0, 2, 3)); var = y.var(dim=(0, 2, 3), unbiased=False)
+    a = (y - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-5) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+    z = F.leaky_relu(a, 0.1)
+    if with_res:
+        z = z + res
+    dz = torch.from_numpy(rng.standard_normal((N, Cc, H, W)).astype(np.float32))
+    z.backward(dz)
+    st = torch.cuda.current_stream().cuda_stream
+    dev = lambda t: t.detach().to(cuda).contiguous()
+    yd, resd, dzd = to_nhwc(y.detach().numpy(), 'f32', cuda), (to_nhwc(res.numpy(), 'f32', cuda) if with_res else None), to_nhwc(dz.numpy(), 'f32', cuda)
+    g_, b_ = dev(gamma), dev(beta)
+    zd = torch.empty_like(yd); m_ = torch.empty(Cc, device=cuda); is_ = torch.empty(Cc, device=cuda)
+    rm = torch.zeros(Cc, device=cuda); rv = torch.ones(Cc, device=cuda)
+    ws = torch.zeros(2 * Cc, dtype=torch.float64, device=cuda)
+    npix = N * H * W
+    assert lib.yolo_bn_train_fwd(yd.data_ptr(), g_.data_ptr(), b_.data_ptr(), resd.data_ptr() if with_res else None,
+                                 zd.data_ptr(), m_.data_ptr(), is_.data_ptr(), rm.data_ptr(), rv.data_ptr(), ws.data_ptr(),
+                                 npix, Cc, 1e-5, 0.9, 0.1, st) == 0
+    np.testing.assert_allclose(from_nhwc(zd), z.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(m_.cpu().numpy(), mean.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), 0.9 + 0.1 * var.detach().numpy(), rtol=1e-5)
+    dyd = torch.empty_like(yd); dg = torch.empty(Cc, device=cuda); db = torch.empty(Cc, device=cuda)
+    assert lib.yolo_bn_train_bwd(dzd.data_ptr(), yd.data_ptr(), m_.data_ptr(), is_.data_ptr(), g_.data_ptr(), b_.data_ptr(),
+                                 dyd.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), npix, Cc, 0.1, st) == 0
+    np.testing.assert_allclose(from_nhwc(dyd), y.grad.numpy(), rtol=1e-3, atol=1e-4 * np.abs(y.grad.numpy()).max())
+    np.testing.assert_allclose(dg.cpu().numpy(), gamma.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), beta.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_upcat_bwd(lib, cuda):
+    rng = np.random.default_rng(4)
+    up = torch.from_numpy(rng.standard_normal((2, 8, 4, 6)).astype(np.float32)).requires_grad_(True)
+    route = torch.from_numpy(rng.standard_normal((2, 12, 8, 12)).astype(np.float32)).requires_grad_(True)
+    cat = torch.cat([up.repeat_interleave(2, -1).repeat_interleave(2, -2), route], dim=1)
+    dcat = torch.from_numpy(rng.standard_normal(tuple(cat.shape)).astype(np.float32))
+    cat.backward(dcat)
+    st = torch.cuda.current_stream().cuda_stream
+    dc = to_nhwc(dcat.numpy(), 'f32', cuda)
+    dup = torch.empty((2, 4, 6, 8), device=cuda); dr = torch.ones((2, 8, 12, 12), device=cuda)
+    assert lib.yolo_upsample2x_concat_bwd(dc.data_ptr(), dup.data_ptr(), dr.data_ptr(), 2, 8, 12, 8, 12, 0, 1, st) == 0
+    np.testing.assert_allclose(from_nhwc(dup), up.grad.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(from_nhwc(dr), route.grad.numpy() + 1.0, rtol=1e-5, atol=1e-6)

@@ -302,7 +302,8 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
 // reference's batch sizes tile quantisation on the 13x13 / 26x26 maps costs more than any difference
 // between the variants' inner loops.  The per-variant factors are measured (tools/conv_bench.py).
 static int conv_auto_algo(const ConvArgs& a, int ks, int stride, int dtype) {
-    if (stride != 1 || (a.Cin * elem_size(dtype)) % 64 || a.nchunks < 2) return 1;
+    if ((a.Cin * elem_size(dtype)) % 64 || a.nchunks < 2) return 1;
+    if (stride == 2) return ks == 3 ? (a.Cout > 128 ? 10 : 9) : 1;
     struct V { int algo, bp, bc, bpc; float f; bool k1; };
     static const V vs[] = {{2, 256, 256, 1, 1.00f, true}, {3, 256, 128, 1, 1.10f, true}, {4, 128, 128, 2, 1.05f, true},
                            {6, 192, 256, 1, 1.00f, false}, {8, 192, 128, 2, 1.05f, true}};
@@ -379,7 +380,7 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin,
-                                    int ks, int Cout_pad, int nchunks) {
+                                    int ks, int Cout_pad, int nchunks, int dgrad) {
     constexpr int CH = 64 / sizeof(T);       // channels per chunk
     constexpr int UE = 16 / sizeof(T);       // elements per 16-byte unit
     const long long total = (long long)nchunks * ks * ks * Cout_pad * CH;
@@ -395,7 +396,15 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
         const int lunit = punit ^ ((co >> 2) & 3);            // physical unit holds this logical unit
         const int ci = chunk * CH + lunit * UE + within;
         float v = 0.f;
-        if (co < Cout && ci < Cin) v = w[((long long)(co * Cin + ci) * ks + tap / ks) * ks + tap % ks];
+        if (co < Cout && ci < Cin) {
+            if (!dgrad) {
+                v = w[((long long)(co * Cin + ci) * ks + tap / ks) * ks + tap % ks];
+            } else {
+                // data-gradient image: rows = forward INPUT channels, K = forward OUTPUT channels, taps flipped
+                // (w is the forward OIHW tensor with O = Cin here, I = Cout here)
+                v = w[((long long)(ci * Cout + co) * ks + (ks - 1 - tap / ks)) * ks + (ks - 1 - tap % ks)];
+            }
+        }
         if constexpr (sizeof(T) == 2)
             ((uint16_t*)out)[idx] = (uint16_t)f32_to_bf16_bits(v);
         else
@@ -409,8 +418,24 @@ extern "C" long long yolo_packed_weight_bytes(int Cout, int Cin, int ksize, int 
     return (long long)nchunks * ksize * ksize * round_up(Cout, YOLO_COUT_PAD) * 64;
 }
 
+static int pack_impl(const float* w_oihw, void* packed, int Cout, int Cin, int ksize, int dtype, int dgrad,
+                     void* stream);
+
 extern "C" int yolo_pack_conv_weights(const float* w_oihw, void* packed, int Cout, int Cin, int ksize,
                                       int dtype, void* stream) {
+    return pack_impl(w_oihw, packed, Cout, Cin, ksize, dtype, 0, stream);
+}
+
+// Weight image of the DATA-GRADIENT convolution of a forward conv (Cout_f, Cin_f, k): a stride-1 conv with
+// Cin_f output channels over Cout_f input channels, W'[ci][co][a][b] = W[co][ci][k-1-a][k-1-b].
+// Size = yolo_packed_weight_bytes(Cin_f, Cout_f, k, dtype).
+extern "C" int yolo_pack_conv_weights_dgrad(const float* w_oihw, void* packed, int Cout_f, int Cin_f, int ksize,
+                                            int dtype, void* stream) {
+    return pack_impl(w_oihw, packed, Cin_f, Cout_f, ksize, dtype, 1, stream);
+}
+
+static int pack_impl(const float* w_oihw, void* packed, int Cout, int Cin, int ksize, int dtype, int dgrad,
+                     void* stream) {
     if (!w_oihw || !packed) return YOLO_EINVAL;
     const long long bytes = yolo_packed_weight_bytes(Cout, Cin, ksize, dtype);
     if (bytes < 0) return (int)bytes;
@@ -420,10 +445,10 @@ extern "C" int yolo_pack_conv_weights(const float* w_oihw, void* packed, int Cou
     const int grid = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
     if (dtype == YOLO_BF16)
         YOLO_LAUNCH(pack_weights_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
-                           (__bf16*)packed, Cout, Cin, ksize, Cout_pad, nchunks);
+                           (__bf16*)packed, Cout, Cin, ksize, Cout_pad, nchunks, dgrad);
     else
         YOLO_LAUNCH(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
-                           (float*)packed, Cout, Cin, ksize, Cout_pad, nchunks);
+                           (float*)packed, Cout, Cin, ksize, Cout_pad, nchunks, dgrad);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }

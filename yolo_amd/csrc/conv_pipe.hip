@@ -66,7 +66,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // they are interleaved between the MFMAs, and the second half of the waves (which shares SIMDs with
 // the first half) issues them at shifted positions, so a wave stuck in a DMA issue is covered by its
 // SIMD partner's MFMAs.
-template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS>
+template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1>
 __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvArgs a) {
     constexpr int PT = 1;
     constexpr int NW = WAVES_P * WAVES_C;
@@ -113,10 +113,10 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         const int i_last = min(i0 + BP, a.total_i) - 1;
         const int r_first = i0 / TWt, r_last = i_last / TWt;
         const int n_f = r_first / Ho, n_l = r_last / Ho;
-        Rin_lo = n_f * (H + 1) + (r_first - n_f * Ho);
-        const int Rin_hi = n_l * (H + 1) + (r_last - n_l * Ho) + 2;
+        Rin_lo = n_f * (H + 1) + (r_first - n_f * Ho) * S;
+        const int Rin_hi = n_l * (H + 1) + (r_last - n_l * Ho) * S + 2;
         HS = (Rin_hi - Rin_lo + 1) * PW;
-        x0 = strip * TWt - 1;
+        x0 = strip * TWt * S - 1;
     }
 
     // ---- per-thread DMA sources: byte offset of the slot's 16-byte unit for chunk 0 (32-bit: the host
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
             const int r = ii / TWt;
             const int tx = ii - r * TWt;
             const int n = r / Ho;
-            slot00[ni] = (n * (H + 1) + (r - n * Ho) - Rin_lo) * PW + tx;
+            slot00[ni] = (n * (H + 1) + (r - n * Ho) * S - Rin_lo) * PW + tx * S;
         } else {
             slot00[ni] = ii - i0;
         }
@@ -300,23 +300,23 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS>
+template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1>
 static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     constexpr int BP = WAVES_P * NI * 32, BC = WAVES_C * MI * 32;
     if (KS == 3) {
         int best = -1, best_hs = 1 << 30;
         for (int d = 1; d <= a.Wo; ++d) {
             if (a.Wo % d) continue;
-            const int hs = conv_halo_slots(BP, d, a.Ho, a.H, 1, (long long)a.N * a.Ho);
+            const int hs = conv_halo_slots(BP, d, a.Ho, a.H, S, (long long)a.N * a.Ho);
             if (hs <= XSLOTS && hs <= best_hs) { best = d; best_hs = hs; }
         }
         if (const char* e = getenv("YOLO_FORCE_TWT")) {     // experiment knob: force the strip width
             const int d = atoi(e);
-            if (d > 0 && a.Wo % d == 0 && conv_halo_slots(BP, d, a.Ho, a.H, 1, (long long)a.N * a.Ho) <= XSLOTS) best = d;
+            if (d > 0 && a.Wo % d == 0 && conv_halo_slots(BP, d, a.Ho, a.H, S, (long long)a.N * a.Ho) <= XSLOTS) best = d;
         }
         if (best < 0) return YOLO_EUNSUPPORTED;
         a.TWt = best;
-        a.PW = best + 2;
+        a.PW = (best - 1) * S + 3;
     } else {
         a.TWt = a.Wo;
         a.PW = a.Wo;
@@ -330,11 +330,11 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     const long long grid = (long long)a.nstrips * a.tiles_per_strip * a.tiles_c;
     if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
     if (name) {
-        snprintf(name->buf, name->len, "void conv_pipe_kernel<%s, %d, %d, %d, %d, %d, %d>(ConvArgs)",
-                 sizeof(T) == 2 ? "__bf16" : "float", KS, WAVES_P, WAVES_C, MI, NI, XSLOTS);
+        snprintf(name->buf, name->len, "void conv_pipe_kernel<%s, %d, %d, %d, %d, %d, %d, %d>(ConvArgs)",
+                 sizeof(T) == 2 ? "__bf16" : "float", KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S);
         return YOLO_OK;
     }
-    YOLO_LAUNCH((conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS>), dim3((unsigned)grid),
+    YOLO_LAUNCH((conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S>), dim3((unsigned)grid),
                 dim3(WAVES_P * WAVES_C * 64), 0, st, a);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
@@ -345,8 +345,17 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
 //   4: 4 waves, 128 px x 128 cout (wave tile 64x64)    5: 8 waves, 128 px x 256 cout (wave tile 128x32)
 //   6: 8 waves, 192 px x 256 cout (wave tile 96x64)    7: 8 waves, 192 px x 128 cout (wave tile 96x32)
 //   8: 4 waves, 192 px x 128 cout (wave tile 96x64)    -- 192-pixel tiles exist to cut tile quantisation
+//   9 / 10: 3x3 stride 2, 8 waves, 128 px x 128 / 256 cout
 template <typename T>
-static int pipe_dispatch_t(ConvArgs& a, int ks, int algo, hipStream_t st, const NameOut* nm) {
+static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_t st, const NameOut* nm) {
+    if (ks == 3 && stride == 2) {
+        // stride 2: the input footprint is ~4x the output tile, so tiles are 128 output pixels
+        switch (algo) {
+            case 9: return launch_pipe<T, 3, 2, 4, 1, 2, 896, 2>(a, st, nm);     // 8 waves, 128 px x 128 cout
+            case 10: return launch_pipe<T, 3, 2, 4, 2, 2, 896, 2>(a, st, nm);    // 8 waves, 128 px x 256 cout
+        }
+        return YOLO_EUNSUPPORTED;
+    }
     if (ks == 3) {
         switch (algo) {
             case 2: return launch_pipe<T, 3, 2, 4, 2, 4, 512>(a, st, nm);
@@ -370,10 +379,10 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int algo, hipStream_t st, const 
 }
 
 int conv_pipe_dispatch(ConvArgs& a, int ks, int stride, int dtype, int algo, hipStream_t st, const NameOut* nm) {
-    if (stride != 1 || (ks != 1 && ks != 3)) return YOLO_EUNSUPPORTED;
+    if ((ks != 1 && ks != 3) || (stride != 1 && !(ks == 3 && stride == 2))) return YOLO_EUNSUPPORTED;
     if ((a.Cin * elem_size(dtype)) % 64) return YOLO_EUNSUPPORTED;
     if (a.nchunks < 2) return YOLO_EUNSUPPORTED;
     if ((long long)a.N * a.H * a.W * a.Cin * elem_size(dtype) >= 0xffffff00LL) return YOLO_EUNSUPPORTED;
-    if (dtype == YOLO_BF16) return pipe_dispatch_t<__bf16>(a, ks, algo, st, nm);
-    return pipe_dispatch_t<float>(a, ks, algo, st, nm);
+    if (dtype == YOLO_BF16) return pipe_dispatch_t<__bf16>(a, ks, stride, algo, st, nm);
+    return pipe_dispatch_t<float>(a, ks, stride, algo, st, nm);
 }

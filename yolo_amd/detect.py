@@ -128,3 +128,28 @@ def cv_img_2_ndarray(image, device='cuda:0'):
     out = torch.empty((1, Cc, H, W), dtype=torch.float32, device=img.device)
     L.check(L.load().yolo_image_u8_to_nchw(L.ptr(img), L.ptr(out), 1, H, W, Cc, L.stream_ptr()), 'image_u8_to_nchw')
     return out
+
+
+def default_ltrb(all_anchors, size, steps):
+    """_get_default_ltrb (car/YOLO.py:209-240): anchor boxes centred on the cell centres, normalised
+    [l,t,r,b], shape (sum(area), A, 4) float32, scales fine->coarse.  Host-side constant (the reference
+    builds it once in _init_train); fp32 op order: centre = index*pitch + pitch/2, edge = centre -+ 0.5*size."""
+    f32 = np.float32
+    out = []
+    for i, anchors in enumerate(all_anchors):
+        an = np.asarray(anchors, f32)
+        n = len(an)
+        step = float(steps[i])
+        yn, xn = int(size[0] / step), int(size[1] / step)
+        a = yn * xn
+        yc = np.arange(yn, dtype=f32) * f32(step / size[0]) + f32(step / size[0] / 2.)
+        xc = np.arange(xn, dtype=f32) * f32(step / size[1]) + f32(step / size[1] / 2.)
+        y = np.repeat(yc, n * xn)
+        h = np.tile(an[:, 0], a)
+        x = np.repeat(xc, n)
+        w = np.tile(an[:, 1], xn)
+        top, bot = (y - f32(0.5) * h).reshape(a, n, 1), (y + f32(0.5) * h).reshape(a, n, 1)
+        left = np.tile(x - f32(0.5) * w, yn).reshape(a, n, 1)
+        right = np.tile(x + f32(0.5) * w, yn).reshape(a, n, 1)
+        out.append(np.concatenate([left, top, right, bot], axis=-1))
+    return np.concatenate(out, axis=0).astype(f32)

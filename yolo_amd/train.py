@@ -1,0 +1,308 @@
+"""Training step: host-side mirror of YOLO._train_batch (car/YOLO.py:350-399) -- forward with train-mode
+BatchNorm, target assignment (_find_best/_loss_mask), the five losses (_get_loss), backward of
+sum(losses), gradient all-reduce over ranks and the MXNet Adam update of trainer.step(batch_size).
+
+fp32 parity path: every op is a HIP kernel from libyolo_amd.so (train.hip, loss.hip and the forward conv
+kernels re-used for the data gradient on flipped weights); torch owns memory, the stream and the
+process group only.  One process per GPU; BN statistics stay local to the GPU (no SyncBN,
+car/YOLO.py:94-96).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import parallel
+from .detect import make_grid, default_ltrb
+from .spec import BN_EPS, BN_MOMENTUM, LEAKY_SLOPE
+
+DEFAULT_SCALE = {'score': 0.1, 'box_yx': 0.01, 'box_hw': 10.0, 'rotate': 0.0, 'class': 0.3}   # car/v1/spec.yaml:31-35
+
+
+class _T(object):
+    """An activation of the training graph: forward value + (lazily) its gradient."""
+    __slots__ = ('val', 'shape', 'grad', 'ready')
+
+    def __init__(self, val, shape):
+        self.val, self.shape, self.grad, self.ready = val, shape, None, False
+
+
+class Trainer(object):
+    def __init__(self, net, size, scale=None, learning_rate=1e-3, positive_weight=1.0, negative_weight=0.1,
+                 car_rotate=False, beta1=0.9, beta2=0.999, eps=1e-8):
+        if net.dtype != 'f32':
+            raise ValueError('the training path is fp32 (CarNet(dtype="f32"))')
+        self.net, self.size = net, (int(size[0]), int(size[1]))
+        self.lib, self.dev = net._lib, net.device
+        self.scale = dict(DEFAULT_SCALE if scale is None else scale)
+        self.lr, self.b1, self.b2, self.eps = learning_rate, beta1, beta2, eps
+        self.pos_w, self.neg_w, self.car_rotate = positive_weight, negative_weight, car_rotate
+        self.t = 0
+        g = net.graph
+        self.grid, self.nbox = make_grid(g.anchors, self.size, g.steps())
+        self.anchors_ltrb = torch.from_numpy(default_ltrb(g.anchors, self.size, g.steps())).to(self.dev).contiguous()
+        # ---- flat parameter / gradient / Adam-state buffers; net.params become views of wflat ------------
+        names = []
+        for c in g.convs():
+            names += [c.name + '.weight'] + ([c.name + '.gamma', c.name + '.beta'] if c.bn else [c.name + '.bias'])
+        self.names = names
+        sizes = [net.params[n].numel() for n in names]
+        # 16-byte aligned views
+        offs, o = [], 0
+        for s in sizes:
+            offs.append(o)
+            o += (s + 3) // 4 * 4
+        self.wflat = torch.zeros(o, dtype=torch.float32, device=self.dev)
+        self.gflat = torch.zeros_like(self.wflat)
+        self.mflat = torch.zeros_like(self.wflat)
+        self.vflat = torch.zeros_like(self.wflat)
+        self.pview, self.gview = {}, {}
+        for n, s, of in zip(names, sizes, offs):
+            shp = net.params[n].shape
+            self.wflat[of:of + s].copy_(net.params[n].reshape(-1))
+            net.params[n] = self.wflat[of:of + s].view(shp)
+            self.pview[n] = net.params[n]
+            self.gview[n] = self.gflat[of:of + s].view(shp)
+        net._prepared = {}
+        self._prep = {}
+        self._plans = {}
+        cmax = max(c.cout for c in g.convs())
+        self.ws = torch.zeros(2 * cmax, dtype=torch.float64, device=self.dev)
+        self._repack()
+
+    # ---- weight images for the forward and data-gradient convolutions (re-packed after every update) ----
+    def _repack(self):
+        lib, st = self.lib, L.stream_ptr()
+        for c in self.net.graph.convs():
+            w = self.pview[c.name + '.weight']
+            ent = self._prep.get(c.name)
+            if ent is None:
+                wp = torch.empty(lib.yolo_packed_weight_bytes(c.cout, c.cin, c.k, L.F32), dtype=torch.uint8, device=self.dev)
+                wd = torch.empty(lib.yolo_packed_weight_bytes(c.cin, c.cout, c.k, L.F32), dtype=torch.uint8, device=self.dev)
+                cp = lib.yolo_padded_channels(max(c.cout, c.cin))
+                ones = torch.zeros(cp, dtype=torch.float32, device=self.dev); ones[:max(c.cout, c.cin)] = 1.0
+                bias = torch.zeros(cp, dtype=torch.float32, device=self.dev)
+                ent = self._prep[c.name] = (wp, wd, ones, bias, torch.zeros(cp, dtype=torch.float32, device=self.dev))
+            wp, wd, ones, bias, zeros = ent
+            L.check(lib.yolo_pack_conv_weights(L.ptr(w), L.ptr(wp), c.cout, c.cin, c.k, L.F32, st), 'pack')
+            L.check(lib.yolo_pack_conv_weights_dgrad(L.ptr(w), L.ptr(wd), c.cout, c.cin, c.k, L.F32, st), 'pack dgrad')
+            if not c.bn:
+                bias[:c.cout].copy_(self.pview[c.name + '.bias'])
+
+    # ---- plan ---------------------------------------------------------------------------------------------
+    def _new(self, shape):
+        return _T(torch.empty(shape, dtype=torch.float32, device=self.dev), tuple(shape))
+
+    def _conv_desc(self, x, xshape, wp, scale, bias, y, cin, cout, k, stride, residual=None, out_f32=0, y_bs=0, y_ps=0):
+        d = L.ConvDesc()
+        d.x, d.w_packed, d.scale, d.bias = L.ptr(x), L.ptr(wp), L.ptr(scale), L.ptr(bias)
+        d.residual = L.ptr(residual) if residual is not None else None
+        d.y = y if isinstance(y, int) else L.ptr(y)
+        d.N, d.H, d.W, d.Cin, d.Cout = xshape[0], xshape[1], xshape[2], cin, cout
+        d.ksize, d.stride, d.dtype, d.out_f32, d.slope = k, stride, L.F32, out_f32, 1.0
+        d.y_batch_stride, d.y_pixel_stride, d.algo = y_bs, y_ps, 0
+        return d
+
+    def _build(self, B, H, W):
+        g = self.net.graph
+        P = type('Plan', (), {})()
+        P.fwd, P.tensors = [], []
+        P.x8 = self._new((B, H, W, 8))
+
+        def conv_bn(c, xin, residual=None):
+            N, Hh, Ww, Cc = xin.shape
+            ho, wo = c.out_hw(Hh, Ww)
+            yraw, z = self._new((N, ho, wo, c.cout)), self._new((N, ho, wo, c.cout))
+            mean = torch.empty(c.cout, dtype=torch.float32, device=self.dev)
+            invstd = torch.empty_like(mean)
+            wp, wd, ones, bias, zeros = self._prep[c.name]
+            d = self._conv_desc(xin.val, xin.shape, wp, ones, zeros, yraw.val, Cc, c.cout, c.k, c.stride)
+            P.fwd.append(dict(kind='conv_bn', c=c, x=xin, yraw=yraw, z=z, mean=mean, invstd=invstd, res=residual, desc=d))
+            return z
+
+        x = conv_bn(g.stem, P.x8)
+        routes = []
+        nst = len(g.stages)
+        for i, (down, res) in enumerate(g.stages):
+            x = conv_bn(down, x)
+            for c1, c2 in res:
+                x = conv_bn(c2, conv_bn(c1, x), residual=x)
+            if i >= nst - g.num_pyramid:
+                routes.append(x)
+        hw = [r.shape[1] * r.shape[2] for r in routes]
+        A = g.heads[0][3]
+        AC = A * g.per_anchor
+        tot = sum(hw)
+        offs = [sum(hw[:k]) for k in range(len(hw))]
+        P.merged = torch.empty((B, tot, AC), dtype=torch.float32, device=self.dev)
+        P.dmerged = torch.empty_like(P.merged)
+        P.tot, P.AC, P.A = tot, AC, A
+        for i, (body, tip, outc, nA) in enumerate(g.heads):
+            for c in body:
+                x = conv_bn(c, x)
+            route = x
+            t = conv_bn(tip, route)
+            k = len(g.heads) - 1 - i
+            wp, wd, ones, bias, zeros = self._prep[outc.name]
+            yptr = P.merged.data_ptr() + offs[k] * AC * 4
+            d = self._conv_desc(t.val, t.shape, wp, ones, bias, yptr, outc.cin, outc.cout, 1, 1, out_f32=1, y_bs=tot * AC, y_ps=AC)
+            cpad = (outc.cout + 7) // 8 * 8
+            P.fwd.append(dict(kind='out', c=outc, x=t, desc=d, off=offs[k], hw=hw[k], cpad=cpad,
+                              dyp=torch.empty((B * hw[k], cpad), dtype=torch.float32, device=self.dev)))
+            if i >= len(g.heads) - 1:
+                break
+            x = conv_bn(g.transitions[i], route)
+            r = routes[::-1][i + 1]
+            cat = self._new((r.shape[0], r.shape[1], r.shape[2], x.shape[3] + r.shape[3]))
+            P.fwd.append(dict(kind='upcat', up=x, route=r, cat=cat))
+            x = cat
+        return P
+
+    # ---- forward (train mode) -----------------------------------------------------------------------------
+    def _forward(self, P, images):
+        lib, st = self.lib, L.stream_ptr()
+        B, _, H, W = images.shape
+        L.check(lib.yolo_nchw_to_nhwc(images.data_ptr(), L.ptr(P.x8.val), B, 3, H, W, 8, L.F32, st), 'nchw_to_nhwc')
+        for op in P.fwd:
+            if op['kind'] == 'conv_bn':
+                c = op['c']
+                L.check(lib.yolo_conv_fwd(C.byref(op['desc']), st), 'conv ' + c.name)
+                y, z = op['yraw'], op['z']
+                npix = y.shape[0] * y.shape[1] * y.shape[2]
+                p = self.net.params
+                L.check(lib.yolo_bn_train_fwd(L.ptr(y.val), L.ptr(p[c.name + '.gamma']), L.ptr(p[c.name + '.beta']),
+                                              L.ptr(op['res'].val) if op['res'] is not None else None, L.ptr(z.val),
+                                              L.ptr(op['mean']), L.ptr(op['invstd']), L.ptr(p[c.name + '.running_mean']),
+                                              L.ptr(p[c.name + '.running_var']), L.ptr(self.ws), npix, c.cout, BN_EPS,
+                                              BN_MOMENTUM, LEAKY_SLOPE, st), 'bn ' + c.name)
+            elif op['kind'] == 'out':
+                L.check(lib.yolo_conv_fwd(C.byref(op['desc']), st), 'out conv')
+            else:
+                up, r, cat = op['up'], op['route'], op['cat']
+                L.check(lib.yolo_upsample2x_concat(L.ptr(up.val), L.ptr(r.val), L.ptr(cat.val), r.shape[0], r.shape[1],
+                                                   r.shape[2], up.shape[3], r.shape[3], L.F32, st), 'upcat')
+
+    # ---- backward -------------------------------------------------------------------------------------------
+    def _accum(self, t, src):
+        """grad[t] (+)= src (a tensor of the same shape).  First contribution aliases src."""
+        if not t.ready:
+            t.grad, t.ready = src, True
+        else:
+            L.check(self.lib.yolo_add(L.ptr(t.grad), L.ptr(src), L.ptr(t.grad), src.numel(), L.stream_ptr()), 'add')
+
+    def _dgrad(self, c, dy, dy_shape, xin, cin_of_dy):
+        """grad[xin] (+)= data gradient of conv c given dy (N,Ho,Wo,cin_of_dy) (dense)."""
+        lib, st = self.lib, L.stream_ptr()
+        wp, wd, ones, bias, zeros = self._prep[c.name]
+        N, Hh, Ww, Cx = xin.shape
+        if c.stride == 2:
+            dil = torch.empty((N, Hh, Ww, cin_of_dy), dtype=torch.float32, device=self.dev)
+            L.check(lib.yolo_dilate2x(L.ptr(dy), L.ptr(dil), N, Hh, Ww, dy_shape[1], dy_shape[2], cin_of_dy, st), 'dilate')
+            src, sshape = dil, (N, Hh, Ww, cin_of_dy)
+        else:
+            src, sshape = dy, dy_shape
+        if not xin.ready:
+            out = torch.empty(xin.shape, dtype=torch.float32, device=self.dev)
+            resid = None
+        else:
+            out, resid = xin.grad, xin.grad
+        d = self._conv_desc(src, sshape, wd, ones, zeros, out, cin_of_dy, Cx, c.k, 1, residual=resid)
+        L.check(lib.yolo_conv_fwd(C.byref(d), st), 'dgrad ' + c.name)
+        xin.grad, xin.ready = out, True
+
+    def _backward(self, P):
+        lib, st = self.lib, L.stream_ptr()
+        g = self.net.graph
+        self.gflat.zero_()
+        for op in P.fwd:
+            for k in ('x', 'z', 'up', 'route', 'cat', 'res'):
+                t = op.get(k)
+                if t is not None:
+                    t.grad, t.ready = None, False
+        B = P.merged.shape[0]
+        for op in reversed(P.fwd):
+            kind = op['kind']
+            if kind == 'out':
+                c, xin = op['c'], op['x']
+                hw, cpad = op['hw'], op['cpad']
+                src = P.dmerged.data_ptr() + op['off'] * P.AC * 4
+                L.check(lib.yolo_gather_rows(src, L.ptr(op['dyp']), B, hw, c.cout, cpad, P.tot * P.AC, P.AC, st), 'gather')
+                L.check(lib.yolo_bias_grad(L.ptr(op['dyp']), L.ptr(self.gview[c.name + '.bias']), B * hw, c.cout, cpad, st), 'db')
+                N, Hh, Ww, Cx = xin.shape
+                L.check(lib.yolo_conv_wgrad_f32(L.ptr(op['dyp']), L.ptr(xin.val), L.ptr(self.gview[c.name + '.weight']),
+                                                N, Hh, Ww, Cx, c.cout, 1, 1, cpad, st), 'wgrad out')
+                self._dgrad(c, op['dyp'], (N, Hh, Ww, cpad), xin, cpad)
+            elif kind == 'upcat':
+                up, r, cat = op['up'], op['route'], op['cat']
+                if not up.ready:
+                    up.grad = torch.empty(up.shape, dtype=torch.float32, device=self.dev)
+                if not r.ready:
+                    r.grad = torch.empty(r.shape, dtype=torch.float32, device=self.dev)
+                L.check(lib.yolo_upsample2x_concat_bwd(L.ptr(cat.grad), L.ptr(up.grad), L.ptr(r.grad), r.shape[0], r.shape[1],
+                                                       r.shape[2], up.shape[3], r.shape[3], int(up.ready), int(r.ready), st),
+                        'upcat bwd')
+                up.ready = r.ready = True
+            else:
+                c, xin, y, z = op['c'], op['x'], op['yraw'], op['z']
+                dz = z.grad
+                npix = y.shape[0] * y.shape[1] * y.shape[2]
+                p = self.net.params
+                dy = torch.empty(y.shape, dtype=torch.float32, device=self.dev)
+                L.check(lib.yolo_bn_train_bwd(L.ptr(dz), L.ptr(y.val), L.ptr(op['mean']), L.ptr(op['invstd']),
+                                              L.ptr(p[c.name + '.gamma']), L.ptr(p[c.name + '.beta']), L.ptr(dy),
+                                              L.ptr(self.gview[c.name + '.gamma']), L.ptr(self.gview[c.name + '.beta']),
+                                              L.ptr(self.ws), npix, c.cout, LEAKY_SLOPE, st), 'bn bwd ' + c.name)
+                if op['res'] is not None:
+                    self._accum(op['res'], dz)          # the residual branch receives dz unchanged
+                N, Hh, Ww, Cx = xin.shape
+                if c is g.stem:
+                    dw8 = torch.zeros((c.cout, 8, 3, 3), dtype=torch.float32, device=self.dev)
+                    L.check(lib.yolo_conv_wgrad_f32(L.ptr(dy), L.ptr(xin.val), L.ptr(dw8), N, Hh, Ww, 8, c.cout, 3, 1, 0, st), 'wgrad stem')
+                    self.gview[c.name + '.weight'].copy_(dw8[:, :3])
+                else:
+                    L.check(lib.yolo_conv_wgrad_f32(L.ptr(dy), L.ptr(xin.val), L.ptr(self.gview[c.name + '.weight']), N, Hh, Ww,
+                                                    Cx, c.cout, c.k, c.stride, 0, st), 'wgrad ' + c.name)
+                    self._dgrad(c, dy, y.shape, xin, c.cout)
+
+    # ---- one training step -----------------------------------------------------------------------------------
+    def train_step(self, images, labels, global_batch=None, update=True):
+        """images (B,3,H,W) float32 CUDA; labels (B,nobj,6+ncls) float32 CUDA [cls,y,x,h,w,rot,dist...],
+        cls < 0 = no object.  Returns losses (5,B) [score, box_yx, box_hw, rotate, class] (device)."""
+        lib, st = self.lib, L.stream_ptr()
+        images, labels = images.contiguous(), labels.to(self.dev, torch.float32).contiguous()
+        B, _, H, W = images.shape
+        if (H, W) != self.size:
+            raise ValueError('image size differs from the anchor grid the trainer was built for')
+        P = self._plans.get(B)
+        if P is None:
+            P = self._plans[B] = self._build(B, H, W)
+        self._forward(P, images)
+        nobj, ncls = labels.shape[1], labels.shape[2] - 6
+        C_ = self.net.graph.per_anchor
+        rec = torch.empty((B, nobj, 7 + ncls), dtype=torch.float32, device=self.dev)
+        L.check(lib.yolo_assign_targets(L.ptr(labels), L.ptr(self.anchors_ltrb), L.ptr(rec), B, nobj, ncls,
+                                        C.byref(self.grid), st), 'assign')
+        losses = torch.empty((5, B), dtype=torch.float32, device=self.dev)
+        sc = self.scale
+        s5 = (C.c_float * 5)(sc['score'], sc['box_yx'], sc['box_hw'], sc['rotate'] if self.car_rotate else 0.0, sc['class'])
+        L.check(lib.yolo_loss_fwd_bwd(L.ptr(P.merged), L.ptr(rec), L.ptr(P.dmerged), L.ptr(losses), B, self.nbox, C_, nobj,
+                                      s5, self.pos_w, self.neg_w, st), 'loss')
+        self._last = (P, rec)
+        self._backward(P)
+        if update:
+            parallel.allreduce_sum_(self.gflat)                    # KVStore sum-reduce of trainer.step (RCCL)
+            gb = global_batch if global_batch is not None else B * (torch.distributed.get_world_size()
+                                                                     if torch.distributed.is_initialized() else 1)
+            self.t += 1
+            L.check(lib.yolo_adam_step(L.ptr(self.wflat), L.ptr(self.gflat), L.ptr(self.mflat), L.ptr(self.vflat),
+                                       self.wflat.numel(), self.t, self.lr, self.b1, self.b2, self.eps, 1.0 / gb, st), 'adam')
+            self._repack()
+        return losses
+
+    def grads(self):
+        return self.gview
+
+    def merged_logits(self):
+        P = self._last[0]
+        return P.merged.view(P.merged.shape[0], P.tot, P.A, self.net.graph.per_anchor)
