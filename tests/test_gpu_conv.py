@@ -78,6 +78,7 @@ PIPE_CASES = [
     (4, 256, 26, 26, 512, 1, 1, True),
     (2, 512, 13, 13, 88, 1, 1, False),
     (2, 64, 26, 26, 128, 3, 1, False),     # Cout smaller than the widest cout tile
+    (2, 32, 40, 40, 64, 3, 1, True),       # a single K-chunk in bf16 (9 phases)
 ]
 
 

@@ -302,7 +302,7 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
 // reference's batch sizes tile quantisation on the 13x13 / 26x26 maps costs more than any difference
 // between the variants' inner loops.  The per-variant factors are measured (tools/conv_bench.py).
 static int conv_auto_algo(const ConvArgs& a, int ks, int stride, int dtype) {
-    if ((a.Cin * elem_size(dtype)) % 64 || a.nchunks < 2) return 1;
+    if ((a.Cin * elem_size(dtype)) % 64 || (ks == 1 && a.nchunks < 2)) return 1;
     if (stride == 2) return ks == 3 ? (a.Cout > 128 ? 10 : 9) : 1;
     struct V { int algo, bp, bc, bpc; float f; bool k1; };
     static const V vs[] = {{2, 256, 256, 1, 1.00f, true}, {3, 256, 128, 1, 1.10f, true}, {4, 128, 128, 2, 1.05f, true},

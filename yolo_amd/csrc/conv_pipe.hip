@@ -381,7 +381,7 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
 int conv_pipe_dispatch(ConvArgs& a, int ks, int stride, int dtype, int algo, hipStream_t st, const NameOut* nm) {
     if ((ks != 1 && ks != 3) || (stride != 1 && !(ks == 3 && stride == 2))) return YOLO_EUNSUPPORTED;
     if ((a.Cin * elem_size(dtype)) % 64) return YOLO_EUNSUPPORTED;
-    if (a.nchunks < 2) return YOLO_EUNSUPPORTED;
+    if (ks == 1 && a.nchunks < 2) return YOLO_EUNSUPPORTED;     // a 1x1 needs >= 2 phases; a 3x3 has 9 per chunk
     if ((long long)a.N * a.H * a.W * a.Cin * elem_size(dtype) >= 0xffffff00LL) return YOLO_EUNSUPPORTED;
     if (dtype == YOLO_BF16) return pipe_dispatch_t<__bf16>(a, ks, stride, algo, st, nm);
     return pipe_dispatch_t<float>(a, ks, stride, algo, st, nm);

@@ -32,14 +32,20 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     const long long HW = (long long)H * W;
     const float* xn = x + (long long)n * 3 * HW;
 
-    // ---- stage the halo tile: NCHW f32 -> LDS NHWC4 bf16 ------------------------------------------
-    for (int s = tid; s < (STEM_TH + 2) * STEM_PW; s += 256) {
-        const int r = s / STEM_PW, c = s - r * STEM_PW;
+    // ---- stage the halo tile: NCHW f32 -> LDS NHWC4 bf16 (all loads of the block issued before the first
+    //      LDS write: one HBM latency per tile, not one per pass) -------------------------------------------
+    constexpr int NSLOT = (STEM_TH + 2) * STEM_PW;
+    constexpr int NPASS = (NSLOT + 255) / 256;
+    float c0[NPASS], c1[NPASS], c2[NPASS];
+    bool okp[NPASS];
+#pragma unroll
+    for (int j = 0; j < NPASS; ++j) {
+        const int sl = min(tid + j * 256, NSLOT - 1);
+        const int r = sl / STEM_PW, c = sl - r * STEM_PW;
         const int iy = y0 + r - 1, ix = x0 + c - 1;
-        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        okp[j] = iy >= 0 && iy < H && ix >= 0 && ix < W;
         const long long o = (long long)min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1);
-        const float c0 = xn[o], c1 = xn[HW + o], c2 = xn[2 * HW + o];
-        tile[s] = ok ? make_uint2(pack_bf16x2(c0, c1), pack_bf16x2(c2, 0.f)) : make_uint2(0u, 0u);
+        c0[j] = xn[o]; c1[j] = xn[HW + o]; c2[j] = xn[2 * HW + o];
     }
     // ---- weight fragments: lane (cout = mi*32 + l31, k-half h), one per kernel row -----------------
     uint4 wf[3][MI];
@@ -59,6 +65,12 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
             wf[kh][mi] = make_uint4(pack_bf16x2(v[0][0], v[0][1]), pack_bf16x2(v[0][2], 0.f),
                                     pack_bf16x2(v[1][0], v[1][1]), pack_bf16x2(v[1][2], 0.f));
         }
+    }
+#pragma unroll
+    for (int j = 0; j < NPASS; ++j) {
+        const int sl = tid + j * 256;
+        if (sl < NSLOT)
+            tile[sl] = okp[j] ? make_uint2(pack_bf16x2(c0[j], c1[j]), pack_bf16x2(c2[j], 0.f)) : make_uint2(0u, 0u);
     }
     __syncthreads();
 
