@@ -84,7 +84,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('YOLO_BENCH_FORCE_DIST'):      # (the env knob exercises the N>1 code path on one GPU)
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=dev)
 

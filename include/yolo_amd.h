@@ -124,6 +124,12 @@ int yolo_decode(const float* out, float* rows, int B, int C, const yolo_grid_des
 int yolo_predict_top1(const float* out, float* pred, int* best_idx, int B, int C,
                       const yolo_grid_desc* g, void* stream);
 
+/* LicencePlateDetectioin.predict_LP (licence_plate/LP_detection.py:147-162; BASELINE config 1 plumbing):
+ * out (1,C,h,w) float32 NCHW -> pred (C) [sigmoid(score), xyz*1000, 3 angles (sigmoid-.5)*2*r_max*pi/180, rest
+ * raw] of the cell with the highest channel-0 value (first among ties); best_idx (1) int32. */
+int yolo_predict_lp(const float* out, float* pred, int* best_idx, int C, int h, int w, float r_max0,
+                    float r_max1, float r_max2, void* stream);
+
 /* get_iou(predict, target, mode=2), yolo_gluon.py:127-168: boxes (n,4) ltrb vs one target
  * [c,y,x,h,w] (5 floats, device) -> iou (n). */
 int yolo_iou_ltrb_vs_yxhw(const float* boxes, const float* target, float* iou, int n, void* stream);

@@ -138,3 +138,14 @@ def test_cv_img_2_ndarray(cuda):
     img = np.random.default_rng(5).integers(0, 256, (246, 560, 3), dtype=np.uint8)   # licence_plate/test.jpg size
     got = cv_img_2_ndarray(img, cuda).cpu().numpy()
     np.testing.assert_array_equal(got, od.cv_img_2_ndarray(img))
+
+
+def test_predict_LP_config1(cuda):
+    """BASELINE config 1 plumbing: image -> (1,3,H,W)/255 on device, LPD pose decode of the best cell."""
+    from yolo_amd.detect import predict_LP
+    out = np.random.default_rng(6).standard_normal((1, 10, 10, 16)).astype(np.float32)
+    out[0, 0, 3, 5] = out[0, 0, 7, 2] = 9.0                      # tie: the first cell wins
+    got = predict_LP(torch.from_numpy(out).to(cuda), [40, 30, 20])
+    ref, best = od.predict_LP(out, [40, 30, 20])
+    assert best == 3 * 16 + 5
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)

@@ -432,3 +432,54 @@ extern "C" int yolo_nms(const float* rows, int B, int nbox, int C, int mode, flo
     return yolo_nms_from_scores(rows, (const float*)workspace, B, nbox, C, mode == 1 ? C - 6 : 1, valid_thresh,
                                 iou_thresh, topk, post_nms, kept, kept_scores, kept_count, stream);
 }
+
+// ---- LPD plumbing (BASELINE config 1): LicencePlateDetectioin.predict_LP, LP_detection.py:147-162 --------
+// out (1, C, h, w) float32 NCHW -> pred (C): arg-max of channel 0 over the h*w cells (first index among
+// ties), then sigmoid(score), xyz * 1000, three angles (sigmoid - 0.5) * 2 * r_max * pi / 180.
+__global__ __launch_bounds__(256) void predict_lp_kernel(const float* __restrict__ out, float* __restrict__ pred,
+                                                         int* __restrict__ best_idx, int C, int hw, float r0, float r1,
+                                                         float r2) {
+    float bv = -FLT_MAX; int bi = 0x7fffffff;
+    for (int k = threadIdx.x; k < hw; k += blockDim.x) {
+        const float v = out[k];
+        if (v > bv) { bv = v; bi = k; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(bv, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        argmax_combine(bv, bi, ov, oi);
+    }
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) argmax_combine(bv, bi, sv[w], si[w]);
+        si[0] = bi;
+        best_idx[0] = bi;
+    }
+    __syncthreads();
+    const int k = si[0];
+    const int c = threadIdx.x;
+    if (c < C) {
+        float v = out[(long long)c * hw + k];
+        if (c == 0) v = sigmoidf_ref(v);
+        else if (c < 4) v = v * 1000.f;
+        else if (c < 7) {
+            const float r = c == 4 ? r0 : (c == 5 ? r1 : r2);
+            v = (sigmoidf_ref(v) - 0.5f) * 2.f * r;
+            v = v * 3.14159274101257324f / 180.f;
+        }
+        pred[c] = v;
+    }
+}
+
+extern "C" int yolo_predict_lp(const float* out, float* pred, int* best_idx, int C, int h, int w, float r_max0,
+                               float r_max1, float r_max2, void* stream) {
+    if (!out || !pred || !best_idx || C < 7 || C > 256 || h <= 0 || w <= 0) return YOLO_EINVAL;
+    YOLO_LAUNCH(predict_lp_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out, pred, best_idx, C, h * w, r_max0,
+                r_max1, r_max2);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}

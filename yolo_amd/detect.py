@@ -153,3 +153,15 @@ def default_ltrb(all_anchors, size, steps):
         right = np.tile(x + f32(0.5) * w, yn).reshape(a, n, 1)
         out.append(np.concatenate([left, top, right, bot], axis=-1))
     return np.concatenate(out, axis=0).astype(f32)
+
+
+def predict_LP(batch_out, r_max):
+    """LicencePlateDetectioin.predict_LP (licence_plate/LP_detection.py:147-162): (1,C,h,w) float32 CUDA
+    tensor -> np.float32 (C,) pose row of the best cell."""
+    o = batch_out.contiguous()
+    _, Cc, h, w = o.shape
+    pred = torch.empty((Cc,), dtype=torch.float32, device=o.device)
+    idx = torch.empty((1,), dtype=torch.int32, device=o.device)
+    L.check(L.load().yolo_predict_lp(L.ptr(o), L.ptr(pred), L.ptr(idx), Cc, h, w, float(r_max[0]), float(r_max[1]),
+                                     float(r_max[2]), L.stream_ptr()), 'predict_lp')
+    return pred.cpu().numpy()
