@@ -62,6 +62,22 @@ def cpu_baseline(size, seconds=12.0, batch=2):
                        % (size[0], size[1], batch, n, el))
 
 
+def pmc_traffic(kernel, B, size):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/*_pmc_traffic.json,
+    made by tools/pmc_traffic.py in separate --pmc passes: FETCH_SIZE doubled per the gfx950 note of
+    MI355X_MICROARCH.md, + WRITE_SIZE), or None when no profile of this kernel / workload is committed."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')), reverse=True):
+        with open(path) as f:
+            prof = json.load(f)
+        if prof.get('workload') != [B, size[0], size[1]]:
+            continue
+        ent = prof.get('kernels', {}).get(kernel)
+        if ent:
+            return int(ent['hbm_bytes_per_launch'])
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -72,6 +88,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--tune-cache', default=None, help='JSON file remembering the measured per-layer kernel choices')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -95,7 +112,7 @@ def main():
     spec = darknet53_spec()
     size = (args.size, args.size)
     B = args.batch
-    net = CarNet(spec, dtype=args.dtype, device=dev, tune='measure').initialize(seed=1234)
+    net = CarNet(spec, dtype=args.dtype, device=dev, tune='measure', tune_cache=args.tune_cache).initialize(seed=1234)
     net.prepare()
     det = Detector(spec, size, net.graph.steps(), device=dev)
     gen = torch.Generator(device='cpu').manual_seed(100 + rank)
@@ -160,7 +177,7 @@ def main():
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         ach = fl / tsec / 1e12
         out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s',
-                           'frac': round(ach / peak, 4), 'traffic': None, 'kernel': dom,
+                           'frac': round(ach / peak, 4), 'traffic': pmc_traffic(dom, B, size), 'kernel': dom,
                            'launches_per_step': nl // args.steps,
                            'avg_launch_us': round(tsec / nl * 1e6, 2),
                            'flops_per_launch': fl // nl}

@@ -57,7 +57,7 @@ def test_abi_host_only_queries(lib):
     d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.dtype = 32, 13, 13, 1024, 2048, 3, 1, L.BF16
     buf = C.create_string_buffer(256)
     assert lib.yolo_conv_kernel_name(C.byref(d), buf, 256) == 0
-    assert b'conv_' in buf.value and b'__bf16' in buf.value
+    assert b'conv_' in buf.value and b'bf16_t' in buf.value
     d.stride = 3
     assert lib.yolo_conv_kernel_name(C.byref(d), buf, 256) == -2
 

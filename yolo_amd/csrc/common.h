@@ -7,6 +7,9 @@
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// 2-byte element tag for kernel templates.  (Not __bf16 itself: rocprofv3's demangler garbles kernel names
+// that carry the DF16b mangling, which makes profiles unreadable.)
+struct bf16_t { uint16_t bits; };
 
 // hipGetLastError() is per-thread sticky state shared with every other HIP user in the process
 // (torch): YOLO_LAUNCH() drops whatever was pending so YOLO_LAUNCH_CHECK() reports only ours.

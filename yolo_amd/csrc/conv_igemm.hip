@@ -22,7 +22,7 @@
 
 
 template <typename T> struct Frag;
-template <> struct Frag<__bf16> {
+template <> struct Frag<bf16_t> {
     static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16& c) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
                                                     __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -245,7 +245,7 @@ static int launch_cfg(ConvArgs& a, hipStream_t st, const NameOut* name) {
     constexpr int BP = WAVES_P * NI * 32, BC = WAVES_C * MI * 32;
     if (name) {
         snprintf(name->buf, name->len, "void conv_igemm_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d>(ConvArgs)",
-                 sizeof(T) == 2 ? "__bf16" : "float", KS, S, WAVES_P, WAVES_C, MI, NI, XSLOTS, TS);
+                 sizeof(T) == 2 ? "bf16_t" : "float", KS, S, WAVES_P, WAVES_C, MI, NI, XSLOTS, TS);
         return YOLO_OK;
     }
     if (KS == 3) {
@@ -371,7 +371,7 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
             if (rc != YOLO_EUNSUPPORTED) return rc;
         }
     }
-    if (d->dtype == YOLO_BF16) return launch_dtype<__bf16>(a, d->ksize, d->stride, st, nm);
+    if (d->dtype == YOLO_BF16) return launch_dtype<bf16_t>(a, d->ksize, d->stride, st, nm);
     return launch_dtype<float>(a, d->ksize, d->stride, st, nm);
 }
 
@@ -444,8 +444,8 @@ static int pack_impl(const float* w_oihw, void* packed, int Cout, int Cin, int k
     const long long total = bytes / elem_size(dtype);
     const int grid = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
     if (dtype == YOLO_BF16)
-        YOLO_LAUNCH(pack_weights_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
-                           (__bf16*)packed, Cout, Cin, ksize, Cout_pad, nchunks, dgrad);
+        YOLO_LAUNCH(pack_weights_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                           (bf16_t*)packed, Cout, Cin, ksize, Cout_pad, nchunks, dgrad);
     else
         YOLO_LAUNCH(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
                            (float*)packed, Cout, Cin, ksize, Cout_pad, nchunks, dgrad);

@@ -37,7 +37,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <typename T> struct FragP;
-template <> struct FragP<__bf16> {
+template <> struct FragP<bf16_t> {
     static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16& c) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
                                                     0, 0);
@@ -331,7 +331,7 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
     if (name) {
         snprintf(name->buf, name->len, "void conv_pipe_kernel<%s, %d, %d, %d, %d, %d, %d, %d>(ConvArgs)",
-                 sizeof(T) == 2 ? "__bf16" : "float", KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S);
+                 sizeof(T) == 2 ? "bf16_t" : "float", KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S);
         return YOLO_OK;
     }
     YOLO_LAUNCH((conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S>), dim3((unsigned)grid),
@@ -383,6 +383,6 @@ int conv_pipe_dispatch(ConvArgs& a, int ks, int stride, int dtype, int algo, hip
     if ((a.Cin * elem_size(dtype)) % 64) return YOLO_EUNSUPPORTED;
     if (ks == 1 && a.nchunks < 2) return YOLO_EUNSUPPORTED;     // a 1x1 needs >= 2 phases; a 3x3 has 9 per chunk
     if ((long long)a.N * a.H * a.W * a.Cin * elem_size(dtype) >= 0xffffff00LL) return YOLO_EUNSUPPORTED;
-    if (dtype == YOLO_BF16) return pipe_dispatch_t<__bf16>(a, ks, stride, algo, st, nm);
+    if (dtype == YOLO_BF16) return pipe_dispatch_t<bf16_t>(a, ks, stride, algo, st, nm);
     return pipe_dispatch_t<float>(a, ks, stride, algo, st, nm);
 }

@@ -71,8 +71,8 @@ extern "C" int yolo_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, i
     const long long HW = (long long)H * W, total = HW * N;
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (dtype == YOLO_BF16)
-        YOLO_LAUNCH((nchw_to_nhwc_kernel<__bf16, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
-                           (__bf16*)y, C, HW, total);
+        YOLO_LAUNCH((nchw_to_nhwc_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
+                           (bf16_t*)y, C, HW, total);
     else if (dtype == YOLO_F32)
         YOLO_LAUNCH((nchw_to_nhwc_kernel<float, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
                            (float*)y, C, HW, total);
@@ -122,8 +122,8 @@ extern "C" int yolo_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, i
     const long long HW = (long long)H * W, total = HW * N * C;
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (dtype == YOLO_BF16)
-        YOLO_LAUNCH(nhwc_to_nchw_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                           (const __bf16*)x, y, C, HW, total);
+        YOLO_LAUNCH(nhwc_to_nchw_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, y, C, HW, total);
     else if (dtype == YOLO_F32)
         YOLO_LAUNCH(nhwc_to_nchw_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const float*)x, y, C, HW, total);

@@ -6,6 +6,8 @@ fine->coarse, each (B, H_i*W_i, A, C) float32.  Every arithmetic op runs in liby
 (hand-written HIP for gfx950); torch only owns device memory and the stream.
 """
 import ctypes as C
+import json
+import os
 
 import numpy as np
 import torch
@@ -31,7 +33,7 @@ class _Plan(object):
 class CarNet(object):
     ALGOS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10)     # yolo_conv_desc.algo ids tried by tune='measure'
 
-    def __init__(self, spec, num_sync_bn_devices=-1, dtype='bf16', device='cuda:0', tune='auto'):
+    def __init__(self, spec, num_sync_bn_devices=-1, dtype='bf16', device='cuda:0', tune='auto', tune_cache=None):
         # num_sync_bn_devices is accepted for signature parity; the reference always passes -1
         # (no SyncBN, car/YOLO.py:94-96).
         if dtype not in _TORCH_DT:
@@ -45,6 +47,11 @@ class CarNet(object):
             raise ValueError("tune must be 'auto' or 'measure'")
         self.tune = tune
         self._algo_cache = {}
+        # optional JSON file remembering measured choices (so a profiled run launches only the chosen kernels)
+        self._tune_cache = tune_cache
+        if tune_cache and os.path.exists(tune_cache):
+            with open(tune_cache) as f:
+                self._algo_cache = {tuple(json.loads(k)): v for k, v in json.load(f).items()}
         self.params = {}
         self._prepared = {}
         self._plans = {}
@@ -162,6 +169,9 @@ class CarNet(object):
                 best, best_t = algo, t
         d.algo = 0
         self._algo_cache[key] = best
+        if self._tune_cache:
+            with open(self._tune_cache, 'w') as f:
+                json.dump({json.dumps(list(k)): v for k, v in self._algo_cache.items()}, f)
         return best
 
     def _build_plan(self, B, H, W):
