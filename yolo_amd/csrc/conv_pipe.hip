@@ -218,7 +218,6 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     __builtin_amdgcn_s_barrier();
 
     constexpr int NM = 2 * MI * NI;                     // MFMA "steps" per phase (one 16-byte operand pair each)
-    // one phase; SHIFT = first MFMA step after which a DMA is issued (differs between the wave halves)
     auto phase = [&](auto shift_c, int c, int q, int gp) {
         constexpr int SHIFT = decltype(shift_c)::value;
         const int nx = (KS == 3) ? (q < XL ? 1 : 0) : XL;          // input DMAs of this phase
@@ -346,6 +345,8 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
 //   6: 8 waves, 192 px x 256 cout (wave tile 96x64)    7: 8 waves, 192 px x 128 cout (wave tile 96x32)
 //   8: 4 waves, 192 px x 128 cout (wave tile 96x64)    -- 192-pixel tiles exist to cut tile quantisation
 //   9 / 10: 3x3 stride 2, 8 waves, 128 px x 128 / 256 cout
+//   11: 4 waves, 64 px x 128 cout; 12 (1x1 only): 4 waves, 64 px x 256 cout -- small-M layers (13x13 maps at
+//       batch 32 have 5408 pixels: more, smaller tiles fill the chip)
 template <typename T>
 static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_t st, const NameOut* nm) {
     if (ks == 3 && stride == 2) {
@@ -365,6 +366,7 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
             case 6: return launch_pipe<T, 3, 2, 4, 2, 3, 384>(a, st, nm);
             case 7: return launch_pipe<T, 3, 2, 4, 1, 3, 384>(a, st, nm);
             case 8: return launch_pipe<T, 3, 2, 2, 2, 3, 320>(a, st, nm);
+            case 11: return launch_pipe<T, 3, 2, 2, 2, 1, 192>(a, st, nm);
         }
     } else {
         switch (algo) {
@@ -373,6 +375,8 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
             case 4: return launch_pipe<T, 1, 2, 2, 2, 2, 128>(a, st, nm);
             case 5: return launch_pipe<T, 1, 1, 8, 1, 4, 128>(a, st, nm);
             case 8: return launch_pipe<T, 1, 2, 2, 2, 3, 192>(a, st, nm);
+            case 11: return launch_pipe<T, 1, 2, 2, 2, 1, 64>(a, st, nm);
+            case 12: return launch_pipe<T, 1, 1, 4, 2, 2, 64>(a, st, nm);
         }
     }
     return YOLO_EUNSUPPORTED;
