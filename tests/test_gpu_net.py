@@ -59,6 +59,32 @@ def test_test_yaml_f32(cuda):
         np.testing.assert_allclose(o, r.numpy(), rtol=0, atol=1e-3)
 
 
+def test_car_v1_native_size(cuda):
+    """The reference's own model and size: car/v1/spec.yaml (6 down-samplings, stem 16 ch) at 320x512; output
+    shapes as its author recorded them (car/YOLO.py:661-662); fp32 within 1e-3, bf16 as good as simulated bf16."""
+    spec, size = og.spec_car_v1(), (320, 512)
+    g, P, x, net, outs = _run(spec, size, 1, 'f32', 'random', cuda)
+    assert [o.shape for o in outs] == [(1, 640, 3, 30), (1, 160, 3, 30), (1, 40, 3, 30)]
+    ref = [r.numpy() for r in of.forward_torch(g, P, x)]
+    for o, r in zip(outs, ref):
+        np.testing.assert_allclose(o, r, rtol=0, atol=1e-3)
+    _, _, _, _, outs16 = _run(spec, size, 1, 'bf16', 'random', cuda, tune='measure')
+    sim = [s.numpy() for s in of.forward_torch_bf16sim(g, P, x)]
+    rms = lambda a: float(np.sqrt(np.mean(a * a)))
+    for o, s, r in zip(outs16, sim, ref):
+        assert rms(o - r) / r.std() < 1.5 * rms(s - r) / r.std() + 1e-3
+
+
+def test_batch_one_and_odd_batch(cuda):
+    """B=1 (the reference's inference batch, yolo_gluon.py:209) and an odd batch give the same per-image result."""
+    spec, size = og.spec_micro(), (64, 96)
+    g, P, x, net, outs5 = _run(spec, size, 5, 'f32', 'random', cuda)
+    for b in (0, 4):
+        o1 = net(torch.from_numpy(x[b:b + 1]).to(cuda))
+        for a, full in zip(o1, outs5):
+            np.testing.assert_allclose(a.cpu().numpy()[0], full[b], rtol=0, atol=1e-5)
+
+
 def test_micro_bf16(cuda):
     spec, size = og.spec_micro(), (64, 96)
     g, P, x, net, outs = _run(spec, size, 3, 'bf16', 'random', cuda)
