@@ -3,6 +3,24 @@
 #pragma once
 #include "common.h"
 
+// Exact unsigned division by a launch-constant divisor (n < 2^31): q = (n * mul) >> sh.  The per-tile set-up
+// does ~20 divisions per thread (pixel -> strip row / image / column); at ~30 instructions each they were a
+// measurable share of short-K tiles.
+struct FastDiv {
+    unsigned mul, sh;
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    f.sh = 31 + s;
+    f.mul = (unsigned)(((1ull << f.sh) + d - 1) / d);
+    return f;
+}
+__device__ __forceinline__ int fdiv(int n, FastDiv f) {
+    return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.sh);
+}
+
 struct ConvArgs {
     const char* x;
     const char* wp;
@@ -16,8 +34,15 @@ struct ConvArgs {
     int out_f32;
     float slope;
     long long y_bs, y_ps;
-    int dbg;            // experiment knobs (YOLO_DBG env, 0 in production): see conv_pipe.hip
+    int dbg;            // unused (kept for ABI stability of the argument block)
+    FastDiv d_PW, d_H1, d_TWt, d_Ho, d_HoWo, d_tc, d_tps;   // divisors PW, H+1, TWt, Ho, Ho*Wo, tiles_c, tiles_per_strip
 };
+
+static inline void conv_args_fastdiv(ConvArgs& a) {
+    a.d_PW = make_fastdiv(a.PW); a.d_H1 = make_fastdiv(a.H + 1); a.d_TWt = make_fastdiv(a.TWt);
+    a.d_Ho = make_fastdiv(a.Ho); a.d_HoWo = make_fastdiv((unsigned)a.Ho * a.Wo); a.d_tc = make_fastdiv(a.tiles_c);
+    a.d_tps = make_fastdiv(a.tiles_per_strip);
+}
 
 // `name` != nullptr: write the kernel instantiation that WOULD run (rocprofv3's demangled name) and
 // do not launch.

@@ -100,9 +100,9 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     const int wave_p = wave % WAVES_P, wave_c = wave / WAVES_P;
 
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_c = lid % a.tiles_c;
-    const int tile_p = lid / a.tiles_c;
-    const int strip = tile_p / a.tiles_per_strip;
+    const int tile_p = fdiv(lid, a.d_tc);
+    const int tile_c = lid - tile_p * a.tiles_c;
+    const int strip = fdiv(tile_p, a.d_tps);
     const int i0 = (tile_p - strip * a.tiles_per_strip) * BP;
     const int co0 = tile_c * BC;
     const int H = a.H, W = a.W, Ho = a.Ho, Wo = a.Wo, TWt = a.TWt, PW = a.PW;
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     int Rin_lo = 0, HS = XSLOTS, x0 = 0;
     if constexpr (KS == 3) {
         const int i_last = min(i0 + BP, a.total_i) - 1;
-        const int r_first = i0 / TWt, r_last = i_last / TWt;
-        const int n_f = r_first / Ho, n_l = r_last / Ho;
+        const int r_first = fdiv(i0, a.d_TWt), r_last = fdiv(i_last, a.d_TWt);
+        const int n_f = fdiv(r_first, a.d_Ho), n_l = fdiv(r_last, a.d_Ho);
         Rin_lo = n_f * (H + 1) + (r_first - n_f * Ho) * S;
         const int Rin_hi = n_l * (H + 1) + (r_last - n_l * Ho) * S + 2;
         HS = (Rin_hi - Rin_lo + 1) * PW;
@@ -129,9 +129,9 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         bool valid;
         long long off;
         if constexpr (KS == 3) {
-            const int rr = slot / PW, cc = slot - rr * PW;
+            const int rr = fdiv(slot, a.d_PW), cc = slot - rr * PW;
             const int Rr = Rin_lo + rr;
-            const int n = Rr / (H + 1);
+            const int n = fdiv(Rr, a.d_H1);
             const int yy = Rr - n * (H + 1) - 1;
             const int xx = x0 + cc;
             valid = slot < HS && yy >= 0 && n < a.N && xx >= 0 && xx < W;
@@ -155,9 +155,9 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         const int i = i0 + (wave_p * NI + ni) * 32 + l31;
         const int ii = (i < a.total_i) ? i : i0;
         if constexpr (KS == 3) {
-            const int r = ii / TWt;
+            const int r = fdiv(ii, a.d_TWt);
             const int tx = ii - r * TWt;
-            const int n = r / Ho;
+            const int n = fdiv(r, a.d_Ho);
             slot00[ni] = (n * (H + 1) + (r - n * Ho) * S - Rin_lo) * PW + tx * S;
         } else {
             slot00[ni] = ii - i0;
@@ -283,13 +283,13 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         const int i = i0 + (wave_p * NI + ni) * 32 + l31;
         int n, pix;
         if constexpr (KS == 3) {
-            const int r = i / TWt;
-            const int tx = i - r * TWt;
-            n = r / Ho;
+            const int r = fdiv(min(i, a.total_i - 1), a.d_TWt);
+            const int tx = min(i, a.total_i - 1) - r * TWt;
+            n = fdiv(r, a.d_Ho);
             pix = (r - n * Ho) * Wo + strip * TWt + tx;
         } else {
-            n = i / (Ho * Wo);
-            pix = i - n * (Ho * Wo);
+            n = fdiv(min(i, a.total_i - 1), a.d_HoWo);
+            pix = min(i, a.total_i - 1) - n * (Ho * Wo);
         }
         yoff[ni] = (i < a.total_i) ? (long long)n * a.y_bs + (long long)pix * a.y_ps : -1;
     }
@@ -328,6 +328,7 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     a.tiles_c = (a.Cout + BC - 1) / BC;
     const long long grid = (long long)a.nstrips * a.tiles_per_strip * a.tiles_c;
     if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
+    conv_args_fastdiv(a);
     if (name) {
         snprintf(name->buf, name->len, "void conv_pipe_kernel<%s, %d, %d, %d, %d, %d, %d, %d>(ConvArgs)",
                  sizeof(T) == 2 ? "bf16_t" : "float", KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S);
