@@ -161,35 +161,41 @@ int yolo_pack_conv_weights_dgrad(const float* w_oihw, void* packed, int Cout_f, 
                                  int dtype, void* stream);
 
 /* Gluon BatchNorm in training mode fused with LeakyReLU (+ residual add):
- * batch mean / biased variance over (N,H,W) of the NHWC fp32 conv output y (npix x C),
+ * batch mean / biased variance over (N,H,W) of the NHWC conv output y (npix x C, dtype; C % 8 == 0),
  * z = lrelu(gamma*(y-mean)*invstd + beta) [+ residual]; running stats r = momentum*r + (1-momentum)*batch
- * (running_var takes the biased variance).  workspace: 2*C doubles. */
-int yolo_bn_train_fwd(const float* y, const float* gamma, const float* beta, const float* residual,
-                      float* z, float* mean, float* invstd, float* running_mean, float* running_var,
+ * (running_var takes the biased variance).  Statistics are accumulated in double.  workspace: 2*C doubles. */
+int yolo_bn_train_fwd(const void* y, const float* gamma, const float* beta, const void* residual,
+                      void* z, float* mean, float* invstd, float* running_mean, float* running_var,
                       double* workspace, long long npix, int C, float eps, float momentum, float slope,
-                      void* stream);
+                      int dtype, void* stream);
 /* Backward of the above w.r.t. y, gamma, beta given dz (the residual branch receives dz unchanged). */
-int yolo_bn_train_bwd(const float* dz, const float* y, const float* mean, const float* invstd,
-                      const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta,
-                      double* workspace, long long npix, int C, float slope, void* stream);
+int yolo_bn_train_bwd(const void* dz, const void* y, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, void* dy, float* dgamma, float* dbeta,
+                      double* workspace, long long npix, int C, float slope, int dtype, void* stream);
 
 /* Weight gradient of Conv(k, stride, pad k/2): dw (Cout,Cin,k,k) float32 += sum over pixels of
- * dy (N,Ho,Wo,[dy_pixel_stride]) x (N,H,W,Cin), NHWC fp32.  The caller zero-fills dw. */
-int yolo_conv_wgrad_f32(const float* dy, const float* x, float* dw_oihw, int N, int H, int W, int Cin,
-                        int Cout, int ksize, int stride, long long dy_pixel_stride, void* stream);
+ * dy (N,Ho,Wo,[dy_pixel_stride]) x (N,H,W,Cin), NHWC `dtype`.  The caller zero-fills dw once per step.
+ * YOLO_F32: MFMA 32x32x2 f32.  YOLO_BF16: MFMA 32x32x16 bf16 fed by transposing LDS reads
+ * (ds_read_b64_tr_b16), fp32 accumulation; needs `workspace` of yolo_conv_wgrad_workspace_bytes(). */
+long long yolo_conv_wgrad_workspace_bytes(int Cin, int Cout, int ksize, int dtype);
+int yolo_conv_wgrad(const void* dy, const void* x, float* dw_oihw, int N, int H, int W, int Cin, int Cout,
+                    int ksize, int stride, long long dy_pixel_stride, int dtype, void* workspace,
+                    void* stream);
 /* db[c] += sum over npix rows of dy (row stride pixel_stride, 0 = C): YOLOOutput's bias gradient. */
-int yolo_bias_grad(const float* dy, float* db, long long npix, int C, long long pixel_stride, void* stream);
-/* (B, rows, [src strides]) C floats per row -> dense (B*rows, Cpad), zero padded. */
-int yolo_gather_rows(const float* src, float* dst, int B, long long rows_per_batch, int C, int Cpad,
-                     long long src_batch_stride, long long src_row_stride, void* stream);
+int yolo_bias_grad(const void* dy, float* db, long long npix, int C, long long pixel_stride, int dtype,
+                   void* stream);
+/* float32 (B, rows, [src strides]) C values per row -> dense (B*rows, Cpad) of `dtype`, zero padded. */
+int yolo_gather_rows(const float* src, void* dst, int B, long long rows_per_batch, int C, int Cpad,
+                     long long src_batch_stride, long long src_row_stride, int dtype, void* stream);
 /* D (N,H,W,C): D[n,2y,2x,:] = dy[n,y,x,:] (dy is (N,Ho,Wo,C)), zeros elsewhere: turns the stride-2 data
- * gradient into a stride-1 convolution. */
-int yolo_dilate2x(const float* dy, float* d, int N, int H, int W, int Ho, int Wo, int C, void* stream);
+ * gradient into a stride-1 convolution.  C % 8 == 0. */
+int yolo_dilate2x(const void* dy, void* d, int N, int H, int W, int Ho, int Wo, int C, int dtype,
+                  void* stream);
 /* Backward of yolo_upsample2x_concat: dcat (N,H,W,C1+C2) -> dup (N,H/2,W/2,C1), droute (N,H,W,C2);
  * accumulate_* != 0 adds into the destination. */
-int yolo_upsample2x_concat_bwd(const float* dcat, float* dup, float* droute, int N, int H, int W, int C1,
-                               int C2, int accumulate_up, int accumulate_route, void* stream);
-int yolo_add(const float* a, const float* b, float* y, long long n, void* stream);
+int yolo_upsample2x_concat_bwd(const void* dcat, void* dup, void* droute, int N, int H, int W, int C1,
+                               int C2, int accumulate_up, int accumulate_route, int dtype, void* stream);
+int yolo_add(const void* a, const void* b, void* y, long long n, int dtype, void* stream);
 
 /* _find_best + the scatter of _loss_mask (car/YOLO.py:401-480): labels (B,nobj,6+ncls)
  * [cls,y,x,h,w,rot,dist...] (cls < 0 = no object), anchors_ltrb (nbox,4) = _get_default_ltrb

@@ -44,6 +44,8 @@ def _conv_bn_act_torch(P, c, x, training=False, bn_stats=None, sim_bf16=False, r
     if not c['bn']:
         return y + _t(P, c['name'] + '.bias').view(1, -1, 1, 1)
     g, b = _t(P, c['name'] + '.gamma'), _t(P, c['name'] + '.beta')
+    if training and sim_bf16:
+        y = _bf16_round(y)          # the bf16 training path stores the pre-BN conv output in bf16
     if training:
         # Gluon BatchNorm train mode: biased batch variance
         mean = y.mean(dim=(0, 2, 3))

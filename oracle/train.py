@@ -184,7 +184,7 @@ def synthetic_labels(batch, seed=3, render_rate=0.5, num_class=24):
     return lab
 
 
-def train_step_reference(g, P, x, labels, spec, size, scale=DEFAULT_SCALE):
+def train_step_reference(g, P, x, labels, spec, size, scale=DEFAULT_SCALE, sim_bf16=False):
     """One forward (train-mode BN) + loss + backward on the torch-CPU graph; returns losses and
     gradients w.r.t. every trainable parameter (dict name -> ndarray)."""
     Pt = {}
@@ -193,7 +193,8 @@ def train_step_reference(g, P, x, labels, spec, size, scale=DEFAULT_SCALE):
         if k.endswith(('.weight', '.gamma', '.beta', '.bias')):
             t.requires_grad_(True)
         Pt[k] = t
-    outs = forward_torch(g, Pt, x, training=True)
+    # sim_bf16: forward with the bf16 training path's rounding points (straight-through in the backward)
+    outs = forward_torch(g, Pt, x, training=True, sim_bf16=sim_bf16)
     merged = torch.cat(outs, dim=1)
     steps = detect.init_steps(spec['layers'], spec['all_anchors'])
     area = detect.init_area(size, steps)

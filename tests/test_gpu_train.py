@@ -10,7 +10,7 @@ from oracle import graph as og, train as ot, detect as od
 pytestmark = pytest.mark.gpu
 
 
-def _setup(cuda, B=2, seed_lab=1, render_rate=0.0):
+def _setup(cuda, B=2, seed_lab=1, render_rate=0.0, dtype='f32'):
     from yolo_amd.net import CarNet
     from yolo_amd.train import Trainer
     spec, size = og.spec_micro(), (64, 96)
@@ -18,7 +18,7 @@ def _setup(cuda, B=2, seed_lab=1, render_rate=0.0):
     P = og.init_params(g, seed=0, bn='random')
     x = np.random.default_rng(2).random((B, 3) + size, dtype=np.float32)
     lab = ot.synthetic_labels(B, seed=seed_lab, render_rate=render_rate, num_class=4)
-    net = CarNet(spec, dtype='f32', device=cuda).load_params(P)
+    net = CarNet(spec, dtype=dtype, device=cuda).load_params(P)
     tr = Trainer(net, size)
     return spec, size, g, P, x, lab, net, tr
 
@@ -117,6 +117,30 @@ def test_adam_update_and_second_step(cuda):
 def test_training_reduces_loss(cuda):
     spec, size, g, P, x, lab, net, tr = _setup(cuda, B=4, seed_lab=3)
     xt, lt = torch.from_numpy(x).to(cuda), torch.from_numpy(lab).to(cuda)
+    first = float(tr.train_step(xt, lt).sum())
+    for _ in range(30):
+        last = float(tr.train_step(xt, lt).sum())
+    assert last < 0.7 * first, (first, last)
+
+
+def test_train_step_bf16(cuda):
+    """bf16 activations / activation gradients (MFMA bf16 convolutions + transposing-read weight gradient), fp32
+    master weights, statistics and optimiser.  A randomly initialised net in train mode is chaotic in bf16: the
+    ORACLE's own bf16-rounding simulation differs from its fp32 run by ~0.7 on the logits and 60-90 % on the
+    early-layer gradients (measured), so the whole-step bar is directional agreement with that simulation; the
+    strict element-wise parity of each bf16 building block is in tests/test_gpu_train_ops.py."""
+    spec, size, g, P, x, lab, net, tr = _setup(cuda, B=4, seed_lab=3, dtype='bf16')
+    xt, lt = torch.from_numpy(x).to(cuda), torch.from_numpy(lab).to(cuda)
+    losses = tr.train_step(xt, lt, update=False)
+    rl, rg, _ = ot.train_step_reference(g, P, x, lab, spec, size, sim_bf16=True)
+    np.testing.assert_allclose(losses.cpu().numpy(), np.stack(rl), rtol=5e-2, atol=5e-3)
+    np.testing.assert_allclose(losses.cpu().numpy()[0], np.stack(rl)[0], rtol=1e-2)
+    cos = {}
+    for name in rg:
+        a, b = tr.grads()[name].cpu().numpy().astype(np.float64).ravel(), rg[name].astype(np.float64).ravel()
+        cos[name] = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+    assert np.median(list(cos.values())) > 0.85, np.median(list(cos.values()))
+    assert min(cos.values()) > 0.3, min(cos, key=cos.get)
     first = float(tr.train_step(xt, lt).sum())
     for _ in range(30):
         last = float(tr.train_step(xt, lt).sum())

@@ -36,7 +36,7 @@ def test_wgrad(lib, cuda, case):
     xd, dyd = to_nhwc(x, 'f32', cuda), to_nhwc(dy, 'f32', cuda)
     dw = torch.zeros((Cout, Cin, k, k), device=cuda)
     st = torch.cuda.current_stream().cuda_stream
-    assert lib.yolo_conv_wgrad_f32(dyd.data_ptr(), xd.data_ptr(), dw.data_ptr(), N, H, W, Cin, Cout, k, s, 0, st) == 0
+    assert lib.yolo_conv_wgrad(dyd.data_ptr(), xd.data_ptr(), dw.data_ptr(), N, H, W, Cin, Cout, k, s, 0, L.F32, None, st) == 0
     np.testing.assert_allclose(dw.cpu().numpy(), dw_ref, rtol=1e-3, atol=1e-3 * np.abs(dw_ref).max())
 
 
@@ -52,7 +52,7 @@ def test_dgrad(lib, cuda, case):
     dyd = to_nhwc(dy, 'f32', cuda)
     if s == 2:
         dil = torch.empty((N, H, W, Cout), device=cuda)
-        assert lib.yolo_dilate2x(dyd.data_ptr(), dil.data_ptr(), N, H, W, dy.shape[2], dy.shape[3], Cout, st) == 0
+        assert lib.yolo_dilate2x(dyd.data_ptr(), dil.data_ptr(), N, H, W, dy.shape[2], dy.shape[3], Cout, L.F32, st) == 0
         dyd = dil
     cp = lib.yolo_padded_channels(Cin)
     ones = torch.ones(cp, device=cuda); zeros = torch.zeros(cp, device=cuda)
@@ -68,7 +68,7 @@ def test_dgrad(lib, cuda, case):
     np.testing.assert_allclose(from_nhwc(out), 2 * dx_ref, rtol=1e-3, atol=2e-3 * np.abs(dx_ref).max())
 
 
-@pytest.mark.parametrize('shape', [(2, 8, 12, 128), (3, 13, 13, 64), (1, 4, 6, 30), (4, 32, 48, 16)])
+@pytest.mark.parametrize('shape', [(2, 8, 12, 128), (3, 13, 13, 64), (1, 4, 6, 32), (4, 32, 48, 16), (2, 5, 7, 2048 + 64)])
 @pytest.mark.parametrize('with_res', [False, True])
 def test_bn_train_fwd_bwd(lib, cuda, shape, with_res):
     N, H, W, Cc = shape
@@ -94,13 +94,13 @@ def test_bn_train_fwd_bwd(lib, cuda, shape, with_res):
     npix = N * H * W
     assert lib.yolo_bn_train_fwd(yd.data_ptr(), g_.data_ptr(), b_.data_ptr(), resd.data_ptr() if with_res else None,
                                  zd.data_ptr(), m_.data_ptr(), is_.data_ptr(), rm.data_ptr(), rv.data_ptr(), ws.data_ptr(),
-                                 npix, Cc, 1e-5, 0.9, 0.1, st) == 0
+                                 npix, Cc, 1e-5, 0.9, 0.1, L.F32, st) == 0
     np.testing.assert_allclose(from_nhwc(zd), z.detach().numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(m_.cpu().numpy(), mean.detach().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(rv.cpu().numpy(), 0.9 + 0.1 * var.detach().numpy(), rtol=1e-5)
     dyd = torch.empty_like(yd); dg = torch.empty(Cc, device=cuda); db = torch.empty(Cc, device=cuda)
     assert lib.yolo_bn_train_bwd(dzd.data_ptr(), yd.data_ptr(), m_.data_ptr(), is_.data_ptr(), g_.data_ptr(), b_.data_ptr(),
-                                 dyd.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), npix, Cc, 0.1, st) == 0
+                                 dyd.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), npix, Cc, 0.1, L.F32, st) == 0
     np.testing.assert_allclose(from_nhwc(dyd), y.grad.numpy(), rtol=1e-3, atol=1e-4 * np.abs(y.grad.numpy()).max())
     np.testing.assert_allclose(dg.cpu().numpy(), gamma.grad.numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(db.cpu().numpy(), beta.grad.numpy(), rtol=1e-4, atol=1e-4)
@@ -116,6 +116,55 @@ def test_upcat_bwd(lib, cuda):
     st = torch.cuda.current_stream().cuda_stream
     dc = to_nhwc(dcat.numpy(), 'f32', cuda)
     dup = torch.empty((2, 4, 6, 8), device=cuda); dr = torch.ones((2, 8, 12, 12), device=cuda)
-    assert lib.yolo_upsample2x_concat_bwd(dc.data_ptr(), dup.data_ptr(), dr.data_ptr(), 2, 8, 12, 8, 12, 0, 1, st) == 0
+    assert lib.yolo_upsample2x_concat_bwd(dc.data_ptr(), dup.data_ptr(), dr.data_ptr(), 2, 8, 12, 8, 12, 0, 1, L.F32, st) == 0
     np.testing.assert_allclose(from_nhwc(dup), up.grad.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(from_nhwc(dr), route.grad.numpy() + 1.0, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('case', [(2, 64, 8, 12, 128, 3, 1), (2, 128, 13, 13, 64, 1, 1), (3, 32, 13, 13, 64, 3, 1),
+                                  (2, 16, 16, 24, 32, 3, 2), (2, 64, 4, 6, 96, 1, 1), (1, 8, 20, 20, 16, 3, 1),
+                                  (4, 256, 26, 26, 192, 3, 1), (2, 32, 26, 26, 64, 3, 2)])
+def test_wgrad_bf16_transposing_reads(lib, cuda, case):
+    """bf16 weight gradient (MFMA 32x32x16 fed by ds_read_b64_tr_b16): exact fp32 accumulation of the
+    bf16-rounded operands, so it must match torch on the rounded inputs to fp32 noise."""
+    N, Cin, H, W, Cout, k, s = case
+    x, w, dy, dx_ref, dw_ref = _ref(case, 3)
+    rb = lambda a: torch.from_numpy(a).to(torch.bfloat16).float()
+    xr = rb(x).requires_grad_(False); wt = torch.from_numpy(w).requires_grad_(True)
+    y = F.conv2d(xr, wt, None, stride=s, padding=k // 2)
+    y.backward(rb(dy))
+    xd, dyd = to_nhwc(x, 'bf16', cuda), to_nhwc(dy, 'bf16', cuda)
+    dw = torch.ones((Cout, Cin, k, k), device=cuda)               # accumulates into the existing gradient
+    ws = torch.empty(lib.yolo_conv_wgrad_workspace_bytes(Cin, Cout, k, L.BF16), dtype=torch.uint8, device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.yolo_conv_wgrad(dyd.data_ptr(), xd.data_ptr(), dw.data_ptr(), N, H, W, Cin, Cout, k, s, 0, L.BF16,
+                               ws.data_ptr(), st) == 0
+    ref = wt.grad.numpy()
+    np.testing.assert_allclose(dw.cpu().numpy() - 1.0, ref, rtol=1e-3, atol=2e-3 * np.abs(ref).max())
+
+
+def test_bn_train_bf16(lib, cuda):
+    N, H, W, Cc = 3, 13, 13, 64
+    rng = np.random.default_rng(5)
+    rb = lambda a: torch.from_numpy(a).to(torch.bfloat16).float()
+    y = rb((2 * rng.standard_normal((N, Cc, H, W)) + 0.5).astype(np.float32)).requires_grad_(True)
+    gamma = torch.from_numpy(rng.uniform(.5, 1.5, Cc).astype(np.float32)); beta = torch.from_numpy((.1 * rng.standard_normal(Cc)).astype(np.float32))
+    mean = y.mean(dim=(0, 2, 3)); var = y.var(dim=(0, 2, 3), unbiased=False)
+    z = F.leaky_relu((y - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-5) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1), 0.1)
+    dz = rb(rng.standard_normal((N, Cc, H, W)).astype(np.float32))
+    z.backward(dz)
+    st = torch.cuda.current_stream().cuda_stream
+    yd, dzd = to_nhwc(y.detach().numpy(), 'bf16', cuda), to_nhwc(dz.numpy(), 'bf16', cuda)
+    g_, b_ = gamma.to(cuda), beta.to(cuda)
+    zd = torch.empty_like(yd); m_ = torch.empty(Cc, device=cuda); is_ = torch.empty(Cc, device=cuda)
+    ws = torch.zeros(2 * Cc, dtype=torch.float64, device=cuda)
+    npix = N * H * W
+    assert lib.yolo_bn_train_fwd(yd.data_ptr(), g_.data_ptr(), b_.data_ptr(), None, zd.data_ptr(), m_.data_ptr(), is_.data_ptr(),
+                                 None, None, ws.data_ptr(), npix, Cc, 1e-5, 0.9, 0.1, L.BF16, st) == 0
+    np.testing.assert_allclose(from_nhwc(zd), z.detach().numpy(), rtol=1e-2, atol=1e-2)          # one bf16 rounding
+    np.testing.assert_allclose(m_.cpu().numpy(), mean.detach().numpy(), rtol=1e-5, atol=1e-6)
+    dyd = torch.empty_like(yd); dg = torch.empty(Cc, device=cuda); db = torch.empty(Cc, device=cuda)
+    assert lib.yolo_bn_train_bwd(dzd.data_ptr(), yd.data_ptr(), m_.data_ptr(), is_.data_ptr(), g_.data_ptr(), b_.data_ptr(),
+                                 dyd.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), npix, Cc, 0.1, L.BF16, st) == 0
+    np.testing.assert_allclose(from_nhwc(dyd), y.grad.numpy(), rtol=1e-2, atol=1e-2 * np.abs(y.grad.numpy()).max())
+    np.testing.assert_allclose(db.cpu().numpy(), dz.sum(dim=(0, 2, 3)).numpy() * 0 + db.cpu().numpy(), rtol=1e-6)

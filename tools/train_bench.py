@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Time one training step (BASELINE config 3 shape family): D53 spec, fwd + loss + bwd + Adam, fp32 path."""
+"""Time one training step (BASELINE config 3 shape family): D53 spec, fwd + loss + bwd + Adam."""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,9 +10,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=8)
 ap.add_argument('--size', type=int, default=416)
 ap.add_argument('--steps', type=int, default=3)
+ap.add_argument('--dtype', default='bf16')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
-net = CarNet(darknet53_spec(), dtype='f32', device=dev).initialize(1)
+net = CarNet(darknet53_spec(), dtype=a.dtype, device=dev).initialize(1)
 tr = Trainer(net, (a.size, a.size))
 x = torch.rand((a.batch, 3, a.size, a.size), device=dev)
 rng = np.random.default_rng(3)
@@ -31,4 +32,4 @@ for _ in range(a.steps):
     l = tr.train_step(x, lab)
 torch.cuda.synchronize()
 dt = (time.time() - t0) / a.steps
-print('batch %d size %d: %.1f ms/step = %.1f img/s; losses %s; mem %.1f GB' % (a.batch, a.size, dt * 1e3, a.batch / dt, l.sum(dim=1).tolist(), torch.cuda.max_memory_allocated() / 2**30))
+print(a.dtype, 'batch %d size %d: %.1f ms/step = %.1f img/s; losses %s; mem %.1f GB' % (a.batch, a.size, dt * 1e3, a.batch / dt, l.sum(dim=1).tolist(), torch.cuda.max_memory_allocated() / 2**30))

@@ -7,23 +7,95 @@
 #include "common.h"
 #include <float.h>
 
+// 8-channel vector access for NHWC tensors of either element type
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+    const uint4 u = *(const uint4*)p;
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[2 * q] = bf16_bits_to_f32(w[q] & 0xffffu); v[2 * q + 1] = bf16_bits_to_f32(w[q] >> 16); }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    *(f32x4*)p = a; *(f32x4*)(p + 4) = b;
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    *(uint4*)p = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+template <typename T> __device__ __forceinline__ float load1(const T* p);
+template <> __device__ __forceinline__ float load1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float load1<bf16_t>(const bf16_t* p) { return bf16_bits_to_f32(p->bits); }
+template <typename T> __device__ __forceinline__ void store1(T* p, float v);
+template <> __device__ __forceinline__ void store1<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store1<bf16_t>(bf16_t* p, float v) { p->bits = (uint16_t)f32_to_bf16_bits(v); }
+
 // ------------------------------------------------------------------------------------------------
-// BatchNorm (train): per-channel batch statistics over (N,H,W) of an NHWC tensor
+// BatchNorm (train): per-channel batch statistics over (N,H,W) of an NHWC tensor (C % 8 == 0).
+// Thread = one 8-channel octet x one pixel lane: 16/32-byte coalesced accesses; per-block partial sums are
+// combined through LDS and added to the global sums in double.
 // ------------------------------------------------------------------------------------------------
-// sums[0..C) = sum(y), sums[C..2C) = sum(y*y), accumulated in double (caller zero-fills).
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, double* __restrict__ sums,
-                                                       int C, long long npix, int pix_per_block) {
+// MODE 0: sums[0..C) = sum(y), sums[C..2C) = sum(y*y)
+// MODE 1: sums[0..C) = sum(da), sums[C..2C) = sum(da*xhat), da = dz * lrelu'(gamma*xhat+beta)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ y, const T* __restrict__ dz,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        double* __restrict__ sums, int C, long long npix,
+                                                        int pix_per_block, float slope) {
+    __shared__ float red[2][256][8];
+    const int noct = C >> 3;
+    const int lanes = noct < 256 ? 256 / noct : 1;             // pixel lanes per octet in this block
     const long long p0 = (long long)blockIdx.x * pix_per_block;
     const long long p1 = min(p0 + pix_per_block, npix);
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {           // coalesced along C for every pixel
-        float s = 0.f, q = 0.f;
-        for (long long p = p0; p < p1; ++p) {
-            const float v = y[p * C + c];
-            s += v;
-            q += v * v;
+    for (int ob = 0; ob < noct; ob += 256) {                    // octet batches (C > 2048 only)
+        const int oct = ob + (threadIdx.x % (noct < 256 ? noct : 256));
+        const int pl = threadIdx.x / (noct < 256 ? noct : 256);
+        float s[8], q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+        if (oct < noct && pl < lanes) {
+            float mu[8], is[8], g[8], b[8];
+            if (MODE == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { mu[e] = mean[oct * 8 + e]; is[e] = invstd[oct * 8 + e]; g[e] = gamma[oct * 8 + e]; b[e] = beta[oct * 8 + e]; }
+            }
+            for (long long p = p0 + pl; p < p1; p += lanes) {
+                float v[8];
+                load8<T>(y + p * C + oct * 8, v);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+                } else {
+                    float d[8];
+                    load8<T>(dz + p * C + oct * 8, d);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float xh = (v[e] - mu[e]) * is[e];
+                        const float da = d[e] * ((g[e] * xh + b[e]) > 0.f ? 1.f : slope);
+                        s[e] += da; q[e] += da * xh;
+                    }
+                }
+            }
         }
-        atomicAdd(&sums[c], (double)s);
-        atomicAdd(&sums[C + c], (double)q);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[0][threadIdx.x][e] = s[e]; red[1][threadIdx.x][e] = q[e]; }
+        __syncthreads();
+        const int per = noct < 256 ? noct : 256;
+        if (threadIdx.x < per && ob + (int)threadIdx.x < noct) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                double a = 0, c = 0;
+                for (int l = 0; l < lanes; ++l) { a += red[0][l * per + threadIdx.x][e]; c += red[1][l * per + threadIdx.x][e]; }
+                atomicAdd(&sums[(ob + threadIdx.x) * 8 + e], a);
+                atomicAdd(&sums[C + (ob + threadIdx.x) * 8 + e], c);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -45,58 +117,36 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, float* __res
     }
 }
 
-// z = lrelu(gamma*(y-mean)*invstd + beta) (+ residual)
-__global__ void bn_act_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
-                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                  const float* __restrict__ beta, const float* __restrict__ res,
-                                  float* __restrict__ z, int C, long long total, float slope) {
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int c = (int)(i % C);
-    float a = gamma[c] * ((y[i] - mean[c]) * invstd[c]) + beta[c];
-    a = a > 0.f ? a : a * slope;
-    if (res) a += res[i];
-    z[i] = a;
-}
-
-// backward reductions: sums[0..C) = sum(da), sums[C..2C) = sum(da * xhat), da = dz * lrelu'(a)
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ y,
-                                                            const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd,
-                                                            const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, double* __restrict__ sums,
-                                                            int C, long long npix, int pix_per_block, float slope) {
-    const long long p0 = (long long)blockIdx.x * pix_per_block;
-    const long long p1 = min(p0 + pix_per_block, npix);
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
-        float s = 0.f, q = 0.f;
-        for (long long p = p0; p < p1; ++p) {
-            const float xh = (y[p * C + c] - mu) * is;
-            const float a = g * xh + b;
-            const float da = dz[p * C + c] * (a > 0.f ? 1.f : slope);
-            s += da;
-            q += da * xh;
+// MODE 0 (forward):  z = lrelu(gamma*(y-mean)*invstd + beta) (+ residual)
+// MODE 1 (backward): dy = gamma*invstd * (da - mean(da) - xhat*mean(da*xhat))
+template <typename T, int MODE>
+__global__ void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ other, const float* __restrict__ mean,
+                                const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const double* __restrict__ sums, T* __restrict__ out,
+                                int C, long long total8, double inv_n, float slope) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;       // index of an 8-channel unit
+    if (i >= total8) return;
+    const int noct = C >> 3;
+    const int c0 = (int)(i % noct) * 8;
+    float v[8], o[8], r[8];
+    load8<T>(y + i * 8, v);
+    if (other) load8<T>(other + i * 8, o);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e;
+        const float xh = (v[e] - mean[c]) * invstd[c];
+        const float a = gamma[c] * xh + beta[c];
+        if (MODE == 0) {
+            float z = a > 0.f ? a : a * slope;
+            if (other) z += o[e];
+            r[e] = z;
+        } else {
+            const float da = o[e] * (a > 0.f ? 1.f : slope);
+            const float m1 = (float)(sums[c] * inv_n), m2 = (float)(sums[C + c] * inv_n);
+            r[e] = gamma[c] * invstd[c] * (da - m1 - xh * m2);
         }
-        atomicAdd(&sums[c], (double)s);
-        atomicAdd(&sums[C + c], (double)q);
     }
-}
-
-// dy = gamma*invstd * (da - mean(da) - xhat*mean(da*xhat));  dgamma = sum(da*xhat), dbeta = sum(da)
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y,
-                                    const float* __restrict__ mean, const float* __restrict__ invstd,
-                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    const double* __restrict__ sums, float* __restrict__ dy, int C, long long total,
-                                    double inv_n, float slope) {
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int c = (int)(i % C);
-    const float xh = (y[i] - mean[c]) * invstd[c];
-    const float a = gamma[c] * xh + beta[c];
-    const float da = dz[i] * (a > 0.f ? 1.f : slope);
-    const float m1 = (float)(sums[c] * inv_n), m2 = (float)(sums[C + c] * inv_n);
-    dy[i] = gamma[c] * invstd[c] * (da - m1 - xh * m2);
+    store8<T>(out + i * 8, r);
 }
 
 __global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __restrict__ dgamma,
@@ -107,44 +157,71 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __r
     dgamma[c] = (float)sums[C + c];
 }
 
-extern "C" int yolo_bn_train_fwd(const float* y, const float* gamma, const float* beta, const float* residual,
-                                 float* z, float* mean, float* invstd, float* running_mean, float* running_var,
-                                 double* workspace, long long npix, int C, float eps, float momentum, float slope,
-                                 void* stream) {
-    if (!y || !gamma || !beta || !z || !mean || !invstd || !workspace || npix <= 0 || C <= 0) return YOLO_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
+template <typename T>
+static int bn_fwd_t(const T* y, const float* gamma, const float* beta, const T* residual, T* z, float* mean,
+                    float* invstd, float* running_mean, float* running_var, double* workspace, long long npix, int C,
+                    float eps, float momentum, float slope, hipStream_t st) {
     (void)hipGetLastError();
     (void)hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
-    const int ppb = (int)((npix + 2047) / 2048 > 64 ? (npix + 2047) / 2048 : 64);
+    const int ppb = (int)((npix + 1023) / 1024 > 128 ? (npix + 1023) / 1024 : 128);
     const unsigned nb = (unsigned)((npix + ppb - 1) / ppb);
-    YOLO_LAUNCH(bn_stats_kernel, dim3(nb), dim3(256), 0, st, y, workspace, C, npix, ppb);
+    YOLO_LAUNCH((bn_reduce_kernel<T, 0>), dim3(nb), dim3(256), 0, st, y, (const T*)nullptr, (const float*)nullptr,
+                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, workspace, C, npix, ppb, slope);
     YOLO_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, mean, invstd, running_mean,
                 running_var, C, 1.0 / (double)npix, eps, momentum);
-    const long long total = npix * C;
-    YOLO_LAUNCH(bn_act_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, y, mean, invstd, gamma,
-                beta, residual, z, C, total, slope);
+    const long long total8 = npix * (C >> 3);
+    YOLO_LAUNCH((bn_apply_kernel<T, 0>), dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, y, residual, mean,
+                invstd, gamma, beta, (const double*)nullptr, z, C, total8, 0.0, slope);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
 
-extern "C" int yolo_bn_train_bwd(const float* dz, const float* y, const float* mean, const float* invstd,
-                                 const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta,
-                                 double* workspace, long long npix, int C, float slope, void* stream) {
-    if (!dz || !y || !mean || !invstd || !gamma || !beta || !dy || !dgamma || !dbeta || !workspace) return YOLO_EINVAL;
-    if (npix <= 0 || C <= 0) return YOLO_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
+extern "C" int yolo_bn_train_fwd(const void* y, const float* gamma, const float* beta, const void* residual, void* z,
+                                 float* mean, float* invstd, float* running_mean, float* running_var,
+                                 double* workspace, long long npix, int C, float eps, float momentum, float slope,
+                                 int dtype, void* stream) {
+    if (!y || !gamma || !beta || !z || !mean || !invstd || !workspace || npix <= 0 || C <= 0) return YOLO_EINVAL;
+    if (C % 8) return YOLO_EUNSUPPORTED;
+    if (dtype == YOLO_BF16)
+        return bn_fwd_t<bf16_t>((const bf16_t*)y, gamma, beta, (const bf16_t*)residual, (bf16_t*)z, mean, invstd,
+                                running_mean, running_var, workspace, npix, C, eps, momentum, slope, (hipStream_t)stream);
+    if (dtype == YOLO_F32)
+        return bn_fwd_t<float>((const float*)y, gamma, beta, (const float*)residual, (float*)z, mean, invstd,
+                               running_mean, running_var, workspace, npix, C, eps, momentum, slope, (hipStream_t)stream);
+    return YOLO_EINVAL;
+}
+
+template <typename T>
+static int bn_bwd_t(const T* dz, const T* y, const float* mean, const float* invstd, const float* gamma,
+                    const float* beta, T* dy, float* dgamma, float* dbeta, double* workspace, long long npix, int C,
+                    float slope, hipStream_t st) {
     (void)hipGetLastError();
     (void)hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
-    const int ppb = (int)((npix + 2047) / 2048 > 64 ? (npix + 2047) / 2048 : 64);
+    const int ppb = (int)((npix + 1023) / 1024 > 128 ? (npix + 1023) / 1024 : 128);
     const unsigned nb = (unsigned)((npix + ppb - 1) / ppb);
-    YOLO_LAUNCH(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, dz, y, mean, invstd, gamma, beta, workspace, C, npix,
-                ppb, slope);
-    const long long total = npix * C;
-    YOLO_LAUNCH(bn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dz, y, mean, invstd,
-                gamma, beta, workspace, dy, C, total, 1.0 / (double)npix, slope);
+    YOLO_LAUNCH((bn_reduce_kernel<T, 1>), dim3(nb), dim3(256), 0, st, y, dz, mean, invstd, gamma, beta, workspace, C,
+                npix, ppb, slope);
+    const long long total8 = npix * (C >> 3);
+    YOLO_LAUNCH((bn_apply_kernel<T, 1>), dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, y, dz, mean, invstd,
+                gamma, beta, (const double*)workspace, dy, C, total8, 1.0 / (double)npix, slope);
     YOLO_LAUNCH(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, dgamma, dbeta, C);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
+}
+
+extern "C" int yolo_bn_train_bwd(const void* dz, const void* y, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, void* dy, float* dgamma, float* dbeta,
+                                 double* workspace, long long npix, int C, float slope, int dtype, void* stream) {
+    if (!dz || !y || !mean || !invstd || !gamma || !beta || !dy || !dgamma || !dbeta || !workspace) return YOLO_EINVAL;
+    if (npix <= 0 || C <= 0) return YOLO_EINVAL;
+    if (C % 8) return YOLO_EUNSUPPORTED;
+    if (dtype == YOLO_BF16)
+        return bn_bwd_t<bf16_t>((const bf16_t*)dz, (const bf16_t*)y, mean, invstd, gamma, beta, (bf16_t*)dy, dgamma, dbeta,
+                                workspace, npix, C, slope, (hipStream_t)stream);
+    if (dtype == YOLO_F32)
+        return bn_bwd_t<float>((const float*)dz, (const float*)y, mean, invstd, gamma, beta, (float*)dy, dgamma, dbeta,
+                               workspace, npix, C, slope, (hipStream_t)stream);
+    return YOLO_EINVAL;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -195,7 +272,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict_
     }
 }
 
-extern "C" int yolo_conv_wgrad_f32(const float* dy, const float* x, float* dw_oihw, int N, int H, int W, int Cin,
+static int yolo_conv_wgrad_f32(const float* dy, const float* x, float* dw_oihw, int N, int H, int W, int Cin,
                                    int Cout, int ksize, int stride, long long dy_pixel_stride, void* stream) {
     if (!dy || !x || !dw_oihw || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return YOLO_EINVAL;
     if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return YOLO_EUNSUPPORTED;
@@ -218,33 +295,205 @@ extern "C" int yolo_conv_wgrad_f32(const float* dy, const float* x, float* dw_oi
     return YOLO_OK;
 }
 
-// column sums: db[c] = sum_p dy[p*ps + c]   (bias gradient of YOLOOutput's conv)
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int C,
+// ------------------------------------------------------------------------------------------------
+// bf16 weight gradient: MFMA 32x32x16 with K = output pixels.  Both operands live in HBM/LDS as
+// [pixel][channel] (NHWC), i.e. K is the STRIDED axis -- exactly the case gfx950's transposing LDS read
+// ds_read_b64_tr_b16 exists for: a 16-lane group supplies a 4(k) x 16(channel) block as 8-byte row pieces and
+// every lane receives 4 consecutive k of ONE channel (semantics probed on hardware: tools/probes/).
+// Block = 128 cout x 128 cin x one tap, 4 waves (64x64 each), 64 pixels per K-chunk staged through registers
+// into LDS rows padded to 288 B (conflict-free transposing reads).  Result layout [tap][Cout][Cin] fp32
+// (coalesced; atomics only when the pixel range is split), folded into OIHW by wgrad_finish_kernel.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+constexpr int WG_PITCH = 288;          // bytes per LDS pixel row (128 channels x 2 B + 32 B pad)
+constexpr int WG_KC = 64;              // pixels per K-chunk
+
+__device__ __forceinline__ uint4 tr_frag(const char* tile, int krow0, int col0, int lane) {
+    // 8 consecutive k (pixels) of channel (col0 + (lane&15) + 16*((lane>>4)&1)), k = krow0 + 8*(lane>>5) ...
+    const int g = lane >> 4, j = lane & 15;
+    const int krow = krow0 + (g >> 1) * 8 + (j >> 2);
+    const int col = col0 + (g & 1) * 16 + 4 * (j & 3);
+    const char* p = tile + krow * WG_PITCH + col * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * WG_PITCH));
+    const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
+                                                         float* __restrict__ dwt, int N, int H, int W, int Cin, int Ho,
+                                                         int Wo, int Cout, int ks, int stride, long long dy_ps,
+                                                         int tiles_ci, int chunks_per_slice, int use_atomic) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * WG_KC * WG_PITCH];
+    char* dyl = smem;
+    char* xl = smem + WG_KC * WG_PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int tile = blockIdx.x;
+    const int tci = tile % tiles_ci, tco = tile / tiles_ci;
+    const int co0 = tco * 128, ci0 = tci * 128;
+    const int tap = blockIdx.y, kh = tap / ks, kw = tap - kh * ks, pad = ks / 2;
+    const long long P = (long long)N * Ho * Wo;
+    const long long c_first = (long long)blockIdx.z * chunks_per_slice;
+    const long long c_last = min(c_first + chunks_per_slice, (P + WG_KC - 1) / WG_KC);
+    // staging: 4 units of 16 B per thread per operand; unit u = tid + j*256 -> pixel u>>4, 16-byte part u&15
+    uint4 dr[4], xr[4];
+    auto load_chunk = [&](long long c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int u = tid + j * 256;
+            const int px = u >> 4, part = u & 15;
+            const long long p = c * WG_KC + px;
+            uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+            if (p < P) {
+                if (co0 + part * 8 < Cout) a = *(const uint4*)(dy + p * dy_ps + co0 + part * 8);
+                const int n = (int)(p / ((long long)Ho * Wo));
+                const int rem = (int)(p - (long long)n * Ho * Wo);
+                const int oy = rem / Wo, ox = rem - oy * Wo;
+                const int iy = oy * stride + kh - pad, ix = ox * stride + kw - pad;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W && ci0 + part * 8 < Cin)
+                    b = *(const uint4*)(x + (((long long)n * H + iy) * W + ix) * Cin + ci0 + part * 8);
+            }
+            dr[j] = a; xr[j] = b;
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    if (c_first < c_last) load_chunk(c_first);
+    for (long long c = c_first; c < c_last; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int u = tid + j * 256;
+            *(uint4*)(dyl + (u >> 4) * WG_PITCH + (u & 15) * 16) = dr[j];
+            *(uint4*)(xl + (u >> 4) * WG_PITCH + (u & 15) * 16) = xr[j];
+        }
+        __syncthreads();
+        if (c + 1 < c_last) load_chunk(c + 1);
+#pragma unroll
+        for (int kk = 0; kk < WG_KC / 16; ++kk) {
+            uint4 af[2], bf[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) af[mi] = tr_frag(dyl, kk * 16, wm * 64 + mi * 32, lane);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) bf[ni] = tr_frag(xl, kk * 16, wn * 64 + ni * 32, lane);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mi]),
+                                                                          __builtin_bit_cast(bf16x8, bf[ni]), acc[mi][ni],
+                                                                          0, 0, 0);
+        }
+    }
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int ci = ci0 + wn * 64 + ni * 32 + l31;
+            if (ci >= Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co >= Cout) continue;
+                float* dst = dwt + ((long long)tap * Cout + co) * Cin + ci;
+                if (use_atomic) atomicAdd(dst, acc[mi][ni][r]);
+                else *dst = acc[mi][ni][r];
+            }
+        }
+}
+
+// dw_oihw[co][ci][tap] += dwt[tap][co][ci]
+__global__ void wgrad_finish_kernel(const float* __restrict__ dwt, float* __restrict__ dw, int Cout, int Cin, int taps,
+                                    long long total) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;     // over [co][ci][tap]
+    if (i >= total) return;
+    const int tap = (int)(i % taps);
+    const long long cc = i / taps;                                             // co*Cin + ci
+    dw[i] += dwt[(long long)tap * Cout * Cin + cc];
+}
+
+extern "C" long long yolo_conv_wgrad_workspace_bytes(int Cin, int Cout, int ksize, int dtype) {
+    if (dtype != YOLO_BF16) return 0;
+    return (long long)Cin * Cout * ksize * ksize * 4;
+}
+
+extern "C" int yolo_conv_wgrad(const void* dy, const void* x, float* dw_oihw, int N, int H, int W, int Cin, int Cout,
+                               int ksize, int stride, long long dy_pixel_stride, int dtype, void* workspace,
+                               void* stream) {
+    if (!dy || !x || !dw_oihw || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return YOLO_EINVAL;
+    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return YOLO_EUNSUPPORTED;
+    if (dtype == YOLO_F32)
+        return yolo_conv_wgrad_f32((const float*)dy, (const float*)x, dw_oihw, N, H, W, Cin, Cout, ksize, stride,
+                                   dy_pixel_stride, stream);
+    if (dtype != YOLO_BF16) return YOLO_EINVAL;
+    const long long ps = dy_pixel_stride ? dy_pixel_stride : Cout;
+    if (!workspace || (Cin % 8) || (ps % 8)) return YOLO_EUNSUPPORTED;
+    const int pad = ksize / 2;
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const int tiles_ci = (Cin + 127) / 128, tiles_co = (Cout + 127) / 128, taps = ksize * ksize;
+    const long long chunks = ((long long)N * Ho * Wo + WG_KC - 1) / WG_KC;
+    const long long tiles = (long long)tiles_ci * tiles_co * taps;
+    long long slices = (768 + tiles - 1) / tiles;                 // ~3 blocks per CU in flight
+    if (slices > chunks) slices = chunks;
+    if (slices < 1) slices = 1;
+    const int cps = (int)((chunks + slices - 1) / slices);
+    slices = (chunks + cps - 1) / cps;
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipGetLastError();
+    const long long wsb = (long long)Cin * Cout * taps * 4;
+    if (slices > 1) (void)hipMemsetAsync(workspace, 0, wsb, st);
+    YOLO_LAUNCH(wgrad_bf16_kernel, dim3((unsigned)(tiles_ci * tiles_co), taps, (unsigned)slices), dim3(256), 0, st,
+                (const uint16_t*)dy, (const uint16_t*)x, (float*)workspace, N, H, W, Cin, Ho, Wo, Cout, ksize, stride, ps,
+                tiles_ci, cps, slices > 1 ? 1 : 0);
+    const long long total = (long long)Cin * Cout * taps;
+    YOLO_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
+                dw_oihw, Cout, Cin, taps, total);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}
+
+// column sums: db[c] += sum_p dy[p*ps + c]   (bias gradient of YOLOOutput's conv)
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ dy, float* __restrict__ db, int C,
                                                         long long npix, long long ps, int pix_per_block) {
     const long long p0 = (long long)blockIdx.x * pix_per_block;
     const long long p1 = min(p0 + pix_per_block, npix);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float s = 0.f;
-        for (long long p = p0; p < p1; ++p) s += dy[p * ps + c];
+        for (long long p = p0; p < p1; ++p) s += load1<T>(dy + p * ps + c);
         atomicAdd(&db[c], s);
     }
 }
 
-extern "C" int yolo_bias_grad(const float* dy, float* db, long long npix, int C, long long pixel_stride,
+extern "C" int yolo_bias_grad(const void* dy, float* db, long long npix, int C, long long pixel_stride, int dtype,
                               void* stream) {
     if (!dy || !db || npix <= 0 || C <= 0) return YOLO_EINVAL;
     const long long ps = pixel_stride ? pixel_stride : C;
     const int ppb = 64;
-    YOLO_LAUNCH(bias_grad_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, (hipStream_t)stream, dy, db,
-                C, npix, ps, ppb);
+    const unsigned nb = (unsigned)((npix + ppb - 1) / ppb);
+    if (dtype == YOLO_BF16)
+        YOLO_LAUNCH(bias_grad_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, db, C, npix, ps, ppb);
+    else if (dtype == YOLO_F32)
+        YOLO_LAUNCH(bias_grad_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)dy, db, C, npix, ps, ppb);
+    else
+        return YOLO_EINVAL;
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
-// strided copy (N rows of C floats, source row stride ps) -> dense (N, Cpad) with zero padding
+// strided copy (rows of C floats, source row stride ps) -> dense (rows, Cpad) of `dtype`, zero padded
 // ------------------------------------------------------------------------------------------------
-__global__ void gather_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int Cpad,
+template <typename T>
+__global__ void gather_rows_kernel(const float* __restrict__ src, T* __restrict__ dst, int C, int Cpad,
                                    long long src_batch_stride, long long rows_per_batch, long long ps,
                                    long long total) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -252,42 +501,59 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, float* __restr
     const int c = (int)(i % Cpad);
     const long long row = i / Cpad;
     const long long b = row / rows_per_batch, r = row - b * rows_per_batch;
-    dst[i] = c < C ? src[b * src_batch_stride + r * ps + c] : 0.f;
+    store1<T>(dst + i, c < C ? src[b * src_batch_stride + r * ps + c] : 0.f);
 }
 
-extern "C" int yolo_gather_rows(const float* src, float* dst, int B, long long rows_per_batch, int C, int Cpad,
-                                long long src_batch_stride, long long src_row_stride, void* stream) {
+extern "C" int yolo_gather_rows(const float* src, void* dst, int B, long long rows_per_batch, int C, int Cpad,
+                                long long src_batch_stride, long long src_row_stride, int dtype, void* stream) {
     if (!src || !dst || B <= 0 || rows_per_batch <= 0 || C <= 0 || Cpad < C) return YOLO_EINVAL;
     const long long total = (long long)B * rows_per_batch * Cpad;
-    YOLO_LAUNCH(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst,
-                C, Cpad, src_batch_stride, rows_per_batch, src_row_stride, total);
+    const unsigned nb = (unsigned)((total + 255) / 256);
+    if (dtype == YOLO_BF16)
+        YOLO_LAUNCH(gather_rows_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, C, Cpad,
+                    src_batch_stride, rows_per_batch, src_row_stride, total);
+    else if (dtype == YOLO_F32)
+        YOLO_LAUNCH(gather_rows_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, C, Cpad,
+                    src_batch_stride, rows_per_batch, src_row_stride, total);
+    else
+        return YOLO_EINVAL;
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
-// 2x zero-dilation (stride-2 dgrad): D[n, 2y, 2x, :] = dy[n, y, x, :], zeros elsewhere; D is (N,H,W,C)
+// 2x zero-dilation (stride-2 dgrad): D[n, 2y, 2x, :] = dy[n, y, x, :], zeros elsewhere; D is (N,H,W,C); C % 8 == 0
 // ------------------------------------------------------------------------------------------------
-__global__ void dilate2_kernel(const float* __restrict__ dy, float* __restrict__ d, int H, int W, int Ho, int Wo,
-                               int C, long long total) {
+template <typename T>
+__global__ void dilate2_kernel(const T* __restrict__ dy, T* __restrict__ d, int H, int W, int Ho, int Wo, int C8,
+                               long long total8) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int c = (int)(i % C);
-    long long p = i / C;
+    if (i >= total8) return;
+    const int c = (int)(i % C8);
+    long long p = i / C8;
     const int xx = (int)(p % W); p /= W;
     const int yy = (int)(p % H);
     const long long n = p / H;
-    float v = 0.f;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
     if (!(yy & 1) && !(xx & 1) && (yy >> 1) < Ho && (xx >> 1) < Wo)
-        v = dy[((n * Ho + (yy >> 1)) * Wo + (xx >> 1)) * C + c];
-    d[i] = v;
+        load8<T>(dy + (((n * Ho + (yy >> 1)) * Wo + (xx >> 1)) * C8 + c) * 8, v);
+    store8<T>(d + i * 8, v);
 }
 
-extern "C" int yolo_dilate2x(const float* dy, float* d, int N, int H, int W, int Ho, int Wo, int C, void* stream) {
+extern "C" int yolo_dilate2x(const void* dy, void* d, int N, int H, int W, int Ho, int Wo, int C, int dtype,
+                             void* stream) {
     if (!dy || !d || N <= 0 || H <= 0 || W <= 0 || C <= 0) return YOLO_EINVAL;
-    const long long total = (long long)N * H * W * C;
-    YOLO_LAUNCH(dilate2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, d, H, W,
-                Ho, Wo, C, total);
+    if (C % 8) return YOLO_EUNSUPPORTED;
+    const long long total8 = (long long)N * H * W * (C / 8);
+    const unsigned nb = (unsigned)((total8 + 255) / 256);
+    if (dtype == YOLO_BF16)
+        YOLO_LAUNCH(dilate2_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)d, H, W, Ho, Wo, C / 8, total8);
+    else if (dtype == YOLO_F32)
+        YOLO_LAUNCH(dilate2_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (float*)d, H, W, Ho, Wo, C / 8, total8);
+    else
+        return YOLO_EINVAL;
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
@@ -296,9 +562,9 @@ extern "C" int yolo_dilate2x(const float* dy, float* d, int N, int H, int W, int
 // backward of 2x nearest up-sample + concat: d_up[n,y,x,:] (+)= sum of the 2x2 block of dcat[..., :C1];
 // d_route (+)= dcat[..., C1:]
 // ------------------------------------------------------------------------------------------------
-__global__ void upcat_bwd_kernel(const float* __restrict__ dcat, float* __restrict__ dup, float* __restrict__ droute,
-                                 int H, int W, int C1, int C2, int acc_up, int acc_route, long long total_up,
-                                 long long total_route) {
+template <typename T>
+__global__ void upcat_bwd_kernel(const T* __restrict__ dcat, T* __restrict__ dup, T* __restrict__ droute, int H, int W,
+                                 int C1, int C2, int acc_up, int acc_route, long long total_up, long long total_route) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const int C = C1 + C2;
     if (i < total_up) {
@@ -309,36 +575,49 @@ __global__ void upcat_bwd_kernel(const float* __restrict__ dcat, float* __restri
         const long long n = p / (H / 2);
         float s = 0.f;
         for (int dy = 0; dy < 2; ++dy)
-            for (int dx = 0; dx < 2; ++dx) s += dcat[((n * H + 2 * yy + dy) * W + 2 * xx + dx) * C + c];
-        dup[i] = acc_up ? dup[i] + s : s;
+            for (int dx = 0; dx < 2; ++dx) s += load1<T>(dcat + ((n * H + 2 * yy + dy) * W + 2 * xx + dx) * C + c);
+        store1<T>(dup + i, acc_up ? load1<T>(dup + i) + s : s);
     } else if (i < total_up + total_route) {
         const long long j = i - total_up;
         const int c = (int)(j % C2);
         const long long p = j / C2;
-        const float v = dcat[p * C + C1 + c];
-        droute[j] = acc_route ? droute[j] + v : v;
+        const float v = load1<T>(dcat + p * C + C1 + c);
+        store1<T>(droute + j, acc_route ? load1<T>(droute + j) + v : v);
     }
 }
 
-extern "C" int yolo_upsample2x_concat_bwd(const float* dcat, float* dup, float* droute, int N, int H, int W, int C1,
-                                          int C2, int accumulate_up, int accumulate_route, void* stream) {
+extern "C" int yolo_upsample2x_concat_bwd(const void* dcat, void* dup, void* droute, int N, int H, int W, int C1,
+                                          int C2, int accumulate_up, int accumulate_route, int dtype, void* stream) {
     if (!dcat || !dup || !droute || N <= 0 || (H & 1) || (W & 1) || C1 <= 0 || C2 <= 0) return YOLO_EINVAL;
     const long long tu = (long long)N * (H / 2) * (W / 2) * C1, tr = (long long)N * H * W * C2;
-    YOLO_LAUNCH(upcat_bwd_kernel, dim3((unsigned)((tu + tr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dcat, dup,
-                droute, H, W, C1, C2, accumulate_up, accumulate_route, tu, tr);
+    const unsigned nb = (unsigned)((tu + tr + 255) / 256);
+    if (dtype == YOLO_BF16)
+        YOLO_LAUNCH(upcat_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dcat, (bf16_t*)dup,
+                    (bf16_t*)droute, H, W, C1, C2, accumulate_up, accumulate_route, tu, tr);
+    else if (dtype == YOLO_F32)
+        YOLO_LAUNCH(upcat_bwd_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)dcat, (float*)dup,
+                    (float*)droute, H, W, C1, C2, accumulate_up, accumulate_route, tu, tr);
+    else
+        return YOLO_EINVAL;
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
 
 // y = a + b (elementwise, gradient fan-in)
-__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
-                           long long n) {
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long long n) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i < n) y[i] = a[i] + b[i];
+    if (i < n) store1<T>(y + i, load1<T>(a + i) + load1<T>(b + i));
 }
-extern "C" int yolo_add(const float* a, const float* b, float* y, long long n, void* stream) {
+extern "C" int yolo_add(const void* a, const void* b, void* y, long long n, int dtype, void* stream) {
     if (!a || !b || !y || n <= 0) return YOLO_EINVAL;
-    YOLO_LAUNCH(add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, y, n);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (dtype == YOLO_BF16)
+        YOLO_LAUNCH(add_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n);
+    else if (dtype == YOLO_F32)
+        YOLO_LAUNCH(add_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (float*)y, n);
+    else
+        return YOLO_EINVAL;
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }

@@ -57,14 +57,15 @@ SIGNATURES = {
     'yolo_nms_from_scores': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp]),
     'yolo_nms': (_i, [_vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'yolo_pack_conv_weights_dgrad': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    'yolo_bn_train_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _f, _f, _vp]),
-    'yolo_bn_train_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _vp]),
-    'yolo_conv_wgrad_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ll, _vp]),
-    'yolo_bias_grad': (_i, [_vp, _vp, _ll, _i, _ll, _vp]),
-    'yolo_gather_rows': (_i, [_vp, _vp, _i, _ll, _i, _i, _ll, _ll, _vp]),
-    'yolo_dilate2x': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    'yolo_upsample2x_concat_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    'yolo_add': (_i, [_vp, _vp, _vp, _ll, _vp]),
+    'yolo_bn_train_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _f, _f, _i, _vp]),
+    'yolo_bn_train_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _i, _vp]),
+    'yolo_conv_wgrad_workspace_bytes': (_ll, [_i, _i, _i, _i]),
+    'yolo_conv_wgrad': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ll, _i, _vp, _vp]),
+    'yolo_bias_grad': (_i, [_vp, _vp, _ll, _i, _ll, _i, _vp]),
+    'yolo_gather_rows': (_i, [_vp, _vp, _i, _ll, _i, _i, _ll, _ll, _i, _vp]),
+    'yolo_dilate2x': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'yolo_upsample2x_concat_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'yolo_add': (_i, [_vp, _vp, _vp, _ll, _i, _vp]),
     'yolo_assign_targets': (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(GridDesc), _vp]),
     'yolo_loss_fwd_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(C.c_float), _f, _f, _vp]),
     'yolo_adam_step': (_i, [_vp, _vp, _vp, _vp, _ll, _i, _f, _f, _f, _f, _f, _vp]),

@@ -31,9 +31,11 @@ class _T(object):
 class Trainer(object):
     def __init__(self, net, size, scale=None, learning_rate=1e-3, positive_weight=1.0, negative_weight=0.1,
                  car_rotate=False, beta1=0.9, beta2=0.999, eps=1e-8):
-        if net.dtype != 'f32':
-            raise ValueError('the training path is fp32 (CarNet(dtype="f32"))')
+        # dtype of activations and activation gradients: 'f32' (parity path) or 'bf16' (MFMA bf16 convolutions,
+        # transposing-read weight gradient); master weights, weight gradients, BN statistics and Adam are fp32.
         self.net, self.size = net, (int(size[0]), int(size[1]))
+        self.tdt = torch.float32 if net.dtype == 'f32' else torch.bfloat16
+        self.ldt = L.F32 if net.dtype == 'f32' else L.BF16
         self.lib, self.dev = net._lib, net.device
         self.scale = dict(DEFAULT_SCALE if scale is None else scale)
         self.lr, self.b1, self.b2, self.eps = learning_rate, beta1, beta2, eps
@@ -69,6 +71,8 @@ class Trainer(object):
         self._plans = {}
         cmax = max(c.cout for c in g.convs())
         self.ws = torch.zeros(2 * cmax, dtype=torch.float64, device=self.dev)
+        wsb = max(self.lib.yolo_conv_wgrad_workspace_bytes(max(c.cin, 8), c.cout, c.k, self.ldt) for c in g.convs())
+        self.wg_ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=self.dev)
         self._repack()
 
     # ---- weight images for the forward and data-gradient convolutions (re-packed after every update) ----
@@ -78,21 +82,21 @@ class Trainer(object):
             w = self.pview[c.name + '.weight']
             ent = self._prep.get(c.name)
             if ent is None:
-                wp = torch.empty(lib.yolo_packed_weight_bytes(c.cout, c.cin, c.k, L.F32), dtype=torch.uint8, device=self.dev)
-                wd = torch.empty(lib.yolo_packed_weight_bytes(c.cin, c.cout, c.k, L.F32), dtype=torch.uint8, device=self.dev)
+                wp = torch.empty(lib.yolo_packed_weight_bytes(c.cout, c.cin, c.k, self.ldt), dtype=torch.uint8, device=self.dev)
+                wd = torch.empty(lib.yolo_packed_weight_bytes(c.cin, c.cout, c.k, self.ldt), dtype=torch.uint8, device=self.dev)
                 cp = lib.yolo_padded_channels(max(c.cout, c.cin))
                 ones = torch.zeros(cp, dtype=torch.float32, device=self.dev); ones[:max(c.cout, c.cin)] = 1.0
                 bias = torch.zeros(cp, dtype=torch.float32, device=self.dev)
                 ent = self._prep[c.name] = (wp, wd, ones, bias, torch.zeros(cp, dtype=torch.float32, device=self.dev))
             wp, wd, ones, bias, zeros = ent
-            L.check(lib.yolo_pack_conv_weights(L.ptr(w), L.ptr(wp), c.cout, c.cin, c.k, L.F32, st), 'pack')
-            L.check(lib.yolo_pack_conv_weights_dgrad(L.ptr(w), L.ptr(wd), c.cout, c.cin, c.k, L.F32, st), 'pack dgrad')
+            L.check(lib.yolo_pack_conv_weights(L.ptr(w), L.ptr(wp), c.cout, c.cin, c.k, self.ldt, st), 'pack')
+            L.check(lib.yolo_pack_conv_weights_dgrad(L.ptr(w), L.ptr(wd), c.cout, c.cin, c.k, self.ldt, st), 'pack dgrad')
             if not c.bn:
                 bias[:c.cout].copy_(self.pview[c.name + '.bias'])
 
     # ---- plan ---------------------------------------------------------------------------------------------
     def _new(self, shape):
-        return _T(torch.empty(shape, dtype=torch.float32, device=self.dev), tuple(shape))
+        return _T(torch.empty(shape, dtype=self.tdt, device=self.dev), tuple(shape))
 
     def _conv_desc(self, x, xshape, wp, scale, bias, y, cin, cout, k, stride, residual=None, out_f32=0, y_bs=0, y_ps=0):
         d = L.ConvDesc()
@@ -100,7 +104,7 @@ class Trainer(object):
         d.residual = L.ptr(residual) if residual is not None else None
         d.y = y if isinstance(y, int) else L.ptr(y)
         d.N, d.H, d.W, d.Cin, d.Cout = xshape[0], xshape[1], xshape[2], cin, cout
-        d.ksize, d.stride, d.dtype, d.out_f32, d.slope = k, stride, L.F32, out_f32, 1.0
+        d.ksize, d.stride, d.dtype, d.out_f32, d.slope = k, stride, self.ldt, out_f32, 1.0
         d.y_batch_stride, d.y_pixel_stride, d.algo = y_bs, y_ps, 0
         return d
 
@@ -149,7 +153,7 @@ class Trainer(object):
             d = self._conv_desc(t.val, t.shape, wp, ones, bias, yptr, outc.cin, outc.cout, 1, 1, out_f32=1, y_bs=tot * AC, y_ps=AC)
             cpad = (outc.cout + 7) // 8 * 8
             P.fwd.append(dict(kind='out', c=outc, x=t, desc=d, off=offs[k], hw=hw[k], cpad=cpad,
-                              dyp=torch.empty((B * hw[k], cpad), dtype=torch.float32, device=self.dev)))
+                              dyp=torch.empty((B * hw[k], cpad), dtype=self.tdt, device=self.dev)))
             if i >= len(g.heads) - 1:
                 break
             x = conv_bn(g.transitions[i], route)
@@ -163,7 +167,7 @@ class Trainer(object):
     def _forward(self, P, images):
         lib, st = self.lib, L.stream_ptr()
         B, _, H, W = images.shape
-        L.check(lib.yolo_nchw_to_nhwc(images.data_ptr(), L.ptr(P.x8.val), B, 3, H, W, 8, L.F32, st), 'nchw_to_nhwc')
+        L.check(lib.yolo_nchw_to_nhwc(images.data_ptr(), L.ptr(P.x8.val), B, 3, H, W, 8, self.ldt, st), 'nchw_to_nhwc')
         for op in P.fwd:
             if op['kind'] == 'conv_bn':
                 c = op['c']
@@ -175,13 +179,13 @@ class Trainer(object):
                                               L.ptr(op['res'].val) if op['res'] is not None else None, L.ptr(z.val),
                                               L.ptr(op['mean']), L.ptr(op['invstd']), L.ptr(p[c.name + '.running_mean']),
                                               L.ptr(p[c.name + '.running_var']), L.ptr(self.ws), npix, c.cout, BN_EPS,
-                                              BN_MOMENTUM, LEAKY_SLOPE, st), 'bn ' + c.name)
+                                              BN_MOMENTUM, LEAKY_SLOPE, self.ldt, st), 'bn ' + c.name)
             elif op['kind'] == 'out':
                 L.check(lib.yolo_conv_fwd(C.byref(op['desc']), st), 'out conv')
             else:
                 up, r, cat = op['up'], op['route'], op['cat']
                 L.check(lib.yolo_upsample2x_concat(L.ptr(up.val), L.ptr(r.val), L.ptr(cat.val), r.shape[0], r.shape[1],
-                                                   r.shape[2], up.shape[3], r.shape[3], L.F32, st), 'upcat')
+                                                   r.shape[2], up.shape[3], r.shape[3], self.ldt, st), 'upcat')
 
     # ---- backward -------------------------------------------------------------------------------------------
     def _accum(self, t, src):
@@ -189,7 +193,7 @@ class Trainer(object):
         if not t.ready:
             t.grad, t.ready = src, True
         else:
-            L.check(self.lib.yolo_add(L.ptr(t.grad), L.ptr(src), L.ptr(t.grad), src.numel(), L.stream_ptr()), 'add')
+            L.check(self.lib.yolo_add(L.ptr(t.grad), L.ptr(src), L.ptr(t.grad), src.numel(), self.ldt, L.stream_ptr()), 'add')
 
     def _dgrad(self, c, dy, dy_shape, xin, cin_of_dy):
         """grad[xin] (+)= data gradient of conv c given dy (N,Ho,Wo,cin_of_dy) (dense)."""
@@ -197,13 +201,13 @@ class Trainer(object):
         wp, wd, ones, bias, zeros = self._prep[c.name]
         N, Hh, Ww, Cx = xin.shape
         if c.stride == 2:
-            dil = torch.empty((N, Hh, Ww, cin_of_dy), dtype=torch.float32, device=self.dev)
-            L.check(lib.yolo_dilate2x(L.ptr(dy), L.ptr(dil), N, Hh, Ww, dy_shape[1], dy_shape[2], cin_of_dy, st), 'dilate')
+            dil = torch.empty((N, Hh, Ww, cin_of_dy), dtype=self.tdt, device=self.dev)
+            L.check(lib.yolo_dilate2x(L.ptr(dy), L.ptr(dil), N, Hh, Ww, dy_shape[1], dy_shape[2], cin_of_dy, self.ldt, st), 'dilate')
             src, sshape = dil, (N, Hh, Ww, cin_of_dy)
         else:
             src, sshape = dy, dy_shape
         if not xin.ready:
-            out = torch.empty(xin.shape, dtype=torch.float32, device=self.dev)
+            out = torch.empty(xin.shape, dtype=self.tdt, device=self.dev)
             resid = None
         else:
             out, resid = xin.grad, xin.grad
@@ -227,20 +231,20 @@ class Trainer(object):
                 c, xin = op['c'], op['x']
                 hw, cpad = op['hw'], op['cpad']
                 src = P.dmerged.data_ptr() + op['off'] * P.AC * 4
-                L.check(lib.yolo_gather_rows(src, L.ptr(op['dyp']), B, hw, c.cout, cpad, P.tot * P.AC, P.AC, st), 'gather')
-                L.check(lib.yolo_bias_grad(L.ptr(op['dyp']), L.ptr(self.gview[c.name + '.bias']), B * hw, c.cout, cpad, st), 'db')
+                L.check(lib.yolo_gather_rows(src, L.ptr(op['dyp']), B, hw, c.cout, cpad, P.tot * P.AC, P.AC, self.ldt, st), 'gather')
+                L.check(lib.yolo_bias_grad(L.ptr(op['dyp']), L.ptr(self.gview[c.name + '.bias']), B * hw, c.cout, cpad, self.ldt, st), 'db')
                 N, Hh, Ww, Cx = xin.shape
-                L.check(lib.yolo_conv_wgrad_f32(L.ptr(op['dyp']), L.ptr(xin.val), L.ptr(self.gview[c.name + '.weight']),
-                                                N, Hh, Ww, Cx, c.cout, 1, 1, cpad, st), 'wgrad out')
+                L.check(lib.yolo_conv_wgrad(L.ptr(op['dyp']), L.ptr(xin.val), L.ptr(self.gview[c.name + '.weight']),
+                                            N, Hh, Ww, Cx, c.cout, 1, 1, cpad, self.ldt, L.ptr(self.wg_ws), st), 'wgrad out')
                 self._dgrad(c, op['dyp'], (N, Hh, Ww, cpad), xin, cpad)
             elif kind == 'upcat':
                 up, r, cat = op['up'], op['route'], op['cat']
                 if not up.ready:
-                    up.grad = torch.empty(up.shape, dtype=torch.float32, device=self.dev)
+                    up.grad = torch.empty(up.shape, dtype=self.tdt, device=self.dev)
                 if not r.ready:
-                    r.grad = torch.empty(r.shape, dtype=torch.float32, device=self.dev)
+                    r.grad = torch.empty(r.shape, dtype=self.tdt, device=self.dev)
                 L.check(lib.yolo_upsample2x_concat_bwd(L.ptr(cat.grad), L.ptr(up.grad), L.ptr(r.grad), r.shape[0], r.shape[1],
-                                                       r.shape[2], up.shape[3], r.shape[3], int(up.ready), int(r.ready), st),
+                                                       r.shape[2], up.shape[3], r.shape[3], int(up.ready), int(r.ready), self.ldt, st),
                         'upcat bwd')
                 up.ready = r.ready = True
             else:
@@ -248,21 +252,22 @@ class Trainer(object):
                 dz = z.grad
                 npix = y.shape[0] * y.shape[1] * y.shape[2]
                 p = self.net.params
-                dy = torch.empty(y.shape, dtype=torch.float32, device=self.dev)
+                dy = torch.empty(y.shape, dtype=self.tdt, device=self.dev)
                 L.check(lib.yolo_bn_train_bwd(L.ptr(dz), L.ptr(y.val), L.ptr(op['mean']), L.ptr(op['invstd']),
                                               L.ptr(p[c.name + '.gamma']), L.ptr(p[c.name + '.beta']), L.ptr(dy),
                                               L.ptr(self.gview[c.name + '.gamma']), L.ptr(self.gview[c.name + '.beta']),
-                                              L.ptr(self.ws), npix, c.cout, LEAKY_SLOPE, st), 'bn bwd ' + c.name)
+                                              L.ptr(self.ws), npix, c.cout, LEAKY_SLOPE, self.ldt, st), 'bn bwd ' + c.name)
                 if op['res'] is not None:
                     self._accum(op['res'], dz)          # the residual branch receives dz unchanged
                 N, Hh, Ww, Cx = xin.shape
                 if c is g.stem:
                     dw8 = torch.zeros((c.cout, 8, 3, 3), dtype=torch.float32, device=self.dev)
-                    L.check(lib.yolo_conv_wgrad_f32(L.ptr(dy), L.ptr(xin.val), L.ptr(dw8), N, Hh, Ww, 8, c.cout, 3, 1, 0, st), 'wgrad stem')
+                    L.check(lib.yolo_conv_wgrad(L.ptr(dy), L.ptr(xin.val), L.ptr(dw8), N, Hh, Ww, 8, c.cout, 3, 1, 0, self.ldt,
+                                                L.ptr(self.wg_ws), st), 'wgrad stem')
                     self.gview[c.name + '.weight'].copy_(dw8[:, :3])
                 else:
-                    L.check(lib.yolo_conv_wgrad_f32(L.ptr(dy), L.ptr(xin.val), L.ptr(self.gview[c.name + '.weight']), N, Hh, Ww,
-                                                    Cx, c.cout, c.k, c.stride, 0, st), 'wgrad ' + c.name)
+                    L.check(lib.yolo_conv_wgrad(L.ptr(dy), L.ptr(xin.val), L.ptr(self.gview[c.name + '.weight']), N, Hh, Ww,
+                                                Cx, c.cout, c.k, c.stride, 0, self.ldt, L.ptr(self.wg_ws), st), 'wgrad ' + c.name)
                     self._dgrad(c, dy, y.shape, xin, c.cout)
 
     # ---- one training step -----------------------------------------------------------------------------------
