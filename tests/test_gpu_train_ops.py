@@ -90,7 +90,7 @@ def test_bn_train_fwd_bwd(lib, cuda, shape, with_res):
     g_, b_ = dev(gamma), dev(beta)
     zd = torch.empty_like(yd); m_ = torch.empty(Cc, device=cuda); is_ = torch.empty(Cc, device=cuda)
     rm = torch.zeros(Cc, device=cuda); rv = torch.ones(Cc, device=cuda)
-    ws = torch.zeros(2 * Cc, dtype=torch.float64, device=cuda)
+    ws = torch.zeros(3 * Cc, dtype=torch.float64, device=cuda)
     npix = N * H * W
     assert lib.yolo_bn_train_fwd(yd.data_ptr(), g_.data_ptr(), b_.data_ptr(), resd.data_ptr() if with_res else None,
                                  zd.data_ptr(), m_.data_ptr(), is_.data_ptr(), rm.data_ptr(), rv.data_ptr(), ws.data_ptr(),
@@ -157,7 +157,7 @@ def test_bn_train_bf16(lib, cuda):
     yd, dzd = to_nhwc(y.detach().numpy(), 'bf16', cuda), to_nhwc(dz.numpy(), 'bf16', cuda)
     g_, b_ = gamma.to(cuda), beta.to(cuda)
     zd = torch.empty_like(yd); m_ = torch.empty(Cc, device=cuda); is_ = torch.empty(Cc, device=cuda)
-    ws = torch.zeros(2 * Cc, dtype=torch.float64, device=cuda)
+    ws = torch.zeros(3 * Cc, dtype=torch.float64, device=cuda)
     npix = N * H * W
     assert lib.yolo_bn_train_fwd(yd.data_ptr(), g_.data_ptr(), b_.data_ptr(), None, zd.data_ptr(), m_.data_ptr(), is_.data_ptr(),
                                  None, None, ws.data_ptr(), npix, Cc, 1e-5, 0.9, 0.1, L.BF16, st) == 0

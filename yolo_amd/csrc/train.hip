@@ -36,9 +36,19 @@ template <> __device__ __forceinline__ void store1<bf16_t>(bf16_t* p, float v) {
 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm (train): per-channel batch statistics over (N,H,W) of an NHWC tensor (C % 8 == 0).
-// Thread = one 8-channel octet x one pixel lane: 16/32-byte coalesced accesses; per-block partial sums are
+// Both passes are HBM-bound.  Thread = one 8-channel octet x one pixel lane of a block-owned pixel range:
+// 16/32-byte coalesced accesses, BN_U independent loads in flight per thread (the first version had one and
+// ran at ~0.5 TB/s -- latency-bound), per-channel constants held in registers.  Block partial sums are
 // combined through LDS and added to the global sums in double.
 // ------------------------------------------------------------------------------------------------
+static void bn_partition(long long npix, int C, int elem, int* ppb, unsigned* nb) {
+    long long p = 32768 / ((long long)C * elem);               // ~32 KB of one tensor per block ...
+    if (p < 16) p = 16;
+    if ((npix + p - 1) / p > 2048) p = (npix + 2047) / 2048;    // ... and at most 2048 blocks (bounds the atomics)
+    *ppb = (int)p;
+    *nb = (unsigned)((npix + p - 1) / p);
+}
+
 // MODE 0: sums[0..C) = sum(y), sums[C..2C) = sum(y*y)
 // MODE 1: sums[0..C) = sum(da), sums[C..2C) = sum(da*xhat), da = dz * lrelu'(gamma*xhat+beta)
 template <typename T, int MODE>
@@ -47,14 +57,16 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         double* __restrict__ sums, int C, long long npix,
                                                         int pix_per_block, float slope) {
+    constexpr int U = MODE == 0 ? 8 : 4;
     __shared__ float red[2][256][8];
     const int noct = C >> 3;
-    const int lanes = noct < 256 ? 256 / noct : 1;             // pixel lanes per octet in this block
+    const int per = noct < 256 ? noct : 256;                    // octets handled per batch
+    const int lanes = 256 / per;                                // pixel lanes per octet in this block
     const long long p0 = (long long)blockIdx.x * pix_per_block;
     const long long p1 = min(p0 + pix_per_block, npix);
     for (int ob = 0; ob < noct; ob += 256) {                    // octet batches (C > 2048 only)
-        const int oct = ob + (threadIdx.x % (noct < 256 ? noct : 256));
-        const int pl = threadIdx.x / (noct < 256 ? noct : 256);
+        const int oct = ob + (threadIdx.x % per);
+        const int pl = threadIdx.x / per;
         float s[8], q[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
@@ -64,35 +76,47 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ y,
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { mu[e] = mean[oct * 8 + e]; is[e] = invstd[oct * 8 + e]; g[e] = gamma[oct * 8 + e]; b[e] = beta[oct * 8 + e]; }
             }
-            for (long long p = p0 + pl; p < p1; p += lanes) {
-                float v[8];
-                load8<T>(y + p * C + oct * 8, v);
-                if (MODE == 0) {
+            auto accum = [&](const float (&v)[8], const float (&d)[8]) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
-                } else {
-                    float d[8];
-                    load8<T>(dz + p * C + oct * 8, d);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
+                for (int e = 0; e < 8; ++e) {
+                    if (MODE == 0) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+                    else {
                         const float xh = (v[e] - mu[e]) * is[e];
                         const float da = d[e] * ((g[e] * xh + b[e]) > 0.f ? 1.f : slope);
                         s[e] += da; q[e] += da * xh;
                     }
                 }
+            };
+            const T* yp = y + oct * 8;
+            const T* dp = dz + oct * 8;
+            long long p = p0 + pl;
+            for (; p + (long long)(U - 1) * lanes < p1; p += (long long)U * lanes) {
+                float v[U][8], d[U][8];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    load8<T>(yp + (p + (long long)u * lanes) * C, v[u]);
+                    if (MODE == 1) load8<T>(dp + (p + (long long)u * lanes) * C, d[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) accum(v[u], MODE == 1 ? d[u] : v[u]);
+            }
+            for (; p < p1; p += lanes) {
+                float v[8], d[8];
+                load8<T>(yp + p * C, v);
+                if (MODE == 1) load8<T>(dp + p * C, d);
+                accum(v, MODE == 1 ? d : v);
             }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) { red[0][threadIdx.x][e] = s[e]; red[1][threadIdx.x][e] = q[e]; }
         __syncthreads();
-        const int per = noct < 256 ? noct : 256;
-        if (threadIdx.x < per && ob + (int)threadIdx.x < noct) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                double a = 0, c = 0;
-                for (int l = 0; l < lanes; ++l) { a += red[0][l * per + threadIdx.x][e]; c += red[1][l * per + threadIdx.x][e]; }
-                atomicAdd(&sums[(ob + threadIdx.x) * 8 + e], a);
-                atomicAdd(&sums[C + (ob + threadIdx.x) * 8 + e], c);
+        // 2*per*8 (quantity, octet, element) sums of `lanes` partials each, spread over the whole block
+        for (int i = threadIdx.x; i < 2 * per * 8; i += 256) {
+            const int e = i & 7, o = (i >> 3) % per, w = i / (per * 8);
+            if (ob + o < noct) {
+                double a = 0;
+                for (int l = 0; l < lanes; ++l) a += red[w][l * per + o][e];
+                atomicAdd(&sums[w * C + (ob + o) * 8 + e], a);
             }
         }
         __syncthreads();
@@ -117,44 +141,81 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, float* __res
     }
 }
 
-// MODE 0 (forward):  z = lrelu(gamma*(y-mean)*invstd + beta) (+ residual)
-// MODE 1 (backward): dy = gamma*invstd * (da - mean(da) - xhat*mean(da*xhat))
-template <typename T, int MODE>
-__global__ void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ other, const float* __restrict__ mean,
-                                const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, const double* __restrict__ sums, T* __restrict__ out,
-                                int C, long long total8, double inv_n, float slope) {
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;       // index of an 8-channel unit
-    if (i >= total8) return;
-    const int noct = C >> 3;
-    const int c0 = (int)(i % noct) * 8;
-    float v[8], o[8], r[8];
-    load8<T>(y + i * 8, v);
-    if (other) load8<T>(other + i * 8, o);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int c = c0 + e;
-        const float xh = (v[e] - mean[c]) * invstd[c];
-        const float a = gamma[c] * xh + beta[c];
-        if (MODE == 0) {
-            float z = a > 0.f ? a : a * slope;
-            if (other) z += o[e];
-            r[e] = z;
-        } else {
-            const float da = o[e] * (a > 0.f ? 1.f : slope);
-            const float m1 = (float)(sums[c] * inv_n), m2 = (float)(sums[C + c] * inv_n);
-            r[e] = gamma[c] * invstd[c] * (da - m1 - xh * m2);
-        }
-    }
-    store8<T>(out + i * 8, r);
-}
-
+// dbeta = sum(da), dgamma = sum(da*xhat); m12[0..C) / m12[C..2C) = their means (float) for the apply pass
 __global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, int C) {
+                                     float* __restrict__ dbeta, float* __restrict__ m12, int C, double inv_n) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     dbeta[c] = (float)sums[c];
     dgamma[c] = (float)sums[C + c];
+    m12[c] = (float)(sums[c] * inv_n);
+    m12[C + c] = (float)(sums[C + c] * inv_n);
+}
+
+// MODE 0 (forward):  z = lrelu(gamma*(y-mean)*invstd + beta) (+ residual)
+// MODE 1 (backward): dy = gamma*invstd * (da - mean(da) - xhat*mean(da*xhat))
+// Same thread <-> (octet, pixel lane) mapping as the reduction: channel constants live in registers.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ other,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ m12, T* __restrict__ out, int C,
+                                                       long long npix, int pix_per_block, float slope) {
+    constexpr int U = 4;
+    const int noct = C >> 3;
+    const int per = noct < 256 ? noct : 256;
+    const int lanes = 256 / per;
+    const long long p0 = (long long)blockIdx.x * pix_per_block;
+    const long long p1 = min(p0 + pix_per_block, npix);
+    const int pl = threadIdx.x / per;
+    if (pl >= lanes) return;
+    for (int oct = threadIdx.x % per; oct < noct; oct += 256) {
+        float sc[8], sh[8], k1[8], k2[8], mu[8], is[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = oct * 8 + e;
+            mu[e] = mean[c]; is[e] = invstd[c];
+            sc[e] = gamma[c]; sh[e] = beta[c];
+            if (MODE == 1) { k1[e] = m12[c]; k2[e] = m12[C + c]; }
+        }
+        auto apply = [&](const float (&v)[8], const float (&o)[8], float (&r)[8]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (v[e] - mu[e]) * is[e];
+                const float a = sc[e] * xh + sh[e];
+                if (MODE == 0) {
+                    float z = a > 0.f ? a : a * slope;
+                    if (other) z += o[e];
+                    r[e] = z;
+                } else {
+                    const float da = o[e] * (a > 0.f ? 1.f : slope);
+                    r[e] = sc[e] * is[e] * (da - k1[e] - xh * k2[e]);
+                }
+            }
+        };
+        const long long co = oct * 8;
+        long long p = p0 + pl;
+        for (; p + (long long)(U - 1) * lanes < p1; p += (long long)U * lanes) {
+            float v[U][8], o[U][8], r[8];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                load8<T>(y + (p + (long long)u * lanes) * C + co, v[u]);
+                if (other) load8<T>(other + (p + (long long)u * lanes) * C + co, o[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                apply(v[u], other ? o[u] : v[u], r);
+                store8<T>(out + (p + (long long)u * lanes) * C + co, r);
+            }
+        }
+        for (; p < p1; p += lanes) {
+            float v[8], o[8], r[8];
+            load8<T>(y + p * C + co, v);
+            if (other) load8<T>(other + p * C + co, o);
+            apply(v, other ? o : v, r);
+            store8<T>(out + p * C + co, r);
+        }
+    }
 }
 
 template <typename T>
@@ -163,15 +224,14 @@ static int bn_fwd_t(const T* y, const float* gamma, const float* beta, const T* 
                     float eps, float momentum, float slope, hipStream_t st) {
     (void)hipGetLastError();
     (void)hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
-    const int ppb = (int)((npix + 1023) / 1024 > 128 ? (npix + 1023) / 1024 : 128);
-    const unsigned nb = (unsigned)((npix + ppb - 1) / ppb);
+    int ppb; unsigned nb;
+    bn_partition(npix, C, (int)sizeof(T), &ppb, &nb);
     YOLO_LAUNCH((bn_reduce_kernel<T, 0>), dim3(nb), dim3(256), 0, st, y, (const T*)nullptr, (const float*)nullptr,
                 (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, workspace, C, npix, ppb, slope);
     YOLO_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, mean, invstd, running_mean,
                 running_var, C, 1.0 / (double)npix, eps, momentum);
-    const long long total8 = npix * (C >> 3);
-    YOLO_LAUNCH((bn_apply_kernel<T, 0>), dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, y, residual, mean,
-                invstd, gamma, beta, (const double*)nullptr, z, C, total8, 0.0, slope);
+    YOLO_LAUNCH((bn_apply_kernel<T, 0>), dim3(nb), dim3(256), 0, st, y, residual, mean, invstd, gamma, beta,
+                (const float*)nullptr, z, C, npix, ppb, slope);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
@@ -197,14 +257,15 @@ static int bn_bwd_t(const T* dz, const T* y, const float* mean, const float* inv
                     float slope, hipStream_t st) {
     (void)hipGetLastError();
     (void)hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
-    const int ppb = (int)((npix + 1023) / 1024 > 128 ? (npix + 1023) / 1024 : 128);
-    const unsigned nb = (unsigned)((npix + ppb - 1) / ppb);
+    int ppb; unsigned nb;
+    bn_partition(npix, C, (int)sizeof(T), &ppb, &nb);
+    float* m12 = (float*)(workspace + 2 * C);                 // workspace = 2C doubles + 2C floats
     YOLO_LAUNCH((bn_reduce_kernel<T, 1>), dim3(nb), dim3(256), 0, st, y, dz, mean, invstd, gamma, beta, workspace, C,
                 npix, ppb, slope);
-    const long long total8 = npix * (C >> 3);
-    YOLO_LAUNCH((bn_apply_kernel<T, 1>), dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, y, dz, mean, invstd,
-                gamma, beta, (const double*)workspace, dy, C, total8, 1.0 / (double)npix, slope);
-    YOLO_LAUNCH(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, dgamma, dbeta, C);
+    YOLO_LAUNCH(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, dgamma, dbeta, m12, C,
+                1.0 / (double)npix);
+    YOLO_LAUNCH((bn_apply_kernel<T, 1>), dim3(nb), dim3(256), 0, st, y, dz, mean, invstd, gamma, beta,
+                (const float*)m12, dy, C, npix, ppb, slope);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
