@@ -123,7 +123,10 @@ def test_upcat_bwd(lib, cuda):
 
 @pytest.mark.parametrize('case', [(2, 64, 8, 12, 128, 3, 1), (2, 128, 13, 13, 64, 1, 1), (3, 32, 13, 13, 64, 3, 1),
                                   (2, 16, 16, 24, 32, 3, 2), (2, 64, 4, 6, 96, 1, 1), (1, 8, 20, 20, 16, 3, 1),
-                                  (4, 256, 26, 26, 192, 3, 1), (2, 32, 26, 26, 64, 3, 2)])
+                                  (4, 256, 26, 26, 192, 3, 1), (2, 32, 26, 26, 64, 3, 2),
+                                  # strip kernel (3x3, Cin <= 64): several strips / row slices, ragged widths, channel tails
+                                  (1, 8, 70, 45, 32, 3, 1), (2, 40, 37, 66, 72, 3, 1), (1, 64, 50, 33, 128, 3, 2),
+                                  (1, 24, 41, 71, 40, 3, 2), (40, 32, 9, 9, 64, 3, 1)])
 def test_wgrad_bf16_transposing_reads(lib, cuda, case):
     """bf16 weight gradient (MFMA 32x32x16 fed by ds_read_b64_tr_b16): exact fp32 accumulation of the
     bf16-rounded operands, so it must match torch on the rounded inputs to fp32 noise."""

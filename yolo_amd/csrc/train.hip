@@ -471,6 +471,191 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const uint16_t* __restr
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 weight gradient of the early 3x3 layers (Cin <= 64: few output tiles, millions of pixels).  The per-tap
+// kernel above re-reads dy and x nine times and pads 32 channels to 128; here ONE WAVE (= one block, no block
+// barriers) owns a 32-pixel-wide column strip of one image and walks down its output rows with a rolling window
+// of input rows in LDS, so x and dy are read once and all nine taps accumulate from the same staged rows:
+// (CO_F*32 cout) x (32 cin) x 9 taps of fp32 accumulators per wave (144 AGPRs at CO_F = 1).
+// Next rows are fetched into registers while the current ones feed the MFMAs.  Partial sums of the strips are
+// added atomically into the [tap][Cout][Cin] workspace.
+// ------------------------------------------------------------------------------------------------
+template <int CO_F, int S, int TH>
+__global__ __launch_bounds__(64) void wgrad_strip_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
+                                                         float* __restrict__ dwt, int N, int H, int W, int Cin, int Ho,
+                                                         int Wo, int Cout, long long dy_ps, int tiles_ci, int tiles_co,
+                                                         int strips_w, int rows_per_slice) {
+    constexpr int TW = 32;                          // output pixels per strip row = 2 MFMA K-steps
+    constexpr int XW = (TW - 1) * S + 3;            // input pixels per staged row (with halo)
+    constexpr int XP = 64 + 16, DP = CO_F * 64 + 16;  // LDS pitches (bytes per pixel row, padded)
+    constexpr int INUSE = (TH - 1) * S + 3, NEW = S * TH, RING = INUSE + NEW;
+    constexpr int XROW = XW * XP, DYB = TH * TW * DP;
+    constexpr int XU = (NEW * XW * 4 + 63) / 64, DU = TH * TW * CO_F * 4 / 64;
+    __shared__ __attribute__((aligned(16))) char smem[RING * XROW + 2 * DYB];
+    char* xl = smem;
+    char* dyl = smem + RING * XROW;
+    const int lane = threadIdx.x;
+    int b = blockIdx.x;
+    const int tci = b % tiles_ci; b /= tiles_ci;
+    const int tco = b % tiles_co; b /= tiles_co;
+    const int sw = b % strips_w;
+    const int n = b / strips_w;
+    const int ci0 = tci * 32, co0 = tco * CO_F * 32;
+    const int ox0 = sw * TW, ix0 = ox0 * S - 1;
+    const int oy_begin = blockIdx.y * rows_per_slice;
+    const int oy_end = min(oy_begin + rows_per_slice, Ho);
+    if (oy_begin >= oy_end) return;
+
+    uint4 xr[XU], dr[DU];
+    auto load_x = [&](int iy0) {
+#pragma unroll
+        for (int j = 0; j < XU; ++j) {
+            const int u = lane + j * 64;
+            const int r = u / (XW * 4), rem = u - r * (XW * 4), px = rem >> 2, part = rem & 3;
+            const int iy = iy0 + r, ix = ix0 + px;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r < NEW && iy >= 0 && iy < H && ix >= 0 && ix < W && ci0 + part * 8 < Cin)
+                v = *(const uint4*)(x + (((long long)n * H + iy) * W + ix) * Cin + ci0 + part * 8);
+            xr[j] = v;
+        }
+    };
+    auto store_x = [&](int slot0) {
+#pragma unroll
+        for (int j = 0; j < XU; ++j) {
+            const int u = lane + j * 64;
+            const int r = u / (XW * 4), rem = u - r * (XW * 4), px = rem >> 2, part = rem & 3;
+            if (r < NEW) {
+                int slot = slot0 + r;
+                if (slot >= RING) slot -= RING;
+                *(uint4*)(xl + slot * XROW + px * XP + part * 16) = xr[j];
+            }
+        }
+    };
+    auto load_dy = [&](int oy) {
+#pragma unroll
+        for (int j = 0; j < DU; ++j) {
+            const int u = lane + j * 64;
+            const int part = u % (CO_F * 4), px = (u / (CO_F * 4)) % TW, t = u / (CO_F * 4 * TW);
+            const int o = oy + t, ox = ox0 + px;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (o < oy_end && ox < Wo && co0 + part * 8 < Cout)
+                v = *(const uint4*)(dy + (((long long)n * Ho + o) * Wo + ox) * dy_ps + co0 + part * 8);
+            dr[j] = v;
+        }
+    };
+    auto store_dy = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < DU; ++j) {
+            const int u = lane + j * 64;
+            const int part = u % (CO_F * 4), px = (u / (CO_F * 4)) % TW, t = u / (CO_F * 4 * TW);
+            *(uint4*)(dyl + buf * DYB + (t * TW + px) * DP + part * 16) = dr[j];
+        }
+    };
+
+    f32x16 acc[CO_F][9];
+#pragma unroll
+    for (int cf = 0; cf < CO_F; ++cf)
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cf][tp][r] = 0.f;
+
+    // prologue: the input rows the first TH output rows need, and their dy
+    const int iyb0 = oy_begin * S - 1;
+#pragma unroll
+    for (int r0 = 0; r0 < INUSE; r0 += NEW) {
+        load_x(iyb0 + r0);
+        store_x(r0);
+    }
+    load_dy(oy_begin);
+    store_dy(0);
+    __syncthreads();
+
+    const int g = lane >> 4, j16 = lane & 15;
+    const int frag_row = (g >> 1) * 8 + (j16 >> 2), frag_col2 = ((g & 1) * 16 + 4 * (j16 & 3)) * 2;
+    const int a_off = frag_row * DP + frag_col2;
+    const int b_off = frag_row * S * XP + frag_col2;
+    int slot0 = 0, buf = 0;
+    for (int oy = oy_begin; oy < oy_end; oy += TH) {
+        const bool more = oy + TH < oy_end;
+        if (more) {
+            load_x(oy * S - 1 + INUSE);
+            load_dy(oy + TH);
+        }
+#pragma unroll
+        for (int t = 0; t < TH; ++t) {
+            int slot[3];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                slot[kh] = slot0 + t * S + kh;
+                if (slot[kh] >= RING) slot[kh] -= RING;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[CO_F];
+#pragma unroll
+                for (int cf = 0; cf < CO_F; ++cf) {
+                    const char* p = dyl + buf * DYB + (t * TW + kk * 16) * DP + cf * 64 + a_off;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * DP));
+                    const uint2 a = __builtin_bit_cast(uint2, lo), c = __builtin_bit_cast(uint2, hi);
+                    af[cf] = __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, c.x, c.y));
+                }
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const char* p = xl + slot[kh] * XROW + (kk * 16 * S + kw) * XP + b_off;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * S * XP));
+                        const uint2 a = __builtin_bit_cast(uint2, lo), c = __builtin_bit_cast(uint2, hi);
+                        const bf16x8 bfr = __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, c.x, c.y));
+#pragma unroll
+                        for (int cf = 0; cf < CO_F; ++cf)
+                            acc[cf][kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cf], bfr, acc[cf][kh * 3 + kw], 0, 0, 0);
+                    }
+            }
+        }
+        if (more) {
+            int ns = slot0 + INUSE;
+            if (ns >= RING) ns -= RING;
+            store_x(ns);
+            store_dy(buf ^ 1);
+        }
+        slot0 += NEW;
+        if (slot0 >= RING) slot0 -= RING;
+        buf ^= 1;
+        __syncthreads();
+    }
+
+    const int l31 = lane & 31, h = lane >> 5;
+    const int ci = ci0 + l31;
+    if (ci >= Cin) return;
+#pragma unroll
+    for (int cf = 0; cf < CO_F; ++cf)
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + cf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < Cout) atomicAdd(dwt + ((long long)tp * Cout + co) * Cin + ci, acc[cf][tp][r]);
+            }
+}
+
+template <int CO_F, int S, int TH>
+static void wgrad_strip_launch(const uint16_t* dy, const uint16_t* x, float* dwt, int N, int H, int W, int Cin, int Ho,
+                               int Wo, int Cout, long long ps, hipStream_t st) {
+    const int tiles_ci = (Cin + 31) / 32, tiles_co = (Cout + CO_F * 32 - 1) / (CO_F * 32), strips_w = (Wo + 31) / 32;
+    const long long bx = (long long)tiles_ci * tiles_co * strips_w * N;
+    long long slices = (1024 + bx / 2) / bx;                  // ~4 single-wave blocks per CU resident
+    if (slices < 1) slices = 1;
+    int rps = (int)((Ho + slices - 1) / slices);
+    rps = (rps + TH - 1) / TH * TH;
+    slices = (Ho + rps - 1) / rps;
+    YOLO_LAUNCH((wgrad_strip_kernel<CO_F, S, TH>), dim3((unsigned)bx, (unsigned)slices), dim3(64), 0, st, dy, x, dwt, N, H,
+                W, Cin, Ho, Wo, Cout, ps, tiles_ci, tiles_co, strips_w, rps);
+}
+
 // dw_oihw[co][ci][tap] += dwt[tap][co][ci]
 __global__ void wgrad_finish_kernel(const float* __restrict__ dwt, float* __restrict__ dw, int Cout, int Cin, int taps,
                                     long long total) {
@@ -510,11 +695,24 @@ extern "C" int yolo_conv_wgrad(const void* dy, const void* x, float* dw_oihw, in
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
     const long long wsb = (long long)Cin * Cout * taps * 4;
+    const long long total = (long long)Cin * Cout * taps;
+    if (ksize == 3 && Cin <= 64) {
+        (void)hipMemsetAsync(workspace, 0, wsb, st);
+        const uint16_t* d16 = (const uint16_t*)dy;
+        const uint16_t* x16 = (const uint16_t*)x;
+        float* ws = (float*)workspace;
+        // CO_F = 1 (144 accumulator registers): CO_F = 2 needs 288 and spills
+        if (stride == 2) wgrad_strip_launch<1, 2, 1>(d16, x16, ws, N, H, W, Cin, Ho, Wo, Cout, ps, st);
+        else wgrad_strip_launch<1, 1, 2>(d16, x16, ws, N, H, W, Cin, Ho, Wo, Cout, ps, st);
+        YOLO_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
+                    dw_oihw, Cout, Cin, taps, total);
+        YOLO_LAUNCH_CHECK();
+        return YOLO_OK;
+    }
     if (slices > 1) (void)hipMemsetAsync(workspace, 0, wsb, st);
     YOLO_LAUNCH(wgrad_bf16_kernel, dim3((unsigned)(tiles_ci * tiles_co), taps, (unsigned)slices), dim3(256), 0, st,
                 (const uint16_t*)dy, (const uint16_t*)x, (float*)workspace, N, H, W, Cin, Ho, Wo, Cout, ksize, stride, ps,
                 tiles_ci, cps, slices > 1 ? 1 : 0);
-    const long long total = (long long)Cin * Cout * taps;
     YOLO_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
                 dw_oihw, Cout, Cin, taps, total);
     YOLO_LAUNCH_CHECK();
