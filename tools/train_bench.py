@@ -11,9 +11,10 @@ ap.add_argument('--batch', type=int, default=8)
 ap.add_argument('--size', type=int, default=416)
 ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--dtype', default='bf16')
+ap.add_argument('--tune', default='measure')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
-net = CarNet(darknet53_spec(), dtype=a.dtype, device=dev).initialize(1)
+net = CarNet(darknet53_spec(), dtype=a.dtype, device=dev, tune=a.tune).initialize(1)
 tr = Trainer(net, (a.size, a.size))
 x = torch.rand((a.batch, 3, a.size, a.size), device=dev)
 rng = np.random.default_rng(3)

@@ -69,6 +69,7 @@ class Trainer(object):
         net._prepared = {}
         self._prep = {}
         self._plans = {}
+        self._dgrad_algo = {}
         cmax = max(c.cout for c in g.convs())
         self.ws = torch.zeros(3 * cmax, dtype=torch.float64, device=self.dev)
         wsb = max(self.lib.yolo_conv_wgrad_workspace_bytes(max(c.cin, 8), c.cout, c.k, self.ldt) for c in g.convs())
@@ -108,6 +109,12 @@ class Trainer(object):
         d.y_batch_stride, d.y_pixel_stride, d.algo = y_bs, y_ps, 0
         return d
 
+    def _tune(self, d):
+        """Pick the conv variant by measurement when the net was built with tune='measure' (the timing runs only
+        overwrite d.y, which nothing has consumed yet)."""
+        if getattr(self.net, 'tune', None) == 'measure':
+            d.algo = self.net._measure_algo(d)
+
     def _build(self, B, H, W):
         g = self.net.graph
         P = type('Plan', (), {})()
@@ -122,6 +129,7 @@ class Trainer(object):
             invstd = torch.empty_like(mean)
             wp, wd, ones, bias, zeros = self._prep[c.name]
             d = self._conv_desc(xin.val, xin.shape, wp, ones, zeros, yraw.val, Cc, c.cout, c.k, c.stride)
+            self._tune(d)
             P.fwd.append(dict(kind='conv_bn', c=c, x=xin, yraw=yraw, z=z, mean=mean, invstd=invstd, res=residual, desc=d))
             return z
 
@@ -151,6 +159,7 @@ class Trainer(object):
             wp, wd, ones, bias, zeros = self._prep[outc.name]
             yptr = P.merged.data_ptr() + offs[k] * AC * 4
             d = self._conv_desc(t.val, t.shape, wp, ones, bias, yptr, outc.cin, outc.cout, 1, 1, out_f32=1, y_bs=tot * AC, y_ps=AC)
+            self._tune(d)
             cpad = (outc.cout + 7) // 8 * 8
             P.fwd.append(dict(kind='out', c=outc, x=t, desc=d, off=offs[k], hw=hw[k], cpad=cpad,
                               dyp=torch.empty((B * hw[k], cpad), dtype=self.tdt, device=self.dev)))
@@ -212,6 +221,15 @@ class Trainer(object):
         else:
             out, resid = xin.grad, xin.grad
         d = self._conv_desc(src, sshape, wd, ones, zeros, out, cin_of_dy, Cx, c.k, 1, residual=resid)
+        if getattr(self.net, 'tune', None) == 'measure':
+            key = (sshape, cin_of_dy, Cx, c.k, resid is not None)
+            if key not in self._dgrad_algo:
+                # time the variants on scratch outputs: the real `out` may already hold an accumulated gradient
+                scratch = torch.zeros(xin.shape, dtype=self.tdt, device=self.dev)
+                dm = self._conv_desc(src, sshape, wd, ones, zeros, scratch, cin_of_dy, Cx, c.k, 1,
+                                     residual=scratch if resid is not None else None)
+                self._dgrad_algo[key] = self.net._measure_algo(dm)
+            d.algo = self._dgrad_algo[key]
         L.check(lib.yolo_conv_fwd(C.byref(d), st), 'dgrad ' + c.name)
         xin.grad, xin.ready = out, True
 
