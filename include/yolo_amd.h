@@ -163,7 +163,8 @@ int yolo_pack_conv_weights_dgrad(const float* w_oihw, void* packed, int Cout_f, 
 /* Gluon BatchNorm in training mode fused with LeakyReLU (+ residual add):
  * batch mean / biased variance over (N,H,W) of the NHWC conv output y (npix x C, dtype; C % 8 == 0),
  * z = lrelu(gamma*(y-mean)*invstd + beta) [+ residual]; running stats r = momentum*r + (1-momentum)*batch
- * (running_var takes the biased variance).  Statistics are accumulated in double.  workspace: 3*C doubles (shared by the backward). */
+ * (running_var takes the biased variance).  Statistics are accumulated in double.  workspace: 2*C doubles (shared by the
+ * backward), ZERO-FILLED by the caller before its first use; every call leaves it zeroed again. */
 int yolo_bn_train_fwd(const void* y, const float* gamma, const float* beta, const void* residual,
                       void* z, float* mean, float* invstd, float* running_mean, float* running_var,
                       double* workspace, long long npix, int C, float eps, float momentum, float slope,

@@ -39,12 +39,22 @@ template <> __device__ __forceinline__ void store1<bf16_t>(bf16_t* p, float v) {
 // Both passes are HBM-bound.  Thread = one 8-channel octet x one pixel lane of a block-owned pixel range:
 // 16/32-byte coalesced accesses, BN_U independent loads in flight per thread (the first version had one and
 // ran at ~0.5 TB/s -- latency-bound), per-channel constants held in registers.  Block partial sums are
-// combined through LDS and added to the global sums in double.
+// combined through LDS and added to the global sums in double.  The sums live in the caller's workspace, which
+// must be zero on first use; the finalize / parameter-gradient kernels zero it again after reading (no memset
+// launch per call).
 // ------------------------------------------------------------------------------------------------
-static void bn_partition(long long npix, int C, int elem, int* ppb, unsigned* nb) {
+static void bn_partition(long long npix, int C, int elem, bool reduces, int* ppb, unsigned* nb) {
     long long p = 32768 / ((long long)C * elem);               // ~32 KB of one tensor per block ...
     if (p < 16) p = 16;
-    if ((npix + p - 1) / p > 2048) p = (npix + 2047) / 2048;    // ... and at most 2048 blocks (bounds the atomics)
+    // ... and a bounded number of blocks: every block of the reduction ends with 2C double atomics, which
+    // dominate the small deep layers (C = 1024 over 5408 pixels) unless the block count shrinks with C
+    long long maxb = 2048;
+    if (reduces) {
+        maxb = 65536 / C;
+        if (maxb < 64) maxb = 64;
+        if (maxb > 2048) maxb = 2048;
+    }
+    if ((npix + p - 1) / p > maxb) p = (npix + maxb - 1) / maxb;
     *ppb = (int)p;
     *nb = (unsigned)((npix + p - 1) / p);
 }
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ y,
 
 // mean / invstd (biased variance, eps) + running-stat update (momentum m: r = m*r + (1-m)*batch;
 // running_var takes the BIASED batch variance -- the MXNet CPU convention).
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ mean,
+__global__ void bn_finalize_kernel(double* __restrict__ sums, float* __restrict__ mean,
                                    float* __restrict__ invstd, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, int C, double inv_n, float eps, float momentum) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -135,21 +145,23 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, float* __res
     if (v < 0) v = 0;
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(v + (double)eps));
+    sums[c] = 0.0;                                   // leave the workspace zeroed for the next call
+    sums[C + c] = 0.0;
     if (running_mean) {
         running_mean[c] = momentum * running_mean[c] + (1.f - momentum) * (float)m;
         running_var[c] = momentum * running_var[c] + (1.f - momentum) * (float)v;
     }
 }
 
-// dbeta = sum(da), dgamma = sum(da*xhat); m12[0..C) / m12[C..2C) = their means (float) for the apply pass
-__global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, float* __restrict__ m12, int C, double inv_n) {
+// dbeta = sum(da), dgamma = sum(da*xhat) (the apply pass divides them by the pixel count)
+__global__ void bn_param_grad_kernel(double* __restrict__ sums, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     dbeta[c] = (float)sums[c];
     dgamma[c] = (float)sums[C + c];
-    m12[c] = (float)(sums[c] * inv_n);
-    m12[C + c] = (float)(sums[C + c] * inv_n);
+    sums[c] = 0.0;
+    sums[C + c] = 0.0;
 }
 
 // MODE 0 (forward):  z = lrelu(gamma*(y-mean)*invstd + beta) (+ residual)
@@ -159,8 +171,9 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ other,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ m12, T* __restrict__ out, int C,
-                                                       long long npix, int pix_per_block, float slope) {
+                                                       const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                       float inv_n, T* __restrict__ out, int C, long long npix,
+                                                       int pix_per_block, float slope) {
     constexpr int U = 4;
     const int noct = C >> 3;
     const int per = noct < 256 ? noct : 256;
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
             const int c = oct * 8 + e;
             mu[e] = mean[c]; is[e] = invstd[c];
             sc[e] = gamma[c]; sh[e] = beta[c];
-            if (MODE == 1) { k1[e] = m12[c]; k2[e] = m12[C + c]; }
+            if (MODE == 1) { k1[e] = dbeta[c] * inv_n; k2[e] = dgamma[c] * inv_n; }
         }
         auto apply = [&](const float (&v)[8], const float (&o)[8], float (&r)[8]) {
 #pragma unroll
@@ -223,15 +236,15 @@ static int bn_fwd_t(const T* y, const float* gamma, const float* beta, const T* 
                     float* invstd, float* running_mean, float* running_var, double* workspace, long long npix, int C,
                     float eps, float momentum, float slope, hipStream_t st) {
     (void)hipGetLastError();
-    (void)hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
-    int ppb; unsigned nb;
-    bn_partition(npix, C, (int)sizeof(T), &ppb, &nb);
+    int ppb, ppa; unsigned nb, na;
+    bn_partition(npix, C, (int)sizeof(T), true, &ppb, &nb);
+    bn_partition(npix, C, (int)sizeof(T), false, &ppa, &na);
     YOLO_LAUNCH((bn_reduce_kernel<T, 0>), dim3(nb), dim3(256), 0, st, y, (const T*)nullptr, (const float*)nullptr,
                 (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, workspace, C, npix, ppb, slope);
     YOLO_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, mean, invstd, running_mean,
                 running_var, C, 1.0 / (double)npix, eps, momentum);
-    YOLO_LAUNCH((bn_apply_kernel<T, 0>), dim3(nb), dim3(256), 0, st, y, residual, mean, invstd, gamma, beta,
-                (const float*)nullptr, z, C, npix, ppb, slope);
+    YOLO_LAUNCH((bn_apply_kernel<T, 0>), dim3(na), dim3(256), 0, st, y, residual, mean, invstd, gamma, beta,
+                (const float*)nullptr, (const float*)nullptr, 0.f, z, C, npix, ppa, slope);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
@@ -256,16 +269,14 @@ static int bn_bwd_t(const T* dz, const T* y, const float* mean, const float* inv
                     const float* beta, T* dy, float* dgamma, float* dbeta, double* workspace, long long npix, int C,
                     float slope, hipStream_t st) {
     (void)hipGetLastError();
-    (void)hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
-    int ppb; unsigned nb;
-    bn_partition(npix, C, (int)sizeof(T), &ppb, &nb);
-    float* m12 = (float*)(workspace + 2 * C);                 // workspace = 2C doubles + 2C floats
+    int ppb, ppa; unsigned nb, na;
+    bn_partition(npix, C, (int)sizeof(T), true, &ppb, &nb);
+    bn_partition(npix, C, (int)sizeof(T), false, &ppa, &na);
     YOLO_LAUNCH((bn_reduce_kernel<T, 1>), dim3(nb), dim3(256), 0, st, y, dz, mean, invstd, gamma, beta, workspace, C,
                 npix, ppb, slope);
-    YOLO_LAUNCH(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, dgamma, dbeta, m12, C,
-                1.0 / (double)npix);
-    YOLO_LAUNCH((bn_apply_kernel<T, 1>), dim3(nb), dim3(256), 0, st, y, dz, mean, invstd, gamma, beta,
-                (const float*)m12, dy, C, npix, ppb, slope);
+    YOLO_LAUNCH(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, dgamma, dbeta, C);
+    YOLO_LAUNCH((bn_apply_kernel<T, 1>), dim3(na), dim3(256), 0, st, y, dz, mean, invstd, gamma, beta,
+                (const float*)dgamma, (const float*)dbeta, (float)(1.0 / (double)npix), dy, C, npix, ppa, slope);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
