@@ -78,17 +78,92 @@ def pmc_traffic(kernel, B, size):
     return None
 
 
+def synthetic_labels(batch, seed, num_class=24):
+    """Config-3 synthetic targets: (B,1,6+C) rows [cls,y,x,h,w,rot,dist...]; with p = 0.5 a row
+    of -1 = no object (render_rate, car/YOLO.py:329); dist = normalised exp(-d^2/0.1) over 24 azimuth bins."""
+    rng = np.random.default_rng(seed)
+    lab = -np.ones((batch, 1, 6 + num_class), np.float32)
+    centres = np.deg2rad(15.0 * np.arange(num_class))
+    for b in range(batch):
+        if rng.random() < 0.5:
+            continue
+        azi = rng.uniform(0, 2 * np.pi)
+        d = np.arccos(np.clip(np.cos(azi - centres), -1, 1))
+        g = np.exp(-d.astype(np.float32) ** 2 / np.float32(0.1))
+        y, x = rng.uniform(.15, .85, 2)
+        h, w = rng.uniform(.2, .9, 2)
+        lab[b, 0, :6] = [int(np.argmin(d)), y, x, h, w, rng.uniform(-30, 30) * np.pi / 180]
+        lab[b, 0, 6:] = g / g.sum()
+    return lab
+
+
+def bench_train(args, spec, size, B, rank, world, dev, dist):
+    """BASELINE configs[2] (N=1) / configs[3] (N>1): car/YOLO.py training step, B images per GPU, the gradient
+    bucket all-reduced over RCCL (one exchange per step), identical Adam on every rank."""
+    from yolo_amd.net import CarNet
+    from yolo_amd.train import Trainer
+    net = CarNet(spec, dtype=args.dtype, device=dev, tune='measure', tune_cache=args.tune_cache).initialize(seed=1234)
+    tr = Trainer(net, size)
+    gen = torch.Generator(device='cpu').manual_seed(100 + rank)
+    x = torch.rand((B, 3) + size, generator=gen).to(dev)
+    lab = torch.from_numpy(synthetic_labels(B, 3 + rank)).to(dev)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):          # the first step also measures the kernel variants
+        tr.train_step(x, lab)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = tr.train_step(x, lab)
+    fence()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    value = world * B * args.steps / el
+    fl = 3 * net.graph.flops(*size)
+    out = {
+        'metric': 'training images/sec at %dx%d bs=%d per GPU (fwd + loss + bwd + train-mode BN + Adam)' % (size[0], size[1], B),
+        'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(el / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[%d]: car/YOLO.py training step, Darknet-53 spec + 3-scale YOLO head '
+                               '(A=3, C=30), synthetic render_car-style targets, %dx%d, bs=%d per GPU, %s activations / '
+                               'fp32 master weights, BN statistics, loss and Adam' % (2 if world == 1 else 3, size[0], size[1], B, args.dtype),
+                   'global_batch': B * world, 'image': list(size),
+                   'parallelism': 'dp%d (batch-sharded; one RCCL all-reduce of the %d-element fp32 gradient bucket per step)'
+                                  % (world, tr.gflat.numel()),
+                   'gflop_per_image': round(fl / 1e9, 2)},
+        'net_tflops': round(fl * value / 1e12, 1),
+        'final_losses': [round(float(v), 6) for v in losses.sum(dim=1).tolist()],
+    }
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (default 32; 64 in --mode train)')
     ap.add_argument('--size', type=int, default=416)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--tune-cache', default=None, help='JSON file remembering the measured per-layer kernel choices')
+    ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
+                    help="'infer' = BASELINE configs[1] (the headline metric); 'train' = configs[2]/[3]: one training "
+                         "step (fwd + loss + bwd + train-mode BN + gradient all-reduce + Adam) per step")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -111,7 +186,9 @@ def main():
 
     spec = darknet53_spec()
     size = (args.size, args.size)
-    B = args.batch
+    B = args.batch or (64 if args.mode == 'train' else 32)
+    if args.mode == 'train':
+        return bench_train(args, spec, size, B, rank, world, dev, dist)
     net = CarNet(spec, dtype=args.dtype, device=dev, tune='measure', tune_cache=args.tune_cache).initialize(seed=1234)
     net.prepare()
     det = Detector(spec, size, net.graph.steps(), device=dev)

@@ -54,3 +54,51 @@ def test_shard_bounds_match_reference_formula():
             got = [P.shard_bounds(B, i, n) for i in range(n)]
             assert got == [(int(i * B / n), int((i + 1) * B / n)) for i in range(n)]
             assert got[0][0] == 0 and got[-1][1] == B
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    names = ['p%d' % i for i in range(7)]
+    sizes = [5, 64, 3, 40, 17, 8, 30]
+    offs, o = [], 0
+    for s in sizes:
+        offs.append(o); o += (s + 3) // 4 * 4
+    flat = torch.zeros(o)
+    for n, of, s in zip(names, offs, sizes):
+        flat[of:of + s] = float(rank + 1) * (1 + names.index(n))
+    b = P.GradBuckets(flat, names, offs, sizes, nbuckets=3)
+    b.reset()
+    # the backward reports parameters roughly from the end of the buffer to its start, not exactly in order
+    for group in (['p6'], ['p4', 'p5'], ['p3'], ['p1'], ['p2'], ['p0']):
+        b.done(group)
+    b.wait()
+    q.put((rank, b.ranges, flat.tolist()))
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_two_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(timeout=60) for p in ps]
+    ranges = out[0][1]
+    assert ranges[0][0] == 0 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])) and len(ranges) >= 2
+    sizes = [5, 64, 3, 40, 17, 8, 30]
+    expect, o = [], 0
+    for i, s in enumerate(sizes):
+        pad = (s + 3) // 4 * 4
+        expect += [3.0 * (1 + i)] * s + [0.0] * (pad - s)          # (1 + 2) * value: SUM over the two ranks
+    assert ranges[-1][1] == len(expect)
+    assert out[0][2] == out[1][2] == expect
+
+
+def test_bucket_ranges_cover_the_buffer():
+    offs, sizes = [0, 8, 24, 28, 100], [6, 16, 3, 70, 9]
+    for nb in (1, 2, 3, 10):
+        r = P.bucket_ranges(offs, sizes, nb, total=112)
+        assert r[0][0] == 0 and r[-1][1] == 112 and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        assert all(a in offs + [112] for a, _ in r) and len(r) <= max(1, nb) + 1

@@ -6,6 +6,8 @@ Inference is embarrassingly parallel: no collective on the data path, results ar
 rank 0 only when the caller asks.  The training exchange step is one SUM all-reduce of the flat
 gradient bucket followed by the 1/global_batch rescale of trainer.step(batch_size) (car/YOLO.py:396).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -52,3 +54,70 @@ def allreduce_sum_(flat):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
+
+
+def bucket_ranges(offsets, sizes, nbuckets, total=None):
+    """Contiguous [start, end) ranges of a flat buffer, cut at parameter boundaries into ~equal buckets.
+    offsets/sizes: start and length of every parameter's slot in the flat buffer (ascending)."""
+    total = offsets[-1] + sizes[-1] if total is None else total
+    target = max(1, -(-total // max(1, nbuckets)))
+    ranges, start = [], 0
+    for i, (o, s) in enumerate(zip(offsets, sizes)):
+        end = offsets[i + 1] if i + 1 < len(offsets) else total      # a slot owns its alignment padding
+        if end - start >= target or i + 1 == len(offsets):
+            ranges.append((start, end))
+            start = end
+    return ranges
+
+
+class GradBuckets(object):
+    """Bucketed gradient all-reduce overlapped with the backward pass (one exchange step =
+    allReduce(sum) of the flat gradient bucket).  The flat buffer is cut into contiguous buckets at parameter
+    boundaries; `done(names)` is called as the backward finishes parameters and launches the asynchronous SUM
+    all-reduce of every bucket whose parameters are all final, on the process group's own stream, while the
+    remaining backward kernels keep running; `wait()` joins them before the optimiser.  xGMI is point-to-point,
+    so a few large buckets (default 4 over 492 MB) keep every ring step bandwidth-bound."""
+
+    def __init__(self, flat, names, offsets, sizes, nbuckets=4):
+        self.flat = flat
+        self.ranges = bucket_ranges(offsets, sizes, nbuckets, flat.numel())
+        self.owner = {}
+        for n, o in zip(names, offsets):
+            self.owner[n] = next(k for k, (a, b) in enumerate(self.ranges) if a <= o < b)
+        self.count0 = [0] * len(self.ranges)
+        for n in names:
+            self.count0[self.owner[n]] += 1
+        self.reset()
+
+    def active(self):
+        # (YOLO_BENCH_FORCE_DIST exercises the exchange on a single rank)
+        return self.enabled and dist.is_initialized() and (dist.get_world_size() > 1 or
+                                                           bool(os.environ.get('YOLO_BENCH_FORCE_DIST')))
+
+    def reset(self, enabled=True):
+        self.enabled = enabled
+        self.pending = list(self.count0)
+        self.works = []
+        self.launched = [False] * len(self.ranges)
+
+    def done(self, names):
+        if not self.active():
+            return
+        for n in names:
+            k = self.owner[n]
+            self.pending[k] -= 1
+            if self.pending[k] == 0 and not self.launched[k]:
+                a, b = self.ranges[k]
+                self.launched[k] = True
+                self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
+
+    def wait(self):
+        if not self.active():
+            return
+        for k, (a, b) in enumerate(self.ranges):          # anything the backward never reported (defensive)
+            if not self.launched[k]:
+                self.launched[k] = True
+                self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
+        for w in self.works:
+            w.wait()
+        self.works = []

@@ -66,6 +66,7 @@ class Trainer(object):
             net.params[n] = self.wflat[of:of + s].view(shp)
             self.pview[n] = net.params[n]
             self.gview[n] = self.gflat[of:of + s].view(shp)
+        self.buckets = parallel.GradBuckets(self.gflat, names, offs, sizes, nbuckets=4)
         net._prepared = {}
         self._prep = {}
         self._plans = {}
@@ -233,10 +234,11 @@ class Trainer(object):
         L.check(lib.yolo_conv_fwd(C.byref(d), st), 'dgrad ' + c.name)
         xin.grad, xin.ready = out, True
 
-    def _backward(self, P):
+    def _backward(self, P, exchange=True):
         lib, st = self.lib, L.stream_ptr()
         g = self.net.graph
         self.gflat.zero_()
+        self.buckets.reset(enabled=exchange)
         for op in P.fwd:
             for k in ('x', 'z', 'up', 'route', 'cat', 'res'):
                 t = op.get(k)
@@ -255,6 +257,7 @@ class Trainer(object):
                 L.check(lib.yolo_conv_wgrad(L.ptr(op['dyp']), L.ptr(xin.val), L.ptr(self.gview[c.name + '.weight']),
                                             N, Hh, Ww, Cx, c.cout, 1, 1, cpad, self.ldt, L.ptr(self.wg_ws), st), 'wgrad out')
                 self._dgrad(c, op['dyp'], (N, Hh, Ww, cpad), xin, cpad)
+                self.buckets.done([c.name + '.weight', c.name + '.bias'])
             elif kind == 'upcat':
                 up, r, cat = op['up'], op['route'], op['cat']
                 if not up.ready:
@@ -287,6 +290,7 @@ class Trainer(object):
                     L.check(lib.yolo_conv_wgrad(L.ptr(dy), L.ptr(xin.val), L.ptr(self.gview[c.name + '.weight']), N, Hh, Ww,
                                                 Cx, c.cout, c.k, c.stride, 0, self.ldt, L.ptr(self.wg_ws), st), 'wgrad ' + c.name)
                     self._dgrad(c, dy, y.shape, xin, c.cout)
+                self.buckets.done([c.name + '.weight', c.name + '.gamma', c.name + '.beta'])
 
     # ---- one training step -----------------------------------------------------------------------------------
     def train_step(self, images, labels, global_batch=None, update=True):
@@ -312,9 +316,9 @@ class Trainer(object):
         L.check(lib.yolo_loss_fwd_bwd(L.ptr(P.merged), L.ptr(rec), L.ptr(P.dmerged), L.ptr(losses), B, self.nbox, C_, nobj,
                                       s5, self.pos_w, self.neg_w, st), 'loss')
         self._last = (P, rec)
-        self._backward(P)
+        self._backward(P, exchange=update)
         if update:
-            parallel.allreduce_sum_(self.gflat)                    # KVStore sum-reduce of trainer.step (RCCL)
+            self.buckets.wait()                                    # KVStore sum-reduce of trainer.step (RCCL), bucketed
             gb = global_batch if global_batch is not None else B * (torch.distributed.get_world_size()
                                                                      if torch.distributed.is_initialized() else 1)
             self.t += 1
