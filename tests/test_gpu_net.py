@@ -143,3 +143,20 @@ def test_zero_input_known_answer(cuda):
     outs = net(torch.zeros((1, 3, 64, 96), device=cuda))
     for o in outs:
         assert float(o.abs().max()) == 0.0
+
+
+def test_gluon_params_file_round_trip(cuda, tmp_path):
+    """A net restored from an MXNet `.params` file (collect_params().save layout, yolo_amd/mxparams.py) gives the
+    same logits as the net that wrote it -- and as the oracle on the same parameters."""
+    from yolo_amd.net import CarNet
+    spec, size = og.spec_micro(), (64, 96)
+    g, P, x, net, outs = _run(spec, size, 2, 'f32', 'random', cuda)
+    path = str(tmp_path / 'micro.params')
+    net.save_gluon_params(path)
+    net2 = CarNet(spec, dtype='f32', device=cuda).load_gluon_params(path)
+    outs2 = [o.cpu().numpy() for o in net2(torch.from_numpy(x).to(cuda))]
+    for a, b in zip(outs, outs2):
+        np.testing.assert_array_equal(a, b)
+    ref = of.forward_torch(g, P, x)
+    for o, r in zip(outs2, ref):
+        np.testing.assert_allclose(o, r.numpy(), rtol=0, atol=1e-3)

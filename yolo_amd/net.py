@@ -97,6 +97,17 @@ class CarNet(object):
         with np.load(path) as z:
             return self.load_params({k: z[k] for k in z.files})
 
+    def load_gluon_params(self, path, order='auto'):
+        """Load a gluon `.params` file written by `net.collect_params().save(path)` (car/YOLO.py:549) or
+        `net.export` (yolo_gluon.py:257) -- the counterpart of `collect_params().load(weight, ctx)`
+        (yolo_gluon.py:190).  See yolo_amd/mxparams.py for the container and the order mapping."""
+        from . import mxparams
+        return self.load_params(mxparams.from_gluon(self.graph, mxparams.read_params(path), order))
+
+    def save_gluon_params(self, path, prefix='carnet0_'):
+        from . import mxparams
+        mxparams.write_params(path, mxparams.to_gluon(self.graph, self.params, prefix))
+
     # ---- one-off preparation: BN folding + weight packing (all on device, HIP kernels) ------------
     def prepare(self):
         lib, st, dt = self._lib, L.stream_ptr(), _LIB_DT[self.dtype]
