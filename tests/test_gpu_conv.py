@@ -126,3 +126,42 @@ def test_conv_pipe_stride2(lib, cuda, case, dtype, algo):
         np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-4)
     else:
         np.testing.assert_allclose(y, ref, rtol=1.6e-2, atol=2e-2)
+
+
+# ---- streaming kernel for the small-channel layers (csrc/conv_stream.hip, algo 13 / 14) -----------------------
+STREAM_CASES = [
+    # (N, Cin, H, W, Cout, k, stride, residual)
+    (2, 32, 40, 75, 64, 3, 1, True),        # several balanced strips, ragged last strip, row slices
+    (1, 32, 9, 200, 64, 3, 1, False),
+    (3, 64, 33, 41, 128, 3, 1, True),
+    (2, 64, 20, 70, 32, 3, 1, True),        # data-gradient shape of a residual block's 3x3
+    (2, 64, 24, 24, 64, 3, 1, False),
+    (2, 32, 41, 77, 64, 3, 2, False),       # stride 2, odd input size
+    (2, 64, 38, 38, 128, 3, 2, False),
+    (2, 64, 30, 131, 32, 1, 1, False),
+    (3, 128, 19, 19, 64, 1, 1, False),
+    (2, 32, 17, 140, 64, 1, 1, True),       # data-gradient shape of a residual block's 1x1
+    (2, 64, 26, 26, 128, 1, 1, True),
+    (1, 128, 13, 70, 128, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize('algo', [13, 14])
+@pytest.mark.parametrize('case', STREAM_CASES)
+def test_conv_stream(lib, cuda, case, algo):
+    x, w, scale, bias, r = _mk(case, 7)
+    y = run_conv(lib, cuda, x, w, scale, bias, case[6], 0.1, 'bf16', residual=r, algo=algo, expect_rc=None)
+    if y is None:
+        assert algo == 14 and (case[6] == 2 or case[4] == 32)     # the wide variant is not instantiated there
+        pytest.skip('variant not instantiated for this shape')
+    ref = ref_conv(x, w, scale, bias, case[6], 0.1, residual=r, bf16=True)
+    assert not np.isnan(y).any()
+    np.testing.assert_allclose(y, ref, rtol=1.6e-2, atol=2e-2)
+    assert np.mean(np.abs(y - ref) > 1e-3 * (1 + np.abs(ref))) < 0.02
+
+
+def test_conv_stream_rejects_ineligible(lib, cuda):
+    case = (2, 256, 13, 13, 128, 1, 1, False)
+    x, w, scale, bias, r = _mk(case, 8)
+    run_conv(lib, cuda, x, w, scale, bias, 1, 0.1, 'bf16', algo=13, expect_rc=-2)
+    run_conv(lib, cuda, x[:, :64], w[:, :64], scale, bias, 1, 0.1, 'f32', algo=13, expect_rc=-2)

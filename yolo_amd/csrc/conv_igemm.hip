@@ -362,8 +362,15 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     if (a.res && (d->y_pixel_stride || d->y_batch_stride || d->out_f32)) return YOLO_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (d->algo < 0) return YOLO_EINVAL;
+    if (d->algo == 13 || d->algo == 14) return conv_stream_dispatch(a, d->ksize, d->stride, d->dtype, d->algo, st, nm);
     if (d->algo >= 2) return conv_pipe_dispatch(a, d->ksize, d->stride, d->dtype, d->algo, st, nm);
     if (d->algo == 0) {
+        // small-channel 3x3 layers: the streaming kernel (measured 1.2-1.45x the generic one; the 1x1s and the
+        // 64->128 stride-2 layer are a wash and stay where they were)
+        if (d->ksize == 3 && d->Cin <= 64 && !(d->stride == 2 && d->Cin == 64)) {
+            const int rc = conv_stream_dispatch(a, d->ksize, d->stride, d->dtype, 13, st, nm);
+            if (rc != YOLO_EUNSUPPORTED) return rc;
+        }
         const int pick = conv_auto_algo(a, d->ksize, d->stride, d->dtype);
         if (pick >= 2) {
             ConvArgs b = a;

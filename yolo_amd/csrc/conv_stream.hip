@@ -1,0 +1,268 @@
+// Streaming convolution for the small-channel layers at the top of the network (bf16; 3x3 with Cin <= 64,
+// 1x1 with Cin <= 128; Cout in {32, 64, 128}).  These layers are HBM-bound (a few hundred MB of activations,
+// K <= 576): what matters is that every byte is read once, in long coalesced runs, with enough loads in flight,
+// not the MFMA rate.  The tiled implicit-GEMM kernels spend their time in per-tile set-up / drain there.
+//
+//   * WEIGHTS-STATIONARY: a wave keeps the MFMA A-fragments of its 32 output channels for the whole K
+//     (<= 36 fragments = 144 VGPRs) in registers for the lifetime of the block -- read once from the packed image.
+//   * a block (4 waves = COUT/32 channel slices x 128/COUT pixel groups) owns a column strip of one image and walks
+//     down its output rows; input rows live in a rolling LDS window (each input byte is fetched once per strip),
+//     the next row's loads are in flight (registers) while the current row is multiplied and stored.
+//   * epilogue as in conv_epilogue.h (transpose through a private LDS scratch, 16-byte row stores) with the
+//     residual prefetched before the MFMAs so its latency hides under them.
+// Same packed-weight image, operand order and rounding points as the other convolution kernels.
+#include "common.h"
+#include "conv_args.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+
+struct StreamArgs {
+    const char* x;
+    const char* wp;
+    const float* scale;
+    const float* bias;
+    const char* res;
+    char* y;
+    int N, H, W, Ho, Wo, Cout_pad;
+    int nstrips, strip_w, rows_per_slice;
+    float slope;
+};
+
+template <int KS, int S, int CIN, int COUT, int NI>
+__global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
+    constexpr int WAVES_C = COUT / 32, WAVES_P = 4 / WAVES_C;
+    constexpr int TW = WAVES_P * NI * 32;               // output pixels per step (strip width capacity)
+    constexpr int NTAP = KS * KS, KC = CIN / 16, KSTEPS = NTAP * KC;
+    constexpr int ROWB = CIN * 2, PARTS = ROWB / 16, PITCH = ROWB + 16;
+    constexpr int PAD = KS / 2;
+    constexpr int XW = (TW - 1) * S + KS;
+    constexpr int INUSE = KS, NEW = S, RING = INUSE + NEW;
+    constexpr int XROW = XW * PITCH;
+    constexpr int XU = (NEW * XW * PARTS + 255) / 256;
+    constexpr int SCR = 32 * 144;                        // per-wave epilogue scratch: 32 pixel rows x (32 f32 + pad)
+    __shared__ __attribute__((aligned(16))) char smem[RING * XROW + 4 * SCR];
+    char* xl = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wave_c = wave % WAVES_C, wave_p = wave / WAVES_C;
+    char* scr = smem + RING * XROW + wave * SCR;
+
+    int b = blockIdx.x;
+    const int strip = b % a.nstrips;
+    const int n = b / a.nstrips;
+    const int ox0 = strip * a.strip_w;
+    const int ox_end = min(ox0 + a.strip_w, a.Wo);
+    const int oy0 = blockIdx.y * a.rows_per_slice;
+    const int oy1 = min(oy0 + a.rows_per_slice, a.Ho);
+    if (oy0 >= oy1) return;
+    const int H = a.H, W = a.W, Ho = a.Ho, Wo = a.Wo;
+    const int ix0 = ox0 * S - PAD;
+
+    // ---- the wave's weights: A-fragments of its 32 couts for every K-step, straight from the packed image ----
+    uint4 A[KSTEPS];
+    {
+        const int row = wave_c * 32 + l31;
+        const int swz = (l31 >> 2) & 3;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int tap = ks / KC, kc = ks % KC;
+            const int chunk = kc >> 1, unit = ((kc & 1) * 2 + h) ^ swz;
+            A[ks] = *(const uint4*)(a.wp + ((long long)(chunk * NTAP + tap) * a.Cout_pad + row) * 64 + unit * 16);
+        }
+    }
+    // ---- per-lane epilogue constants (after the transpose a lane owns 8 couts of a pixel row) -------------------
+    const int ecol = lane & 3, erow0 = lane >> 2;
+    const int eco = wave_c * 32 + ecol * 8;
+    float sc[8], bi[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const f32x4 s4 = *(const f32x4*)(a.scale + eco + 4 * q);
+        const f32x4 b4 = *(const f32x4*)(a.bias + eco + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc[4 * q + e] = s4[e]; bi[4 * q + e] = b4[e]; }
+    }
+    const float slope = a.slope;
+    const bool has_res = a.res != nullptr;
+
+    // ---- input staging (registers; loads run one step ahead) ----------------------------------------------------
+    // (a two-step-ahead variant with two register sets was slower: it costs a wave of occupancy per SIMD, and
+    // co-resident blocks hide more latency than the extra step does)
+    uint4 xr[XU];
+    auto load_x = [&](int iy_first) {
+#pragma unroll
+        for (int j = 0; j < XU; ++j) {
+            const int u = tid + j * 256;
+            const int r = u / (XW * PARTS), rem = u - r * (XW * PARTS), px = rem / PARTS, part = rem % PARTS;
+            const int iy = iy_first + r, ix = ix0 + px;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r < NEW && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                v = *(const uint4*)(a.x + (((long long)n * H + iy) * W + ix) * ROWB + part * 16);
+            xr[j] = v;
+        }
+    };
+    auto store_x = [&](int slot_first) {
+#pragma unroll
+        for (int j = 0; j < XU; ++j) {
+            const int u = tid + j * 256;
+            const int r = u / (XW * PARTS), rem = u - r * (XW * PARTS), px = rem / PARTS, part = rem % PARTS;
+            if (r < NEW) {
+                int slot = slot_first + r;
+                if (slot >= RING) slot -= RING;
+                *(uint4*)(xl + slot * XROW + px * PITCH + part * 16) = xr[j];
+            }
+        }
+    };
+
+    // prologue: the KS input rows of the first output row
+    const int iyb0 = oy0 * S - PAD;
+#pragma unroll
+    for (int r0 = 0; r0 < INUSE; r0 += NEW) {
+        load_x(iyb0 + r0);
+        store_x(r0);
+    }
+    __syncthreads();
+
+    const int b_off = (wave_p * NI * 32 + l31) * S * PITCH + h * 16;
+    int slot0 = 0;
+    for (int oy = oy0; oy < oy1; ++oy) {
+        const bool more = oy + 1 < oy1;
+        if (more) load_x(oy * S - PAD + INUSE);
+        // residual prefetch (same addresses as this lane's stores)
+        long long yo[NI][2];
+        uint4 rv[NI][2];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int ox = ox0 + (wave_p * NI + ni) * 32 + erow0 + 16 * k;
+                yo[ni][k] = ox < ox_end ? ((((long long)n * Ho + oy) * Wo + ox) * COUT + eco) * 2 : -1;
+                rv[ni][k] = make_uint4(0, 0, 0, 0);
+                if (has_res && yo[ni][k] >= 0) rv[ni][k] = *(const uint4*)(a.res + yo[ni][k]);
+            }
+
+        f32x16 acc[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh) {
+            int slot = slot0 + kh;
+            if (slot >= RING) slot -= RING;
+            const char* rowp = xl + slot * XROW + b_off;
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw)
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const uint4 bf = *(const uint4*)(rowp + (ni * 32 * S + kw) * PITCH + kc * 32);
+                        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[(kh * KS + kw) * KC + kc]),
+                                                                          __builtin_bit_cast(bf16x8, bf), acc[ni], 0, 0, 0);
+                    }
+                }
+        }
+
+        // ---- epilogue: folded BN, LeakyReLU, residual, one rounding, 16-byte row stores ---------------------------
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[ni][4 * g], acc[ni][4 * g + 1], acc[ni][4 * g + 2], acc[ni][4 * g + 3]};
+                *(f32x4*)(scr + l31 * 144 + (8 * g + 4 * h) * 4) = v;
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f32x4 t4 = *(const f32x4*)(scr + (erow0 + 16 * k) * 144 + (ecol * 8 + 4 * q) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * q + e] = t4[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = v[e] * sc[e] + bi[e];
+                    v[e] = t > 0.f ? t : t * slope;
+                }
+                if (has_res) {
+                    const uint32_t w[4] = {rv[ni][k].x, rv[ni][k].y, rv[ni][k].z, rv[ni][k].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v[2 * q] += bf16_bits_to_f32(w[q] & 0xffffu);
+                        v[2 * q + 1] += bf16_bits_to_f32(w[q] >> 16);
+                    }
+                }
+                if (yo[ni][k] >= 0)
+                    *(uint4*)(a.y + yo[ni][k]) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
+                                                            pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+            }
+        }
+
+        if (more) {
+            int ns = slot0 + INUSE;
+            if (ns >= RING) ns -= RING;
+            store_x(ns);
+        }
+        slot0 += NEW;
+        if (slot0 >= RING) slot0 -= RING;
+        __syncthreads();
+    }
+}
+
+template <int KS, int S, int CIN, int COUT, int NI>
+static int launch_stream(const ConvArgs& c, hipStream_t st, const NameOut* nm) {
+    constexpr int TW = (4 / (COUT / 32)) * NI * 32;
+    if (nm) {
+        snprintf(nm->buf, nm->len, "void conv_stream_kernel<%d, %d, %d, %d, %d>(StreamArgs)", KS, S, CIN, COUT, NI);
+        return YOLO_OK;
+    }
+    StreamArgs a;
+    a.x = c.x; a.wp = c.wp; a.scale = c.scale; a.bias = c.bias; a.res = c.res; a.y = c.y;
+    a.N = c.N; a.H = c.H; a.W = c.W; a.Ho = c.Ho; a.Wo = c.Wo; a.Cout_pad = c.Cout_pad;
+    a.slope = c.slope;
+    a.nstrips = (c.Wo + TW - 1) / TW;
+    a.strip_w = (c.Wo + a.nstrips - 1) / a.nstrips;              // balanced strips (<= TW)
+    const long long bx = (long long)c.N * a.nstrips;
+    long long target = 3072;
+    if (const char* e = getenv("YOLO_STREAM_BLOCKS")) target = atoi(e);
+    long long slices = (target + bx - 1) / bx;                      // ~12 blocks per CU over the launch (several rounds: small tail)
+    if (slices > c.Ho / 8) slices = c.Ho / 8;
+    if (slices < 1) slices = 1;
+    a.rows_per_slice = (int)((c.Ho + slices - 1) / slices);
+    slices = (c.Ho + a.rows_per_slice - 1) / a.rows_per_slice;
+    YOLO_LAUNCH((conv_stream_kernel<KS, S, CIN, COUT, NI>), dim3((unsigned)bx, (unsigned)slices), dim3(256), 0, st, a);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}
+
+// algo 13 (NI = 1) / 14 (NI = 2: twice the strip width per step)
+int conv_stream_dispatch(const ConvArgs& c, int ks, int stride, int dtype, int algo, hipStream_t st, const NameOut* nm) {
+    if (dtype != YOLO_BF16 || c.out_f32) return YOLO_EUNSUPPORTED;
+    if (c.y_ps != c.Cout || c.y_bs != (long long)c.Ho * c.Wo * c.Cout) return YOLO_EUNSUPPORTED;
+    const int ni = algo == 14 ? 2 : 1;
+#define STREAM_CASE(KS_, S_, CIN_, COUT_)                                                        \
+    if (ks == KS_ && stride == S_ && c.Cin == CIN_ && c.Cout == COUT_)                           \
+        return ni == 2 ? launch_stream<KS_, S_, CIN_, COUT_, 2>(c, st, nm) : launch_stream<KS_, S_, CIN_, COUT_, 1>(c, st, nm);
+#define STREAM_CASE1(KS_, S_, CIN_, COUT_)                                                       \
+    if (ks == KS_ && stride == S_ && c.Cin == CIN_ && c.Cout == COUT_ && ni == 1)                \
+        return launch_stream<KS_, S_, CIN_, COUT_, 1>(c, st, nm);
+    STREAM_CASE(3, 1, 32, 64)
+    STREAM_CASE(3, 1, 64, 128)
+    STREAM_CASE1(3, 1, 64, 32)
+    STREAM_CASE1(3, 1, 32, 32)
+    STREAM_CASE(3, 1, 64, 64)
+    STREAM_CASE1(3, 2, 32, 64)
+    STREAM_CASE1(3, 2, 64, 128)
+    STREAM_CASE1(1, 1, 64, 32)
+    STREAM_CASE(1, 1, 32, 64)
+    STREAM_CASE(1, 1, 128, 64)
+    STREAM_CASE(1, 1, 64, 128)
+    STREAM_CASE(1, 1, 64, 64)
+    STREAM_CASE(1, 1, 128, 128)
+#undef STREAM_CASE
+#undef STREAM_CASE1
+    return YOLO_EUNSUPPORTED;
+}
