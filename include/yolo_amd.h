@@ -75,7 +75,7 @@ typedef struct yolo_conv_desc {
     int ksize, stride;
     int dtype;             /* YOLO_F32 | YOLO_BF16: activations and weights                   */
     int out_f32;           /* 1: y is float32 (head logits)                                   */
-    float slope;           /* LeakyReLU negative slope; 1.0f = linear                         */
+    float slope;           /* LeakyReLU negative slope in [0, 1]; 1.0f = linear               */
     long long y_batch_stride; /* elements between images in y; 0 = dense Ho*Wo*Cout           */
     long long y_pixel_stride; /* elements between pixels in y; 0 = dense Cout                 */
     int algo;              /* 0 = library heuristic; 1 = generic kernel; >= 2 = a specific pipelined

@@ -28,16 +28,18 @@ __host__ __device__ inline int round_up(int a, int b) { return (a + b - 1) / b *
 __host__ __device__ inline long long round_up_ll(long long a, long long b) { return (a + b - 1) / b * b; }
 
 // float -> bf16 bits, round-to-nearest-even (matches torch .to(bfloat16) for finite values).
-__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
-__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+// float -> bf16, round-to-nearest-even: gfx950's v_cvt_pk_bf16_f32 (one VALU op per PAIR; the bit-twiddled
+// version costs ~20 and was a third of the conv epilogue's instruction count).
+typedef __attribute__((ext_vector_type(2))) float yolo_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 yolo_bf16x2;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+    const yolo_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, yolo_bf16x2));
 }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) { return pack_bf16x2(f, 0.f) & 0xffffu; }
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+// LeakyReLU for 0 <= slope <= 1 (the dispatchers reject other slopes): max(t, t*slope), two VALU ops
+__device__ __forceinline__ float leaky(float t, float slope) { return fmaxf(t, t * slope); }
 
 static inline int elem_size(int dtype) { return dtype == YOLO_BF16 ? 2 : 4; }
 // channels held by one 64-byte K-chunk

@@ -48,7 +48,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                     for (int e = 0; e < 4; ++e) {
                         if (co + e >= a.Cout) continue;
                         float t = acc[mi][ni][4 * g + e] * sc[e] + bi[e];
-                        t = t > 0.f ? t : t * slope;
+                        t = leaky(t, slope);
                         if (a.out_f32) {
                             ((float*)a.y)[o + e] = t;
                         } else if constexpr (ES == 2) {
@@ -113,7 +113,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
 #pragma unroll
             for (int e = 0; e < CPL; ++e) {
                 const float t = v[e] * sc[e] + bi[e];
-                v[e] = t > 0.f ? t : t * slope;
+                v[e] = leaky(t, slope);
             }
             uint4 ov;
             if constexpr (ES == 2) {

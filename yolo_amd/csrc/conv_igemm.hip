@@ -337,6 +337,7 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     if (d->stride != 1 && d->stride != 2) return YOLO_EUNSUPPORTED;
     if (d->ksize == 1 && d->stride != 1) return YOLO_EUNSUPPORTED;
     if (d->dtype != YOLO_F32 && d->dtype != YOLO_BF16) return YOLO_EINVAL;
+    if (!(d->slope >= 0.f && d->slope <= 1.f)) return YOLO_EINVAL;       // LeakyReLU is computed as max(t, t*slope)
     const int es = elem_size(d->dtype);
     if ((d->Cin * es) % 16) return YOLO_EUNSUPPORTED;                 // 16-byte K units
     if (!d->out_f32 && (d->Cout % 4)) return YOLO_EUNSUPPORTED;       // 4-channel store groups

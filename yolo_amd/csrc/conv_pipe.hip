@@ -22,6 +22,19 @@
 
 __device__ __attribute__((aligned(64))) unsigned int yolo_zero_page[16];
 
+#ifdef YOLO_STAMP
+// Instrumented build only (make stamp): per-block shader-clock stamps of the phases of conv_pipe_kernel.
+__device__ long long yolo_stamps[8192 * 8];
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) yolo_stamps[blockIdx.x * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define STAMP_ID() do { if (threadIdx.x == 0 && blockIdx.x < 8192) { unsigned id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); yolo_stamps[blockIdx.x * 8 + 7] = (long long)id | ((long long)(xcc & 0xf) << 32); yolo_stamps[blockIdx.x * 8 + 6] = wall_clock64(); } } while (0)
+extern "C" int yolo_debug_read_stamps(long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(yolo_stamps), sizeof(long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define STAMP(i)
+#define STAMP_ID()
+#endif
+
 typedef __attribute__((address_space(3))) char lds_char;
 
 // One 16-byte-per-lane LDS-DMA: LDS[lds_dst + lane*16 .. +16) = *gsrc (per-lane source).
@@ -99,6 +112,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     const int l31 = lane & 31, h = lane >> 5;
     const int wave_p = wave % WAVES_P, wave_c = wave / WAVES_P;
 
+    STAMP(0); STAMP_ID();
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_p = fdiv(lid, a.d_tc);
     const int tile_c = lid - tile_p * a.tiles_c;
@@ -216,6 +230,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         wait_vmcnt<WL + XL>();
     }
     __builtin_amdgcn_s_barrier();
+    STAMP(1);
 
     constexpr int NM = 2 * MI * NI;                     // MFMA "steps" per phase (one 16-byte operand pair each)
     auto phase = [&](auto shift_c, int c, int q, int gp) {
@@ -273,6 +288,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
             phase(std::integral_constant<int, 1>{}, c, q, gp);
         }
     }
+    STAMP(2);
     wait_vmcnt<0>();     // the tail's dead DMAs must land before the block's LDS is released
 
     // ---- epilogue (conv_epilogue.h): every wave transposes its slab through its own LDS scratch ------
@@ -293,7 +309,13 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         }
         yoff[ni] = (i < a.total_i) ? (long long)n * a.y_bs + (long long)pix * a.y_ps : -1;
     }
+    STAMP(3);
     conv_epilogue<T, MI, NI>(acc, yoff, smem + wave * YOLO_EPI_WAVE_BYTES, a, co0 + wave_c * MI * 32, lane);
+    STAMP(4);
+#ifdef YOLO_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(5);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

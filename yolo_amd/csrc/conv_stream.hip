@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float t = v[e] * sc[e] + bi[e];
-                    v[e] = t > 0.f ? t : t * slope;
+                    v[e] = leaky(t, slope);
                 }
                 if (has_res) {
                     const uint32_t w[4] = {rv[ni][k].x, rv[ni][k].y, rv[ni][k].z, rv[ni][k].w};

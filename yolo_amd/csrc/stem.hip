@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float t = acc[mi][ni][4 * g + e] * sc[e] + bi[e];
-                        v[e] = t > 0.f ? t : t * slope;
+                        v[e] = leaky(t, slope);
                     }
                     *(uint2*)(ot + (ni * 32 + l31) * OP + co * 2) =
                         make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
@@ -138,6 +138,7 @@ extern "C" int yolo_stem_conv_fwd(const float* x_nchw, const float* w_oihw, cons
                                   void* y, int N, int H, int W, int Cin, int Cout, int dtype, float slope,
                                   void* stream) {
     if (!x_nchw || !w_oihw || !scale || !bias || !y || N <= 0 || H <= 0 || W <= 0) return YOLO_EINVAL;
+    if (!(slope >= 0.f && slope <= 1.f)) return YOLO_EINVAL;
     if (Cin != 3 || Cout <= 0 || (Cout % 4) || Cout > 64) return YOLO_EUNSUPPORTED;
     if (dtype != YOLO_BF16) return YOLO_EUNSUPPORTED;      // the fp32 path goes through the generic kernel
     const int tiles_x = (W + STEM_TW - 1) / STEM_TW, tiles_y = (H + STEM_TH - 1) / STEM_TH;
