@@ -161,6 +161,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--tune-cache', default=None, help='JSON file remembering the measured per-layer kernel choices')
+    ap.add_argument('--post', default='top1', choices=['top1', 'nms'],
+                    help="post-processing inside the timed step: 'top1' = the reference's predict (decode + per-image arg-max);"
+                         " 'nms' = decode + per-class greedy NMS (BASELINE configs[4])")
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                     help="'infer' = BASELINE configs[1] (the headline metric); 'train' = configs[2]/[3]: one training "
                          "step (fwd + loss + bwd + train-mode BN + gradient all-reduce + Adam) per step")
@@ -197,6 +200,10 @@ def main():
 
     def step():
         outs = net(x)
+        if args.post == 'nms':
+            rows = det.decode(outs)
+            kept, ks, cnt = det.nms(rows, mode='class')
+            return kept, cnt
         return det.predict_device(outs)
 
     def fence():
@@ -222,13 +229,13 @@ def main():
 
     out = {
         'metric': 'images/sec at %dx%d bs=%d per GPU (Darknet-53 spec + 3-scale YOLO head forward, anchor '
-                  'decode + top-1)' % (size[0], size[1], B),
+                  'decode + %s)' % (size[0], size[1], B, 'per-class NMS' if args.post == 'nms' else 'top-1'),
         'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1]: Darknet-53 spec layers [1,2,8,8,4] channels [32..1024] + '
                                '3-scale YOLO head (A=3, C=30) forward, random Xavier weights, %dx%d, bs=%d per GPU, '
-                               '+ decode/top-1' % (size[0], size[1], B),
+                               '+ decode/%s' % (size[0], size[1], B, 'per-class NMS (valid 0.01, IoU 0.45, top-k 400, keep 100)' if args.post == 'nms' else 'top-1'),
                    'global_batch': B * world, 'image': list(size),
                    'parallelism': 'dp%d (batch-sharded, no data-path collective)' % world,
                    'gflop_per_image': round(net.graph.flops(*size) / 1e9, 2)},

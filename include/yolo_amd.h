@@ -138,14 +138,18 @@ int yolo_iou_ltrb_vs_yxhw(const float* boxes, const float* target, float* iou, i
  * SURVEY App. A.8).  mode 0: score = sigmoid(obj), class-agnostic; mode 1: candidates are
  * (box, class) pairs scored sigmoid(obj)*softmax(cls)_c, suppression within a class.
  * kept (B, post_nms) int32 candidate ids in score order padded with -1; kept_scores same
- * shape; kept_count (B).  workspace: yolo_nms_workspace_bytes(). */
+ * shape; kept_count (B).  workspace: yolo_nms_workspace_bytes() = the score array + the selection workspace. */
 long long yolo_nms_workspace_bytes(int B, int nbox, int ncls, int mode, int topk);
 /* The two halves of yolo_nms, exposed so the score array can be inspected / injected:
- * scores (B, nbox) [mode 0] or (B, nbox*ncls) [mode 1]; candidate id = box*cand_per_box + class. */
+ * scores (B, nbox) [mode 0] or (B, nbox*ncls) [mode 1]; candidate id = box*cand_per_box + class.
+ * select_workspace (yolo_nms_select_workspace_bytes(B), may be NULL): with it the top-k pre-selection runs as
+ * chip-wide passes over all images instead of one block per image (same result; ~6x faster at 608x608). */
+long long yolo_nms_select_workspace_bytes(int B);
 int yolo_nms_scores(const float* rows, float* scores, int B, int nbox, int C, int mode, void* stream);
 int yolo_nms_from_scores(const float* rows, const float* scores, int B, int nbox, int C,
                          int cand_per_box, float valid_thresh, float iou_thresh, int topk,
-                         int post_nms, int* kept, float* kept_scores, int* kept_count, void* stream);
+                         int post_nms, int* kept, float* kept_scores, int* kept_count,
+                         void* select_workspace, void* stream);
 int yolo_nms(const float* rows, int B, int nbox, int C, int mode, float valid_thresh,
              float iou_thresh, int topk, int post_nms, int* kept, float* kept_scores,
              int* kept_count, void* workspace, void* stream);

@@ -149,3 +149,36 @@ def test_predict_LP_config1(cuda):
     ref, best = od.predict_LP(out, [40, 30, 20])
     assert best == 3 * 16 + 5
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('mode', ['obj', 'class'])
+def test_nms_chip_wide_selection_equals_single_block(cuda, mode):
+    """The workspace path (grid-wide radix passes + per-image list) and the single-block selection keep the same ids."""
+    det, outs, syxhw, _ = _setup((608, 608), 5, 31, cuda, scale=2.0)
+    dev = [torch.from_numpy(o).to(cuda) for o in outs]
+    rows = det.decode(dev)
+    scores = det.nms_scores(rows, mode)
+    for kw in ({}, {'topk': 37, 'post_nms': 20}, {'valid_thresh': 0.3}, {'topk': 512, 'post_nms': 200, 'iou_thresh': 0.2}):
+        a = det.nms(rows, mode, scores=scores, fast=True, **kw)
+        b = det.nms(rows, mode, scores=scores, fast=False, **kw)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
+def test_nms_list_overflow_falls_back(cuda):
+    """All-equal scores (zero logits) put every candidate in one fine bucket: the list overflows and the
+    single-block selection (ids ascending among ties) must take over on device."""
+    det, outs, syxhw, _ = _setup((416, 416), 2, 32, cuda)
+    for o in outs:
+        o[...] = 0.0
+    outs[0][1, 7, 1, 0] = 3.0                     # image 1: one candidate above the sea of ties
+    dev = [torch.from_numpy(o).to(cuda) for o in outs]
+    rows = det.decode(dev)
+    for mode in ('obj', 'class'):
+        scores = det.nms_scores(rows, mode)
+        a = det.nms(rows, mode, scores=scores, fast=True)
+        b = det.nms(rows, mode, scores=scores, fast=False)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        rk, _ = od.nms(rows[1].cpu().numpy(), mode, scores=scores[1].cpu().numpy())
+        assert a[0][1, :int(a[2][1])].cpu().tolist() == rk.tolist()

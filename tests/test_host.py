@@ -46,12 +46,13 @@ def test_abi_host_only_queries(lib):
     assert lib.yolo_packed_weight_bytes(64, 32, 3, L.BF16) == 1 * 9 * lib.yolo_padded_channels(64) * 64
     assert lib.yolo_packed_weight_bytes(64, 32, 3, L.F32) == 2 * 9 * lib.yolo_padded_channels(64) * 64
     assert lib.yolo_packed_weight_bytes(64, 32, 5, L.BF16) < 0
-    assert lib.yolo_nms_workspace_bytes(2, 10647, 24, 1, 400) == 2 * 10647 * 24 * 4
+    assert lib.yolo_nms_workspace_bytes(2, 10647, 24, 1, 400) == 2 * 10647 * 24 * 4 + lib.yolo_nms_select_workspace_bytes(2)
+    assert lib.yolo_nms_select_workspace_bytes(2) > 0 and lib.yolo_nms_select_workspace_bytes(0) == -1
     # argument validation happens before any launch: NULL pointers / bad shapes are rejected on CPU too
     d = L.ConvDesc()
     assert lib.yolo_conv_fwd(C.byref(d), None) == -1
     assert lib.yolo_decode(None, None, 1, 30, None, None) == -1
-    assert lib.yolo_nms_from_scores(None, None, 1, 1, 30, 1, 0.01, 0.45, 400, 100, None, None, None, None) == -1
+    assert lib.yolo_nms_from_scores(None, None, 1, 1, 30, 1, 0.01, 0.45, 400, 100, None, None, None, None, None) == -1
     # kernel-name query is host-only
     d.x = d.w_packed = d.scale = d.bias = d.y = 1
     d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.dtype = 32, 13, 13, 1024, 2048, 3, 1, L.BF16

@@ -3,6 +3,7 @@
 // evaluation (no fused multiply-add), which is what makes index parity exact.
 #include "common.h"
 #include <float.h>
+#include <string.h>
 
 struct GridDev {
     int nscale, A, img_h, img_w;
@@ -194,26 +195,40 @@ extern "C" int yolo_iou_ltrb_vs_yxhw(const float* boxes, const float* target, fl
 // ---- NMS scores ------------------------------------------------------------------------------
 // mode 0: scores (B, nbox) = sigmoid(obj) column of rows.  mode 1: scores (B, nbox*ncls) =
 // sigmoid(obj) * softmax(cls)_c.  One thread per box.
-__global__ void nms_scores_kernel(const float* __restrict__ rows, float* __restrict__ scores, int C, int ncls,
-                                  int mode, long long nboxes) {
-    const long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (k >= nboxes) return;
-    const float* p = rows + k * C;
-    if (mode == 0) { scores[k] = p[0]; return; }
-    float m = -FLT_MAX;
-    for (int c = 0; c < ncls; ++c) m = fmaxf(m, p[6 + c]);
-    float sum = 0.f;
-    for (int c = 0; c < ncls; ++c) sum += expf(p[6 + c] - m);
-    const float obj = p[0];
-    for (int c = 0; c < ncls; ++c) scores[k * ncls + c] = obj * (expf(p[6 + c] - m) / sum);
+__global__ __launch_bounds__(256) void nms_scores_kernel(const float* __restrict__ rows, float* __restrict__ scores, int C,
+                                                         int ncls, int mode, long long nboxes) {
+    // 256 boxes per block, staged through LDS so that both the row reads and the score writes are coalesced
+    // (one thread per box walking its own 120-byte row ran at 1/18 of the HBM rate)
+    extern __shared__ float sm[];                        // 256*C floats of rows, then 256*ncls of scores
+    const long long k0 = blockIdx.x * 256LL;
+    const int nb = (int)min(256LL, nboxes - k0);
+    if (mode == 0) {
+        if ((int)threadIdx.x < nb) scores[k0 + threadIdx.x] = rows[(k0 + threadIdx.x) * C];
+        return;
+    }
+    for (int i = threadIdx.x; i < nb * C; i += 256) sm[i] = rows[k0 * C + i];
+    __syncthreads();
+    float* so = sm + 256 * C;
+    if ((int)threadIdx.x < nb) {
+        const float* p = sm + threadIdx.x * C;
+        float m = -FLT_MAX;
+        for (int c = 0; c < ncls; ++c) m = fmaxf(m, p[6 + c]);
+        float sum = 0.f;
+        for (int c = 0; c < ncls; ++c) sum += expf(p[6 + c] - m);
+        const float obj = p[0];
+        for (int c = 0; c < ncls; ++c) so[threadIdx.x * ncls + c] = obj * (expf(p[6 + c] - m) / sum);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb * ncls; i += 256) scores[k0 * ncls + i] = so[i];
 }
 
 extern "C" int yolo_nms_scores(const float* rows, float* scores, int B, int nbox, int C, int mode, void* stream) {
     if (!rows || !scores || B <= 0 || nbox <= 0 || C < 6) return YOLO_EINVAL;
     if (mode == 1 && C <= 6) return YOLO_EINVAL;
     const long long nboxes = (long long)B * nbox;
-    YOLO_LAUNCH(nms_scores_kernel, dim3((unsigned)((nboxes + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       rows, scores, C, C - 6, mode, nboxes);
+    if (C > 96) return YOLO_EUNSUPPORTED;                      // LDS staging: 256 boxes x (C + ncls) floats
+    YOLO_LAUNCH(nms_scores_kernel, dim3((unsigned)((nboxes + 255) / 256)), dim3(256),
+                (size_t)256 * (C + (C - 6)) * sizeof(float), (hipStream_t)stream, rows, scores, C, C - 6, mode, nboxes);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
@@ -228,6 +243,105 @@ extern "C" int yolo_nms_scores(const float* rows, float* scores, int B, int nbox
 //      walks the candidates in order OR-ing rows of the matrix (lane w owns 64-bit word w).
 constexpr int NMS_MAXK = 512;
 constexpr int NMS_THREADS = 1024;
+// Chip-wide pre-selection (optional workspace): the single block per image above spends its time streaming the
+// score array three times (546k candidates per image at 608x608, 64 blocks on 256 CUs).  With a workspace the
+// same radix selection runs as grid-wide passes over all images -- 11-bit histogram, 11 more bits inside the
+// selected bucket, then every valid candidate at or above the 22-bit threshold is appended to a per-image list
+// (<= NMS_CAP entries; top-k plus one fine bucket) -- and the per-image block only sorts that list.  Exactly the
+// same (score desc, id asc) order: the list is sorted by the same composite key.  A list that overflows (massive
+// ties, e.g. the all-equal scores of a zero input) falls back to the single-block selection, decided on device.
+constexpr int NMS_CAP = 4096;
+constexpr int NMS_WS_PER_IMAGE = (2 * 2048 + 16) * 4 + NMS_CAP * 8;     // hist x2, sel[8] + cnt + pad, list
+
+__global__ __launch_bounds__(256) void nms_hist_kernel(const float* __restrict__ scores, long long ncand,
+                                                       unsigned vbits, int pass, unsigned* __restrict__ hist,
+                                                       const unsigned* __restrict__ sel, long long per_block) {
+    __shared__ unsigned h[2048];
+    const int b = blockIdx.y;
+    const unsigned* sl = sel + b * 16;
+    if (pass == 1 && sl[4]) return;                       // fewer valid candidates than top-k: everything is taken
+    for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0;
+    __syncthreads();
+    const float* sc = scores + (long long)b * ncand;
+    const long long i0 = blockIdx.x * per_block, i1 = min(i0 + per_block, ncand);
+    const unsigned q1 = pass == 1 ? sl[0] : 0;
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const unsigned u = __float_as_uint(sc[i]);
+        if (u >= vbits && !(u & 0x80000000u)) {
+            if (pass == 0) atomicAdd(&h[u >> 21], 1u);
+            else if ((u >> 21) == q1) atomicAdd(&h[(u >> 10) & 2047u], 1u);
+        }
+    }
+    __syncthreads();
+    unsigned* gh = hist + ((long long)b * 2 + pass) * 2048;
+    for (int i = threadIdx.x; i < 2048; i += 256)
+        if (h[i]) atomicAdd(&gh[i], h[i]);
+}
+
+// one wavefront per image: the bucket in which the cumulative count from the top reaches `need`
+__global__ __launch_bounds__(64) void nms_pick_kernel(const unsigned* __restrict__ hist, unsigned* __restrict__ sel,
+                                                      int pass, int topk) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const unsigned* gh = hist + ((long long)b * 2 + pass) * 2048;
+    unsigned* sl = sel + b * 16;
+    if (pass == 1 && sl[4]) return;
+    const unsigned need = pass == 0 ? (unsigned)topk : sl[2];
+    unsigned hv[32], chunk = 0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) { hv[q] = gh[lane * 32 + q]; chunk += hv[q]; }
+    unsigned above = 0, total = 0;                         // candidates in chunks above this lane's / in all chunks
+    for (int l = 0; l < 64; ++l) {
+        const unsigned c = __shfl(chunk, l, 64);
+        if (l > lane) above += c;
+        total += c;
+    }
+    if (total < need) {                                    // (only possible in pass 0)
+        if (lane == 0) { sl[4] = 1; sl[5] = 0; }
+        return;
+    }
+    if (above < need && above + chunk >= need) {           // exactly one lane
+        unsigned cum = above;
+        int q = 31;
+        for (; q > 0; --q) {
+            if (cum + hv[q] >= need) break;
+            cum += hv[q];
+        }
+        const unsigned bucket = (unsigned)(lane * 32 + q);
+        if (pass == 0) { sl[0] = bucket; sl[1] = cum; sl[2] = need - cum; sl[4] = 0; }
+        else { sl[3] = bucket; sl[5] = (sl[0] << 21) | (bucket << 10); }
+    }
+}
+
+__global__ __launch_bounds__(256) void nms_collect_kernel(const float* __restrict__ scores, long long ncand,
+                                                          unsigned vbits, unsigned* __restrict__ sel,
+                                                          unsigned long long* __restrict__ list, long long per_block) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    unsigned* sl = sel + b * 16;
+    const unsigned thr = sl[4] ? vbits : max(vbits, sl[5]);
+    unsigned* cnt = sl + 8;
+    const float* sc = scores + (long long)b * ncand;
+    unsigned long long* out = list + (long long)b * NMS_CAP;
+    const long long i0 = blockIdx.x * per_block, i1 = min(i0 + per_block, ncand);
+    for (long long base = i0; base < i1; base += 256) {
+        const long long i = base + threadIdx.x;
+        unsigned u = 0;
+        bool take = false;
+        if (i < i1) {
+            u = __float_as_uint(sc[i]);
+            take = u >= thr && !(u & 0x80000000u);
+        }
+        const unsigned long long bal = __ballot(take);
+        if (bal) {
+            unsigned basepos = 0;
+            const int leader = __ffsll((long long)bal) - 1;
+            if (lane == leader) basepos = atomicAdd(cnt, (unsigned)__popcll(bal));
+            basepos = __shfl(basepos, leader, 64);
+            const unsigned pos = basepos + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+            if (take && pos < NMS_CAP) out[pos] = ((unsigned long long)u << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+        }
+    }
+}
+
 
 __device__ __forceinline__ float box_iou(const float4 a, const float4 b) {
     const float iw = fmaxf(0.f, fminf(a.z, b.z) - fmaxf(a.x, b.x));
@@ -241,9 +355,11 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
                                                           const float* __restrict__ scores, int nbox, int C, int cpb,
                                                           float valid_thresh, float iou_thresh, int topk, int post_nms,
                                                           int* __restrict__ kept, float* __restrict__ kept_scores,
-                                                          int* __restrict__ kept_count) {
+                                                          int* __restrict__ kept_count,
+                                                          const unsigned long long* __restrict__ list,
+                                                          const unsigned* __restrict__ sel) {
     __shared__ unsigned hist[2048];
-    __shared__ unsigned long long keys[NMS_MAXK];
+    __shared__ unsigned long long keys[NMS_CAP];
     __shared__ float4 cbox[NMS_MAXK];
     __shared__ unsigned long long supp[NMS_MAXK][NMS_MAXK / 64];
     __shared__ unsigned sh_sel, sh_above, sh_cnt, sh_eqbase;
@@ -255,7 +371,17 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
     const float* sc = scores + (long long)b * ncand;
     const float* rw = rows + (long long)b * nbox * C;
     const unsigned vbits = __float_as_uint(fmaxf(valid_thresh, 0.f));
-
+    unsigned n;
+    int sortn;
+    const unsigned nlist = list ? sel[b * 16 + 8] : 0xffffffffu;
+    if (nlist <= (unsigned)NMS_CAP) {
+    // ---- 1'. pre-selected list (chip-wide passes above): sort it, the first top-k keys are the selection ------
+    for (int i = tid; i < NMS_CAP; i += NMS_THREADS) keys[i] = (unsigned)i < nlist ? list[(long long)b * NMS_CAP + i] : 0ull;
+    n = min(nlist, (unsigned)topk);
+    sortn = 64;
+    while ((unsigned)sortn < nlist) sortn <<= 1;
+    __syncthreads();
+    } else {
     // ---- 1. k-th largest valid score via 3 histogram passes -------------------------------
     // scores are >= 0, so their uint bit patterns order like the floats.
     unsigned prefix = 0;     // bits fixed so far
@@ -334,22 +460,24 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
         }
     }
     __syncthreads();
-    unsigned n = all_taken ? min(sh_cnt, (unsigned)NMS_MAXK) : (unsigned)topk;
+    n = all_taken ? min(sh_cnt, (unsigned)NMS_MAXK) : (unsigned)topk;
     if (!all_taken) n = min(n, above + min(sh_eqbase, need_eq));
     n = min(n, (unsigned)topk);
-
-    // ---- 2. bitonic sort, descending ---------------------------------------------------------
     for (int i = tid; i < NMS_MAXK; i += NMS_THREADS)
         if ((unsigned)i >= n) keys[i] = 0ull;
+    sortn = NMS_MAXK;
     __syncthreads();
-    for (int k = 2; k <= NMS_MAXK; k <<= 1) {
+    }
+
+    // ---- 2. bitonic sort, descending ---------------------------------------------------------
+    for (int k = 2; k <= sortn; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            if (tid < NMS_MAXK) {
-                const int ixj = tid ^ j;
-                if (ixj > tid) {
-                    const unsigned long long a = keys[tid], c = keys[ixj];
-                    const bool desc = (tid & k) == 0;
-                    if (desc ? (a < c) : (a > c)) { keys[tid] = c; keys[ixj] = a; }
+            for (int t = tid; t < sortn; t += NMS_THREADS) {
+                const int ixj = t ^ j;
+                if (ixj > t) {
+                    const unsigned long long a = keys[t], c = keys[ixj];
+                    const bool desc = (t & k) == 0;
+                    if (desc ? (a < c) : (a > c)) { keys[t] = c; keys[ixj] = a; }
                 }
             }
             __syncthreads();
@@ -403,21 +531,53 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
     }
 }
 
+extern "C" long long yolo_nms_select_workspace_bytes(int B) {
+    if (B <= 0) return YOLO_EINVAL;
+    return (long long)B * NMS_WS_PER_IMAGE;
+}
+
 extern "C" long long yolo_nms_workspace_bytes(int B, int nbox, int ncls, int mode, int topk) {
     (void)topk;
     if (B <= 0 || nbox <= 0) return YOLO_EINVAL;
-    return (long long)B * nbox * (mode == 1 ? ncls : 1) * 4;
+    return ((long long)B * nbox * (mode == 1 ? ncls : 1) * 4 + 15) / 16 * 16 + yolo_nms_select_workspace_bytes(B);
 }
 
 extern "C" int yolo_nms_from_scores(const float* rows, const float* scores, int B, int nbox, int C,
                                     int cand_per_box, float valid_thresh, float iou_thresh, int topk, int post_nms,
-                                    int* kept, float* kept_scores, int* kept_count, void* stream) {
+                                    int* kept, float* kept_scores, int* kept_count, void* select_workspace,
+                                    void* stream) {
     if (!rows || !scores || !kept || !kept_scores || !kept_count) return YOLO_EINVAL;
     if (B <= 0 || nbox <= 0 || C < 5 || cand_per_box < 1 || post_nms < 1) return YOLO_EINVAL;
     if (topk < 1 || topk > NMS_MAXK) return YOLO_EUNSUPPORTED;
-    if ((long long)nbox * cand_per_box > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
-    YOLO_LAUNCH(nms_kernel, dim3(B), dim3(NMS_THREADS), 0, (hipStream_t)stream, rows, scores, nbox, C,
-                       cand_per_box, valid_thresh, iou_thresh, topk, post_nms, kept, kept_scores, kept_count);
+    const long long ncand = (long long)nbox * cand_per_box;
+    if (ncand > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned long long* list = nullptr;
+    unsigned* sel = nullptr;
+    if (select_workspace) {
+        unsigned* hist = (unsigned*)select_workspace;
+        sel = hist + (long long)B * 2 * 2048;
+        list = (const unsigned long long*)(sel + (long long)B * 16);
+        (void)hipGetLastError();
+        (void)hipMemsetAsync(select_workspace, 0, (size_t)B * (2 * 2048 + 16) * 4, st);
+        float vt = valid_thresh > 0.f ? valid_thresh : 0.f;
+        unsigned vbits;
+        memcpy(&vbits, &vt, 4);
+        int G = 1024 / B;                                     // ~1024 blocks over the chip
+        if (G < 1) G = 1;
+        if (G > 64) G = 64;
+        long long per = (ncand + G - 1) / G;
+        per = (per + 255) / 256 * 256;
+        G = (int)((ncand + per - 1) / per);
+        YOLO_LAUNCH(nms_hist_kernel, dim3(G, B), dim3(256), 0, st, scores, ncand, vbits, 0, hist, (const unsigned*)sel, per);
+        YOLO_LAUNCH(nms_pick_kernel, dim3(B), dim3(64), 0, st, (const unsigned*)hist, sel, 0, topk);
+        YOLO_LAUNCH(nms_hist_kernel, dim3(G, B), dim3(256), 0, st, scores, ncand, vbits, 1, hist, (const unsigned*)sel, per);
+        YOLO_LAUNCH(nms_pick_kernel, dim3(B), dim3(64), 0, st, (const unsigned*)hist, sel, 1, topk);
+        YOLO_LAUNCH(nms_collect_kernel, dim3(G, B), dim3(256), 0, st, scores, ncand, vbits, sel,
+                    (unsigned long long*)list, per);
+    }
+    YOLO_LAUNCH(nms_kernel, dim3(B), dim3(NMS_THREADS), 0, st, rows, scores, nbox, C, cand_per_box, valid_thresh,
+                iou_thresh, topk, post_nms, kept, kept_scores, kept_count, list, (const unsigned*)sel);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
@@ -427,10 +587,13 @@ extern "C" int yolo_nms(const float* rows, int B, int nbox, int C, int mode, flo
                         void* stream) {
     if (!workspace) return YOLO_EINVAL;
     if (mode != 0 && mode != 1) return YOLO_EINVAL;
+    if (B <= 0 || nbox <= 0 || C < 6) return YOLO_EINVAL;
     int rc = yolo_nms_scores(rows, (float*)workspace, B, nbox, C, mode, stream);
     if (rc) return rc;
+    const long long sbytes = (long long)B * nbox * (mode == 1 ? C - 6 : 1) * 4;
     return yolo_nms_from_scores(rows, (const float*)workspace, B, nbox, C, mode == 1 ? C - 6 : 1, valid_thresh,
-                                iou_thresh, topk, post_nms, kept, kept_scores, kept_count, stream);
+                                iou_thresh, topk, post_nms, kept, kept_scores, kept_count,
+                                (char*)workspace + (sbytes + 15) / 16 * 16, stream);
 }
 
 // ---- LPD plumbing (BASELINE config 1): LicencePlateDetectioin.predict_LP, LP_detection.py:147-162 --------

@@ -45,6 +45,7 @@ class Detector(object):
         self.C = sp[-1]
         self.device = torch.device(device)
         self._lib = L.load()
+        self._nms_ws = {}
 
     def _merged(self, outs):
         """Accepts the list of per-scale outputs (fine->coarse) or an already merged (B,N,A,C) tensor."""
@@ -93,7 +94,7 @@ class Detector(object):
         L.check(self._lib.yolo_nms_scores(L.ptr(rows), L.ptr(scores), B, nbox, Cc, md, L.stream_ptr()), 'nms_scores')
         return scores
 
-    def nms(self, rows, mode='class', valid_thresh=0.01, iou_thresh=0.45, topk=400, post_nms=100, scores=None):
+    def nms(self, rows, mode='class', valid_thresh=0.01, iou_thresh=0.45, topk=400, post_nms=100, scores=None, fast=True):
         """Greedy NMS.  Returns (kept ids (B,post_nms) int32 padded with -1,
         kept scores, kept count).  Candidate id = box*ncls + class in 'class' mode, box in 'obj' mode."""
         rows = rows.contiguous()
@@ -101,11 +102,14 @@ class Detector(object):
         cpb = (Cc - 6) if mode == 'class' else 1
         if scores is None:
             scores = self.nms_scores(rows, mode)
+        ws = self._nms_ws.get(B) if fast else None
+        if fast and ws is None:
+            ws = self._nms_ws[B] = torch.empty(self._lib.yolo_nms_select_workspace_bytes(B), dtype=torch.uint8, device=rows.device)
         kept = torch.empty((B, post_nms), dtype=torch.int32, device=rows.device)
         ks = torch.empty((B, post_nms), dtype=torch.float32, device=rows.device)
         cnt = torch.empty((B,), dtype=torch.int32, device=rows.device)
         L.check(self._lib.yolo_nms_from_scores(L.ptr(rows), L.ptr(scores), B, nbox, Cc, cpb, valid_thresh, iou_thresh,
-                                               topk, post_nms, L.ptr(kept), L.ptr(ks), L.ptr(cnt), L.stream_ptr()),
+                                               topk, post_nms, L.ptr(kept), L.ptr(ks), L.ptr(cnt), L.ptr(ws), L.stream_ptr()),
                 'nms')
         return kept, ks, cnt
 

@@ -54,7 +54,8 @@ SIGNATURES = {
     'yolo_iou_ltrb_vs_yxhw': (_i, [_vp, _vp, _vp, _i, _vp]),
     'yolo_nms_workspace_bytes': (_ll, [_i, _i, _i, _i, _i]),
     'yolo_nms_scores': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    'yolo_nms_from_scores': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp]),
+    'yolo_nms_select_workspace_bytes': (_ll, [_i]),
+    'yolo_nms_from_scores': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'yolo_nms': (_i, [_vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'yolo_pack_conv_weights_dgrad': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'yolo_bn_train_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _f, _f, _i, _vp]),
