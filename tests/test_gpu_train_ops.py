@@ -126,7 +126,13 @@ def test_upcat_bwd(lib, cuda):
                                   (4, 256, 26, 26, 192, 3, 1), (2, 32, 26, 26, 64, 3, 2),
                                   # strip kernel (3x3, Cin <= 64): several strips / row slices, ragged widths, channel tails
                                   (1, 8, 70, 45, 32, 3, 1), (2, 40, 37, 66, 72, 3, 1), (1, 64, 50, 33, 128, 3, 2),
-                                  (1, 24, 41, 71, 40, 3, 2), (40, 32, 9, 9, 64, 3, 1)])
+                                  (1, 24, 41, 71, 40, 3, 2), (40, 32, 9, 9, 64, 3, 1),
+                                  # row-group kernel (3x3 stride 1, Cin > 64): every (TH, K-steps) variant, ragged
+                                  # heights (H % TH != 0), channel tails, several images and row slices
+                                  (3, 128, 13, 13, 96, 3, 1), (2, 72, 17, 19, 200, 3, 1), (2, 128, 11, 26, 64, 3, 1),
+                                  (1, 80, 9, 38, 72, 3, 1), (1, 96, 7, 32, 64, 3, 1), (1, 128, 5, 40, 64, 3, 1),
+                                  (2, 128, 6, 16, 64, 3, 1), (1, 72, 3, 64, 64, 3, 1), (1, 72, 4, 100, 64, 3, 1),
+                                  (70, 128, 13, 13, 128, 3, 1)])
 def test_wgrad_bf16_transposing_reads(lib, cuda, case):
     """bf16 weight gradient (MFMA 32x32x16 fed by ds_read_b64_tr_b16): exact fp32 accumulation of the
     bf16-rounded operands, so it must match torch on the rounded inputs to fp32 noise."""

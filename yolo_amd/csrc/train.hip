@@ -5,6 +5,7 @@
 // (yolo_pack_conv_weights_dgrad).  Reference: car/YOLO.py:350-498 (_train_batch, _find_best, _loss_mask,
 // _score_weight, _get_loss) + the mxnet/gluon operators they call.
 #include "common.h"
+#include "conv_args.h"
 #include <float.h>
 
 // 8-channel vector access for NHWC tensors of either element type
@@ -378,87 +379,107 @@ static int yolo_conv_wgrad_f32(const float* dy, const float* x, float* dw_oihw, 
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-constexpr int WG_PITCH = 288;          // bytes per LDS pixel row (128 channels x 2 B + 32 B pad)
 constexpr int WG_KC = 64;              // pixels per K-chunk
 
+template <int PITCH>
 __device__ __forceinline__ uint4 tr_frag(const char* tile, int krow0, int col0, int lane) {
     // 8 consecutive k (pixels) of channel (col0 + (lane&15) + 16*((lane>>4)&1)), k = krow0 + 8*(lane>>5) ...
     const int g = lane >> 4, j = lane & 15;
     const int krow = krow0 + (g >> 1) * 8 + (j >> 2);
     const int col = col0 + (g & 1) * 16 + 4 * (j & 3);
-    const char* p = tile + krow * WG_PITCH + col * 2;
+    const char* p = tile + krow * PITCH + col * 2;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * WG_PITCH));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * PITCH));
     const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
     return make_uint4(a.x, a.y, b.x, b.y);
 }
 
+// Block = (MI*64) cout x (NI*64) cin x one tap, 4 waves (2 x 2, wave tile MI*32 x NI*32).  The loop is paced by the
+// global-load latency of the next chunk (registers -> LDS, one chunk ahead), so the wider tiles, which do 2-4x the
+// MFMA work per loaded byte and per barrier, are what the big layers use; 128 x 128 remains for small Cin/Cout.
+template <int MI, int NI>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
                                                          float* __restrict__ dwt, int N, int H, int W, int Cin, int Ho,
                                                          int Wo, int Cout, int ks, int stride, long long dy_ps,
-                                                         int tiles_ci, int chunks_per_slice, int use_atomic) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * WG_KC * WG_PITCH];
+                                                         int tiles_ci, int chunks_per_slice, int use_atomic,
+                                                         FastDiv d_howo, FastDiv d_wo) {
+    constexpr int BM = MI * 64, BN = NI * 64;
+    constexpr int PA = BM * 2 + 32, PB = BN * 2 + 32;            // LDS pitches (padded: conflict-free transposing reads)
+    constexpr int UA = WG_KC * (BM / 8) / 256, UB = WG_KC * (BN / 8) / 256;   // 16-byte units per thread per chunk
+    __shared__ __attribute__((aligned(16))) char smem[WG_KC * (PA + PB)];
     char* dyl = smem;
-    char* xl = smem + WG_KC * WG_PITCH;
+    char* xl = smem + WG_KC * PA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int tile = blockIdx.x;
     const int tci = tile % tiles_ci, tco = tile / tiles_ci;
-    const int co0 = tco * 128, ci0 = tci * 128;
+    const int co0 = tco * BM, ci0 = tci * BN;
     const int tap = blockIdx.y, kh = tap / ks, kw = tap - kh * ks, pad = ks / 2;
     const long long P = (long long)N * Ho * Wo;
     const long long c_first = (long long)blockIdx.z * chunks_per_slice;
     const long long c_last = min(c_first + chunks_per_slice, (P + WG_KC - 1) / WG_KC);
-    // staging: 4 units of 16 B per thread per operand; unit u = tid + j*256 -> pixel u>>4, 16-byte part u&15
-    uint4 dr[4], xr[4];
+    uint4 dr[UA], xr[UB];
     auto load_chunk = [&](long long c) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < UA; ++j) {
             const int u = tid + j * 256;
-            const int px = u >> 4, part = u & 15;
+            const int px = u / (BM / 8), part = u % (BM / 8);
             const long long p = c * WG_KC + px;
-            uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
-            if (p < P) {
-                if (co0 + part * 8 < Cout) a = *(const uint4*)(dy + p * dy_ps + co0 + part * 8);
-                const int n = (int)(p / ((long long)Ho * Wo));
-                const int rem = (int)(p - (long long)n * Ho * Wo);
-                const int oy = rem / Wo, ox = rem - oy * Wo;
+            uint4 a = make_uint4(0, 0, 0, 0);
+            if (p < P && co0 + part * 8 < Cout) a = *(const uint4*)(dy + p * dy_ps + co0 + part * 8);
+            dr[j] = a;
+        }
+#pragma unroll
+        for (int j = 0; j < UB; ++j) {
+            const int u = tid + j * 256;
+            const int px = u / (BN / 8), part = u % (BN / 8);
+            const long long p = c * WG_KC + px;
+            uint4 b = make_uint4(0, 0, 0, 0);
+            if (p < P && ci0 + part * 8 < Cin) {
+                // pixel -> (image, row, column) by multiply-shift (a 64-bit division here cost more than the MFMAs)
+                const int n = fdiv((int)p, d_howo);
+                const int rem = (int)p - n * Ho * Wo;
+                const int oy = fdiv(rem, d_wo), ox = rem - oy * Wo;
                 const int iy = oy * stride + kh - pad, ix = ox * stride + kw - pad;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W && ci0 + part * 8 < Cin)
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W)
                     b = *(const uint4*)(x + (((long long)n * H + iy) * W + ix) * Cin + ci0 + part * 8);
             }
-            dr[j] = a; xr[j] = b;
+            xr[j] = b;
         }
     };
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     if (c_first < c_last) load_chunk(c_first);
     for (long long c = c_first; c < c_last; ++c) {
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < UA; ++j) {
             const int u = tid + j * 256;
-            *(uint4*)(dyl + (u >> 4) * WG_PITCH + (u & 15) * 16) = dr[j];
-            *(uint4*)(xl + (u >> 4) * WG_PITCH + (u & 15) * 16) = xr[j];
+            *(uint4*)(dyl + (u / (BM / 8)) * PA + (u % (BM / 8)) * 16) = dr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < UB; ++j) {
+            const int u = tid + j * 256;
+            *(uint4*)(xl + (u / (BN / 8)) * PB + (u % (BN / 8)) * 16) = xr[j];
         }
         __syncthreads();
         if (c + 1 < c_last) load_chunk(c + 1);
 #pragma unroll
         for (int kk = 0; kk < WG_KC / 16; ++kk) {
-            uint4 af[2], bf[2];
+            uint4 af[MI], bf[NI];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) af[mi] = tr_frag(dyl, kk * 16, wm * 64 + mi * 32, lane);
+            for (int mi = 0; mi < MI; ++mi) af[mi] = tr_frag<PA>(dyl, kk * 16, (wm * MI + mi) * 32, lane);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) bf[ni] = tr_frag(xl, kk * 16, wn * 64 + ni * 32, lane);
+            for (int ni = 0; ni < NI; ++ni) bf[ni] = tr_frag<PB>(xl, kk * 16, (wn * NI + ni) * 32, lane);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mi]),
                                                                           __builtin_bit_cast(bf16x8, bf[ni]), acc[mi][ni],
                                                                           0, 0, 0);
@@ -466,20 +487,40 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const uint16_t* __restr
     }
     const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int ci = ci0 + wn * 64 + ni * 32 + l31;
+        for (int ni = 0; ni < NI; ++ni) {
+            const int ci = ci0 + (wn * NI + ni) * 32 + l31;
             if (ci >= Cin) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int co = co0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (co >= Cout) continue;
                 float* dst = dwt + ((long long)tap * Cout + co) * Cin + ci;
                 if (use_atomic) atomicAdd(dst, acc[mi][ni][r]);
                 else *dst = acc[mi][ni][r];
             }
         }
+}
+
+template <int MI, int NI>
+static void wgrad_bf16_launch(const uint16_t* dy, const uint16_t* x, float* ws, int N, int H, int W, int Cin, int Ho, int Wo,
+                              int Cout, int ksize, int stride, long long ps, hipStream_t st) {
+    constexpr int BM = MI * 64, BN = NI * 64;
+    const int tiles_ci = (Cin + BN - 1) / BN, tiles_co = (Cout + BM - 1) / BM, taps = ksize * ksize;
+    const long long chunks = ((long long)N * Ho * Wo + WG_KC - 1) / WG_KC;
+    const long long tiles = (long long)tiles_ci * tiles_co * taps;
+    long long target = (MI * NI >= 8) ? 512 : 768;               // blocks in flight: 2-3 per CU
+    if (const char* e = getenv("YOLO_WGRAD_BLOCKS")) target = atoi(e);
+    long long slices = (target + tiles - 1) / tiles;
+    if (slices > chunks) slices = chunks;
+    if (slices < 1) slices = 1;
+    const int cps = (int)((chunks + slices - 1) / slices);
+    slices = (chunks + cps - 1) / cps;
+    if (slices > 1) (void)hipMemsetAsync(ws, 0, (size_t)Cin * Cout * taps * 4, st);
+    YOLO_LAUNCH((wgrad_bf16_kernel<MI, NI>), dim3((unsigned)(tiles_ci * tiles_co), taps, (unsigned)slices), dim3(256), 0, st,
+                dy, x, ws, N, H, W, Cin, Ho, Wo, Cout, ksize, stride, ps, tiles_ci, cps, slices > 1 ? 1 : 0,
+                make_fastdiv((unsigned)Ho * Wo), make_fastdiv((unsigned)Wo));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -667,6 +708,190 @@ static void wgrad_strip_launch(const uint16_t* dy, const uint16_t* x, float* dwt
                 W, Cin, Ho, Wo, Cout, ps, tiles_ci, tiles_co, strips_w, rps);
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 weight gradient of the 3x3 stride-1 layers with many channels on small maps (Wo <= 78).  The per-tap kernel
+// is bound by L2 traffic there: every (cout tile, cin tile, tap) block re-reads its dy and x slices, 9x per tile
+// pair.  Here a block (4 waves, 64 cout x 64 cin) stages a group of TH whole output rows of one image -- dy and the
+// x rows with their halo -- ONCE and accumulates all nine taps from it (9 accumulator tiles of 32x32 per wave,
+// 144 AGPRs).  The MFMA K index runs over the TH*Wo pixels of the group in row-major order; because
+// ds_read_b64_tr_b16 takes a per-lane row address, a K-step may straddle output rows: each lane's row offsets are
+// precomputed per K-step (unused K slots read zero-filled dy rows).  Global loads of the next group are in flight
+// in registers while the current group is multiplied.
+// ------------------------------------------------------------------------------------------------
+template <int TH, int KSTEPS>
+__global__ __launch_bounds__(256, 2) void wgrad_rows_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
+                                                         float* __restrict__ dwt, int N, int H, int W, int Cin, int Cout,
+                                                         long long dy_ps, int tiles_ci, int groups_per_block, int gpi,
+                                                         FastDiv d_w, FastDiv d_xw8, FastDiv d_gpi) {
+    constexpr int MAXQ = KSTEPS * 16;                   // K slots per group (>= TH*W)
+    constexpr int XWMAX = MAXQ / TH + 2;
+    constexpr int DP = 144, XP = 144;                   // LDS pitches: 64 channels x 2 B + 16 B pad
+    constexpr int XROWS = (TH + 2) * XWMAX;
+    constexpr int DU = (MAXQ * 8 + 255) / 256, XU = (XROWS * 8 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) char smem[MAXQ * DP + XROWS * XP];
+    char* dyl = smem;
+    char* xl = smem + MAXQ * DP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int tci = blockIdx.x % tiles_ci, tco = blockIdx.x / tiles_ci;
+    const int co0 = tco * 64, ci0 = tci * 64;
+    // the block's share of the (image, row group) sequence: gpi groups of TH rows per image
+    const int g_begin = blockIdx.y * groups_per_block;
+    const int g_end = min(g_begin + groups_per_block, N * gpi);
+    if (g_begin >= g_end) return;
+    const int XW = W + 2, Q = TH * W;
+
+    // per-thread staging units (loop invariant), packed to keep the kernel at two waves per SIMD:
+    //   code = LDS byte offset | row-in-group << 20 | (unit takes part in loads) << 28 ; -1 = unit unused
+    int d_code[DU], d_goff[DU];
+#pragma unroll
+    for (int j = 0; j < DU; ++j) {
+        const int u = tid + j * 256, q = u >> 3, part = u & 7;
+        const int ty = fdiv(q, d_w), tx = q - ty * W;
+        const bool live = q < Q && co0 + part * 8 < Cout;
+        d_code[j] = (u < MAXQ * 8) ? (q * DP + part * 16) | (ty << 20) | ((live ? 1 : 0) << 28) : -1;
+        d_goff[j] = (int)((ty * W + tx) * dy_ps) + part * 8;
+    }
+    int x_code[XU], x_goff[XU];
+#pragma unroll
+    for (int j = 0; j < XU; ++j) {
+        const int u = tid + j * 256;
+        const int r = fdiv(u, d_xw8), rem = u - r * (XW * 8), px = rem >> 3, part = rem & 7;
+        const int ix = px - 1;
+        const bool live = ix >= 0 && ix < W && ci0 + part * 8 < Cin;
+        x_code[j] = (r < TH + 2) ? ((r * XW + px) * XP + part * 16) | (r << 20) | ((live ? 1 : 0) << 28) : -1;
+        x_goff[j] = ((r - 1) * W + ix) * Cin + part * 8;
+    }
+    uint4 dr[DU], xr[XU];
+    auto load_group = [&](int gi) {
+        const int n = fdiv(gi, d_gpi);
+        const int oy = (gi - n * gpi) * TH;
+        const uint16_t* dyn = dy + ((long long)n * H + oy) * W * dy_ps + co0;
+        const uint16_t* xn = x + ((long long)n * H + oy) * W * Cin + ci0;
+#pragma unroll
+        for (int j = 0; j < DU; ++j) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (d_code[j] >= 0 && (d_code[j] >> 28) && oy + ((d_code[j] >> 20) & 0xff) < H)
+                v = *(const uint4*)(dyn + d_goff[j]);
+            dr[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < XU; ++j) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            const int iy = oy - 1 + ((x_code[j] >> 20) & 0xff);
+            if (x_code[j] >= 0 && (x_code[j] >> 28) && iy >= 0 && iy < H)
+                v = *(const uint4*)(xn + x_goff[j]);
+            xr[j] = v;
+        }
+    };
+    auto store_group = [&]() {
+#pragma unroll
+        for (int j = 0; j < DU; ++j)
+            if (d_code[j] >= 0) *(uint4*)(dyl + (d_code[j] & 0xfffff)) = dr[j];
+#pragma unroll
+        for (int j = 0; j < XU; ++j)
+            if (x_code[j] >= 0) *(uint4*)(xl + (x_code[j] & 0xfffff)) = xr[j];
+    };
+
+    // per-lane fragment row offsets: dy rows are linear in the K slot (one base register), x rows wrap at the
+    // row width (lo = k 0..3 of the lane's group, hi = k 4..7)
+    const int g = lane >> 4, j16 = lane & 15;
+    const int col2 = ((g & 1) * 16 + 4 * (j16 & 3)) * 2;
+    const int a_base = ((g >> 1) * 8 + (j16 >> 2)) * DP + wm * 64 + col2;
+    int b_off[KSTEPS][2];
+#pragma unroll
+    for (int s_ = 0; s_ < KSTEPS; ++s_)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int q = s_ * 16 + (g >> 1) * 8 + (j16 >> 2) + 4 * hf;
+            const int qq = q < Q ? q : 0;                 // (dy row q is zero there; any x row will do)
+            const int ty = fdiv(qq, d_w), tx = qq - ty * W;
+            b_off[s_][hf] = (ty * XW + tx) * XP + wn * 64 + col2;
+        }
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+
+    load_group(g_begin);
+    for (int gi = g_begin; gi < g_end; ++gi) {
+        __syncthreads();                                  // everyone is done reading the previous group
+        store_group();
+        __syncthreads();
+        if (gi + 1 < g_end) load_group(gi + 1);
+#pragma unroll
+        for (int s_ = 0; s_ < KSTEPS; ++s_) {
+            const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(dyl + a_base + s_ * 16 * DP));
+            const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(dyl + a_base + (s_ * 16 + 4) * DP));
+            const uint2 a0 = __builtin_bit_cast(uint2, alo), a1 = __builtin_bit_cast(uint2, ahi);
+            const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int toff = (kh * XW + kw) * XP;
+                    const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xl + b_off[s_][0] + toff));
+                    const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xl + b_off[s_][1] + toff));
+                    const uint2 b0 = __builtin_bit_cast(uint2, blo), b1 = __builtin_bit_cast(uint2, bhi);
+                    const bf16x8 bfr = __builtin_bit_cast(bf16x8, make_uint4(b0.x, b0.y, b1.x, b1.y));
+                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[kh * 3 + kw], 0, 0, 0);
+                }
+        }
+    }
+
+    const int l31 = lane & 31, h = lane >> 5;
+    const int ci = ci0 + wn * 32 + l31;
+    if (ci >= Cin) return;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (co < Cout) atomicAdd(dwt + ((long long)tp * Cout + co) * Cin + ci, acc[tp][r]);
+        }
+}
+
+template <int TH, int KSTEPS>
+static void wgrad_rows_launch(const uint16_t* dy, const uint16_t* x, float* dwt, int N, int H, int W, int Cin, int Cout,
+                              long long ps, hipStream_t st) {
+    const int tiles_ci = (Cin + 63) / 64, tiles_co = (Cout + 63) / 64;
+    const int tiles = tiles_ci * tiles_co;
+    const int gpi = (H + TH - 1) / TH;
+    const long long groups = (long long)N * gpi;
+    long long target = 512;                                   // measured best of 256..1024 (2 blocks per CU)
+    if (const char* e = getenv("YOLO_WGRAD_ROWS_BLOCKS")) target = atoi(e);
+    long long nb = (target + tiles - 1) / tiles;              // every block ends with a 64x64x9 atomic tile
+    if (nb > groups) nb = groups;
+    if (nb < 1) nb = 1;
+    const int gpb = (int)((groups + nb - 1) / nb);
+    nb = (groups + gpb - 1) / gpb;
+    YOLO_LAUNCH((wgrad_rows_kernel<TH, KSTEPS>), dim3((unsigned)tiles, (unsigned)nb), dim3(256), 0, st, dy, x, dwt, N, H, W,
+                Cin, Cout, ps, tiles_ci, gpb, gpi, make_fastdiv((unsigned)W), make_fastdiv((unsigned)(W + 2) * 8),
+                make_fastdiv((unsigned)gpi));
+}
+
+// (TH, KSTEPS) of the row-group kernel for an output width, or false when none of the instantiations fits
+static bool wgrad_rows_dispatch(const uint16_t* dy, const uint16_t* x, float* dwt, int N, int H, int W, int Cin, int Cout,
+                                long long ps, hipStream_t st) {
+    int best_th = 0, best_k = 0;
+    double best_eff = 0;
+    static const int table[][2] = {{6, 5}, {5, 6}, {3, 5}, {2, 5}, {2, 7}, {1, 5}, {4, 4}, {1, 4}, {1, 7}};
+    for (const auto& t : table) {
+        const int th = t[0], k = t[1];
+        if (th * W > k * 16 || (k - 1) * 16 >= th * W) continue;          // K-steps must match exactly
+        const double eff = (double)th * W / (k * 16.0);
+        if (eff > best_eff) { best_eff = eff; best_th = th; best_k = k; }
+    }
+    if (!best_th) return false;
+#define ROWS_CASE(TH_, K_) if (best_th == TH_ && best_k == K_) { wgrad_rows_launch<TH_, K_>(dy, x, dwt, N, H, W, Cin, Cout, ps, st); return true; }
+    ROWS_CASE(6, 5) ROWS_CASE(5, 6) ROWS_CASE(3, 5) ROWS_CASE(2, 5) ROWS_CASE(2, 7) ROWS_CASE(1, 5) ROWS_CASE(4, 4)
+    ROWS_CASE(1, 4) ROWS_CASE(1, 7)
+#undef ROWS_CASE
+    return false;
+}
+
 // dw_oihw[co][ci][tap] += dwt[tap][co][ci]
 __global__ void wgrad_finish_kernel(const float* __restrict__ dwt, float* __restrict__ dw, int Cout, int Cin, int taps,
                                     long long total) {
@@ -693,21 +918,17 @@ extern "C" int yolo_conv_wgrad(const void* dy, const void* x, float* dw_oihw, in
     if (dtype != YOLO_BF16) return YOLO_EINVAL;
     const long long ps = dy_pixel_stride ? dy_pixel_stride : Cout;
     if (!workspace || (Cin % 8) || (ps % 8)) return YOLO_EUNSUPPORTED;
+    if ((long long)N * H * W >= 0x7fffffffLL) return YOLO_EUNSUPPORTED;
     const int pad = ksize / 2;
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
-    const int tiles_ci = (Cin + 127) / 128, tiles_co = (Cout + 127) / 128, taps = ksize * ksize;
-    const long long chunks = ((long long)N * Ho * Wo + WG_KC - 1) / WG_KC;
-    const long long tiles = (long long)tiles_ci * tiles_co * taps;
-    long long slices = (768 + tiles - 1) / tiles;                 // ~3 blocks per CU in flight
-    if (slices > chunks) slices = chunks;
-    if (slices < 1) slices = 1;
-    const int cps = (int)((chunks + slices - 1) / slices);
-    slices = (chunks + cps - 1) / cps;
+    const int taps = ksize * ksize;
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
     const long long wsb = (long long)Cin * Cout * taps * 4;
     const long long total = (long long)Cin * Cout * taps;
-    if (ksize == 3 && Cin <= 64) {
+    int strip_max_cin = 64;
+    if (const char* e = getenv("YOLO_WGRAD_STRIP_CIN")) strip_max_cin = atoi(e);
+    if (ksize == 3 && Cin <= strip_max_cin) {
         (void)hipMemsetAsync(workspace, 0, wsb, st);
         const uint16_t* d16 = (const uint16_t*)dy;
         const uint16_t* x16 = (const uint16_t*)x;
@@ -720,10 +941,28 @@ extern "C" int yolo_conv_wgrad(const void* dy, const void* x, float* dw_oihw, in
         YOLO_LAUNCH_CHECK();
         return YOLO_OK;
     }
-    if (slices > 1) (void)hipMemsetAsync(workspace, 0, wsb, st);
-    YOLO_LAUNCH(wgrad_bf16_kernel, dim3((unsigned)(tiles_ci * tiles_co), taps, (unsigned)slices), dim3(256), 0, st,
-                (const uint16_t*)dy, (const uint16_t*)x, (float*)workspace, N, H, W, Cin, Ho, Wo, Cout, ksize, stride, ps,
-                tiles_ci, cps, slices > 1 ? 1 : 0);
+    // row-group kernel: wins on the narrow deep maps (26x26: 210 -> 163 us, 13x13: 211 -> 175 us at batch 64); on wider
+    // maps its atomic epilogue (one 64x64x9 tile per block) costs more than the saved L2 traffic
+    if (ksize == 3 && stride == 1 && W <= 40 && !getenv("YOLO_WGRAD_NO_ROWS")) {
+        (void)hipMemsetAsync(workspace, 0, wsb, st);
+        if (wgrad_rows_dispatch((const uint16_t*)dy, (const uint16_t*)x, (float*)workspace, N, H, W, Cin, Cout, ps, st)) {
+            YOLO_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                        (const float*)workspace, dw_oihw, Cout, Cin, taps, total);
+            YOLO_LAUNCH_CHECK();
+            return YOLO_OK;
+        }
+    }
+    {
+        const uint16_t* d16 = (const uint16_t*)dy;
+        const uint16_t* x16 = (const uint16_t*)x;
+        float* ws = (float*)workspace;
+        int tile = 22;                                        // wider tiles: one wave per SIMD, measured slower
+        if (const char* e = getenv("YOLO_WGRAD_TILE")) tile = atoi(e);
+        if (tile == 44) wgrad_bf16_launch<4, 4>(d16, x16, ws, N, H, W, Cin, Ho, Wo, Cout, ksize, stride, ps, st);
+        else if (tile == 42) wgrad_bf16_launch<4, 2>(d16, x16, ws, N, H, W, Cin, Ho, Wo, Cout, ksize, stride, ps, st);
+        else if (tile == 24) wgrad_bf16_launch<2, 4>(d16, x16, ws, N, H, W, Cin, Ho, Wo, Cout, ksize, stride, ps, st);
+        else wgrad_bf16_launch<2, 2>(d16, x16, ws, N, H, W, Cin, Ho, Wo, Cout, ksize, stride, ps, st);
+    }
     YOLO_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
                 dw_oihw, Cout, Cin, taps, total);
     YOLO_LAUNCH_CHECK();
