@@ -13,7 +13,7 @@
 #pragma once
 #include "conv_args.h"
 
-// bytes of LDS scratch one wave needs (max over MI in {1,2}): 32 rows x (64*4+16) + 32 x 8
+// bytes of LDS scratch one wave needs (max over MI in {1,2}): 32 rows x (64*4+16) + 2 x 32 x 8
 #define YOLO_EPI_WAVE_BYTES 9216
 
 template <typename T, int MI, int NI>
@@ -26,7 +26,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
     constexpr int LPR = WN / CPL;               // lanes per pixel row
     constexpr int RPP = 64 / LPR;               // rows per pass
     constexpr int NPASS = 32 / RPP;
-    static_assert(32 * RS + 32 * 8 <= YOLO_EPI_WAVE_BYTES, "scratch size");
+    static_assert(32 * RS + 2 * 32 * 8 <= YOLO_EPI_WAVE_BYTES, "scratch size");
     const int l31 = lane & 31, h = lane >> 5;
     const float slope = a.slope;
 
@@ -78,11 +78,30 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
 #pragma unroll
         for (int e = 0; e < 4; ++e) { sc[4 * q + e] = s4[e]; bi[4 * q + e] = b4[e]; }
     }
+    // The residual loads of slab ni+1 are issued BEFORE slab ni is processed (two register sets), so their latency
+    // hides under the previous slab's transpose/arithmetic/stores -- the phase stamps showed one exposed memory
+    // round trip per 32-pixel slab doubling the epilogue time.  (Prefetching all slabs at once spills on the
+    // 8-wave variants.)  Output offsets go through a small LDS table: the transpose changes which pixel a lane owns.
     long long* ytab = (long long*)(wsm + 32 * RS);
     const bool has_res = a.res != nullptr;
+    long long yo[2][NPASS];
+    uint4 rv[2][NPASS];
+    auto prefetch = [&](int ni) {
+        if (h == 0) ytab[(ni & 1) * 32 + l31] = yoff[ni];
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) yo[ni & 1][k] = co_ok ? ytab[(ni & 1) * 32 + row0 + k * RPP] : -1;
+        if (has_res) {
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k) {
+                rv[ni & 1][k] = make_uint4(0, 0, 0, 0);
+                if (yo[ni & 1][k] >= 0) rv[ni & 1][k] = *(const uint4*)(a.res + (yo[ni & 1][k] + co) * ES);
+            }
+        }
+    };
+    prefetch(0);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-        if (h == 0) ytab[l31] = yoff[ni];
+        if (ni + 1 < NI) prefetch(ni + 1);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -90,17 +109,6 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                 f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
                 *(f32x4*)(wsm + l31 * RS + (mi * 32 + 8 * g + 4 * h) * 4) = v;
             }
-        long long yo[NPASS];
-#pragma unroll
-        for (int k = 0; k < NPASS; ++k) yo[k] = co_ok ? ytab[row0 + k * RPP] : -1;
-        uint4 rv[NPASS];
-        if (has_res) {
-#pragma unroll
-            for (int k = 0; k < NPASS; ++k) {
-                rv[k] = make_uint4(0, 0, 0, 0);
-                if (yo[k] >= 0) rv[k] = *(const uint4*)(a.res + (yo[k] + co) * ES);
-            }
-        }
 #pragma unroll
         for (int k = 0; k < NPASS; ++k) {
             float v[CPL];
@@ -118,7 +126,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
             uint4 ov;
             if constexpr (ES == 2) {
                 if (has_res) {
-                    const uint32_t w[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
+                    const uint32_t w[4] = {rv[ni & 1][k].x, rv[ni & 1][k].y, rv[ni & 1][k].z, rv[ni & 1][k].w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         v[2 * q] += bf16_bits_to_f32(w[q] & 0xffffu);
@@ -129,13 +137,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                                 pack_bf16x2(v[6], v[7]));
             } else {
                 if (has_res) {
-                    v[0] += __uint_as_float(rv[k].x); v[1] += __uint_as_float(rv[k].y);
-                    v[2] += __uint_as_float(rv[k].z); v[3] += __uint_as_float(rv[k].w);
+                    v[0] += __uint_as_float(rv[ni & 1][k].x); v[1] += __uint_as_float(rv[ni & 1][k].y);
+                    v[2] += __uint_as_float(rv[ni & 1][k].z); v[3] += __uint_as_float(rv[ni & 1][k].w);
                 }
                 ov = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
                                 __float_as_uint(v[3]));
             }
-            if (yo[k] >= 0) *(uint4*)(a.y + (yo[k] + co) * ES) = ov;
+            if (yo[ni & 1][k] >= 0) *(uint4*)(a.y + (yo[ni & 1][k] + co) * ES) = ov;
         }
     }
 }

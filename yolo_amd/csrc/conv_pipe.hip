@@ -133,60 +133,11 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         x0 = strip * TWt * S - 1;
     }
 
-    // ---- per-thread DMA sources: byte offset of the slot's 16-byte unit for chunk 0 (32-bit: the host
-    //      checks the activation tensor is < 4 GiB), or ~0 for a zero-padding slot (DMA'd from the zero page)
-    unsigned xo[XL];
-#pragma unroll
-    for (int j = 0; j < XL; ++j) {
-        const int u = tid + j * NT;
-        const int slot = u >> 2, part = u & 3;
-        bool valid;
-        long long off;
-        if constexpr (KS == 3) {
-            const int rr = fdiv(slot, a.d_PW), cc = slot - rr * PW;
-            const int Rr = Rin_lo + rr;
-            const int n = fdiv(Rr, a.d_H1);
-            const int yy = Rr - n * (H + 1) - 1;
-            const int xx = x0 + cc;
-            valid = slot < HS && yy >= 0 && n < a.N && xx >= 0 && xx < W;
-            off = ((long long)(n * H + yy) * W + xx) * row_bytes;
-        } else {
-            const int i = i0 + slot;
-            valid = i < a.total_i;
-            off = (long long)i * row_bytes;
-        }
-        const int lp = (part ^ ((slot >> 2) & 3)) * 16;
-        xo[j] = valid ? (unsigned)(off + lp) : 0xffffffffu;
-    }
     const char* wsrc = a.wp + (long long)co0 * 64 + tid * 16;
     const long long wplane = (long long)a.Cout_pad * 64;
     static_assert((BC * 4) % NT == 0 || NT % (BC * 4) == 0, "tap index must be uniform per DMA");
 
-    // ---- per-lane MFMA operand bases ------------------------------------------------------------
-    int slot00[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int i = i0 + (wave_p * NI + ni) * 32 + l31;
-        const int ii = (i < a.total_i) ? i : i0;
-        if constexpr (KS == 3) {
-            const int r = fdiv(ii, a.d_TWt);
-            const int tx = ii - r * TWt;
-            const int n = fdiv(r, a.d_Ho);
-            slot00[ni] = (n * (H + 1) + (r - n * Ho) * S - Rin_lo) * PW + tx * S;
-        } else {
-            slot00[ni] = ii - i0;
-        }
-    }
-    const int aoff0 = (wave_c * MI * 32 + l31) * 64 + ((h ^ ((l31 >> 2) & 3)) << 4);
-
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
+    unsigned xo[XL];
     const int nchunks = a.nchunks;
     const int nphase = nchunks * PPC;
     const uint32_t wave_lds = lds0 + wave * 1024;        // this wave's 1 KiB lane-linear window per DMA
@@ -213,22 +164,71 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     static_assert(KS == 1 || XL <= PPC, "3x3: at most one input DMA per phase");
     static_assert(BC * 4 >= NT, "one weight DMA covers rows of a single tap plane");
 
-    // ---- prologue ------------------------------------------------------------------------------
+    // ---- prologue: the first weight DMAs go out before the (division-heavy) input address set-up, and the
+    //      MFMA operand bases are computed while the first DMAs are in flight -------------------------------
+    issue_w(0);
+    // ---- per-thread DMA sources: byte offset of the slot's 16-byte unit for chunk 0 (32-bit: the host
+    //      checks the activation tensor is < 4 GiB), or ~0 for a zero-padding slot (DMA'd from the zero page)
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+        const int u = tid + j * NT;
+        const int slot = u >> 2, part = u & 3;
+        bool valid;
+        long long off;
+        if constexpr (KS == 3) {
+            const int rr = fdiv(slot, a.d_PW), cc = slot - rr * PW;
+            const int Rr = Rin_lo + rr;
+            const int n = fdiv(Rr, a.d_H1);
+            const int yy = Rr - n * (H + 1) - 1;
+            const int xx = x0 + cc;
+            valid = slot < HS && yy >= 0 && n < a.N && xx >= 0 && xx < W;
+            off = ((long long)(n * H + yy) * W + xx) * row_bytes;
+        } else {
+            const int i = i0 + slot;
+            valid = i < a.total_i;
+            off = (long long)i * row_bytes;
+        }
+        const int lp = (part ^ ((slot >> 2) & 3)) * 16;
+        xo[j] = valid ? (unsigned)(off + lp) : 0xffffffffu;
+    }
     if constexpr (KS == 3) {
 #pragma unroll
         for (int j = 0; j < XL; ++j) issue_x(j, 0, 0);
-        issue_w(0);
         issue_w(1);
-        wait_vmcnt<WL>();
     } else {
 #pragma unroll
         for (int j = 0; j < XL; ++j) issue_x(j, 0, 0);
-        issue_w(0);
 #pragma unroll
         for (int j = 0; j < XL; ++j) issue_x(j, 1, 1);
         issue_w(1);
-        wait_vmcnt<WL + XL>();
     }
+    // ---- per-lane MFMA operand bases ------------------------------------------------------------
+    int slot00[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int i = i0 + (wave_p * NI + ni) * 32 + l31;
+        const int ii = (i < a.total_i) ? i : i0;
+        if constexpr (KS == 3) {
+            const int r = fdiv(ii, a.d_TWt);
+            const int tx = ii - r * TWt;
+            const int n = fdiv(r, a.d_Ho);
+            slot00[ni] = (n * (H + 1) + (r - n * Ho) * S - Rin_lo) * PW + tx * S;
+        } else {
+            slot00[ni] = ii - i0;
+        }
+    }
+    const int aoff0 = (wave_c * MI * 32 + l31) * 64 + ((h ^ ((l31 >> 2) & 3)) << 4);
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    if constexpr (KS == 3) wait_vmcnt<WL>();
+    else wait_vmcnt<WL + XL>();
     __builtin_amdgcn_s_barrier();
     STAMP(1);
 
