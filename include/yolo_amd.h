@@ -130,6 +130,13 @@ int yolo_predict_top1(const float* out, float* pred, int* best_idx, int B, int C
 int yolo_predict_lp(const float* out, float* pred, int* best_idx, int C, int h, int w, float r_max0,
                     float r_max1, float r_max2, void* stream);
 
+/* CarLPNet.predict_LP + LP_pose_activation (car_and_LP/YOLO.py:133-169): out (B, h*w, C) float32 NHWC (the LP branch
+ * output, C = LP_slice_point[-1] >= 7, channel order [score, x, y, z, r1, r2, r3, class...]) -> pred (B, 7): per image
+ * the cell with the highest sigmoid(score) (first among ties): [sigmoid(score), xyz * 1000, three angles
+ * (sigmoid - 0.5) * 2 * r_max * pi / 180]; best_idx (B) the chosen cells. */
+int yolo_predict_lp_nhwc(const float* out, float* pred, int* best_idx, int B, int hw, int C, float r_max0,
+                         float r_max1, float r_max2, void* stream);
+
 /* get_iou(predict, target, mode=2), yolo_gluon.py:127-168: boxes (n,4) ltrb vs one target
  * [c,y,x,h,w] (5 floats, device) -> iou (n). */
 int yolo_iou_ltrb_vs_yxhw(const float* boxes, const float* target, float* iou, int n, void* stream);

@@ -237,3 +237,28 @@ def predict_LP(batch_out, r_max):
         p = (sigmoid(pred[i + 4]) - f32(0.5)) * f32(2) * f32(r_max[i])
         pred[i + 4] = p * f32(math.pi) / f32(180.)
     return pred, best
+
+
+def predict_LP_batch(LP_batch_out, LP_slice_point, r_max):
+    """car_and_LP/YOLO.py:133-169 (predict_LP + LP_pose_activation).  LP_batch_out: [ (B,h,w,C) ] as CarLPNet
+    returns it.  merge_and_slice at LP_slice_point -> score / xy / z / r (the LP class slice is dropped); per image
+    the cell with the highest sigmoid(score) (first among ties) -> [sigmoid(score), x*1000, y*1000, z*1000, three angles
+    (sigmoid - 0.5) * 2 * r_max * pi / 180].  Returns (B,7) float32 and the chosen cell indices."""
+    out = np.concatenate([np.asarray(o, f32) for o in LP_batch_out], axis=1)
+    B, C = out.shape[0], out.shape[-1]
+    n_used = LP_slice_point[3]                       # score 1 + xy 2 + z 1 + r 3 = 7
+    out = out.reshape(B, -1, C)
+    preds, best = np.zeros((B, n_used), f32), np.zeros(B, np.int64)
+    for b in range(B):
+        score = sigmoid(out[b, :, 0])
+        k = int(np.argmax(score))
+        # sigmoid is monotone but not injective in float32: the reference takes the arg-max of the SIGMOID
+        best[b] = k
+        p = out[b, k, :n_used].copy()
+        p[0] = score[k]
+        p[1:4] *= f32(1000)
+        for i in range(3):
+            v = (sigmoid(p[4 + i]) - f32(0.5)) * f32(2) * f32(r_max[i])
+            p[4 + i] = v * f32(math.pi) / f32(180.)
+        preds[b] = p
+    return preds, best

@@ -73,7 +73,8 @@ def _yolo_output(y, num_anchors, per_anchor):
 
 def forward_torch(g, P, x, training=False, bn_stats=None, sim_bf16=False, taps=None):
     """x: (B,3,H,W) float32 torch tensor or ndarray.  Returns list of 3 tensors fine->coarse,
-    each (B, H_i*W_i, A, C).  `taps`: optional dict filled with named intermediates (NCHW)."""
+    each (B, H_i*W_i, A, C) -- and, for a spec with an LP branch (CarLPNet), the tuple (that list, [LP output
+    (B, h, w, LP channels)]).  `taps`: optional dict filled with named intermediates (NCHW)."""
     if not isinstance(x, torch.Tensor):
         x = torch.from_numpy(np.ascontiguousarray(x))
     x = x.float()
@@ -94,7 +95,16 @@ def forward_torch(g, P, x, training=False, bn_stats=None, sim_bf16=False, taps=N
         if i >= n_st - g['num_pyramid']:       # car/utils.py:73-74 (stem counts as stages[0] there)
             routes.append(x)
     outs = []
+    lp_out = None
     for i, hd in enumerate(g['heads']):
+        if 'lp' in g and i >= len(g['heads']) - 1:
+            # CarLPNet.hybrid_forward, car_and_LP/YOLO.py:72-79: the LP branch reads the input of the finest block
+            t = x
+            for blk in g['lp']['blocks']:
+                for c in blk['body']:
+                    t = conv(c, t)
+                t = conv(blk['tip'], t)                     # `_, LP_output = block(...)`: the tip feeds the next block
+            lp_out = _conv_bn_act_torch(P, g['lp']['out'], t, sim_bf16=sim_bf16).permute(0, 2, 3, 1).contiguous()
         for c in hd['body']:
             x = conv(c, x)
         route = x
@@ -105,6 +115,8 @@ def forward_torch(g, P, x, training=False, bn_stats=None, sim_bf16=False, taps=N
             break
         x = conv(g['transitions'][i], route)
         x = torch.cat([_upsample2(x), routes[::-1][i + 1]], dim=1)
+    if 'lp' in g:
+        return outs[::-1], [lp_out]                          # car_and_LP/YOLO.py:95
     return outs[::-1]
 
 
@@ -152,7 +164,15 @@ def forward_numpy64(g, P, x):
         if i >= n_st - g['num_pyramid']:
             routes.append(x)
     outs = []
+    lp_out = None
     for i, hd in enumerate(g['heads']):
+        if 'lp' in g and i >= len(g['heads']) - 1:
+            t = x
+            for blk in g['lp']['blocks']:
+                for c in blk['body']:
+                    t = conv(c, t)
+                t = conv(blk['tip'], t)
+            lp_out = conv(g['lp']['out'], t).transpose(0, 2, 3, 1)
         for c in hd['body']:
             x = conv(c, x)
         route = x
@@ -163,4 +183,6 @@ def forward_numpy64(g, P, x):
             break
         x = conv(g['transitions'][i], route)
         x = np.concatenate([x.repeat(2, axis=-1).repeat(2, axis=-2), routes[::-1][i + 1]], axis=1)
+    if 'lp' in g:
+        return outs[::-1], [lp_out]
     return outs[::-1]

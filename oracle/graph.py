@@ -65,13 +65,27 @@ def build_graph(spec, in_channels=3):
             transitions.append(_conv('transitions.%d' % (i - 1), pyr[::-1][i - 1], channel, 1, 1))
     g['heads'] = heads
     g['transitions'] = transitions
+    if 'LP_slice_point' in spec:
+        # CarLPNet.__init__, car_and_LP/YOLO.py:47-60: five YOLODetectionBlockV3(channels[-3]) chained through their
+        # TIP outputs on the input of the finest detection block, then a biased 1x1 to LP_slice_point[-1] channels
+        lpc = channels[-3]
+        blocks, c_prev = [], 2 * pyr[0] if n_pyr > 1 else channels[-1]
+        for k in range(5):
+            body = []
+            for b, (cout, kk) in enumerate([(lpc, 1), (2 * lpc, 3), (lpc, 1), (2 * lpc, 3), (lpc, 1)]):
+                body.append(_conv('lp.%d.b%d' % (k, b), c_prev, cout, kk, 1))
+                c_prev = cout
+            tip = _conv('lp.%d.tip' % k, lpc, 2 * lpc, 3, 1)
+            blocks.append(dict(body=body, tip=tip))
+            c_prev = 2 * lpc
+        g['lp'] = dict(blocks=blocks, out=_conv('lp.out', 2 * lpc, spec['LP_slice_point'][-1], 1, 1, bn=False))
     g['num_pyramid'] = n_pyr
     g['per_anchor'] = per_anchor
     return g
 
 
 def conv_list(g):
-    """Deterministic parameter order: stem, stages, heads (deep->shallow), transitions."""
+    """Deterministic parameter order: stem, stages, heads (deep->shallow), transitions, LP branch."""
     out = [g['stem']]
     for st in g['stages']:
         out.append(st['down'])
@@ -80,6 +94,10 @@ def conv_list(g):
     for h in g['heads']:
         out += h['body'] + [h['tip'], h['out']]
     out += g['transitions']
+    if 'lp' in g:                      # registered last (CarLPNet.__init__ adds LP_branch after the base class)
+        for blk in g['lp']['blocks']:
+            out += blk['body'] + [blk['tip']]
+        out.append(g['lp']['out'])
     return out
 
 

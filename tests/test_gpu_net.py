@@ -160,3 +160,70 @@ def test_gluon_params_file_round_trip(cuda, tmp_path):
     ref = of.forward_torch(g, P, x)
     for o, r in zip(outs2, ref):
         np.testing.assert_allclose(o, r.numpy(), rtol=0, atol=1e-3)
+
+
+# ---- CarLPNet (car_and_LP/YOLO.py:47-95): car heads + licence-plate branch --------------------------------------
+def _lp_spec():
+    spec = dict(og.spec_micro())
+    spec['LP_slice_point'] = [1, 3, 4, 7, 10]
+    return spec
+
+
+def test_carlpnet_f32_vs_oracle(cuda):
+    from yolo_amd.net import CarLPNet
+    from yolo_amd.detect import predict_LP_batch
+    from oracle import detect as od
+    spec, size = _lp_spec(), (64, 96)
+    g = og.build_graph(spec)
+    P = og.init_params(g, seed=3, bn='random')
+    x = np.random.default_rng(4).random((3, 3) + size, dtype=np.float32)
+    net = CarLPNet(spec, dtype='f32', device=cuda).load_params(P)
+    outs, lp = net(torch.from_numpy(x).to(cuda))
+    routs, rlp = of.forward_torch(g, P, x)
+    assert lp[0].shape == tuple(rlp[0].shape) == (3, 8, 12, 10)
+    for o, r in zip(outs, routs):
+        np.testing.assert_allclose(o.cpu().numpy(), r.numpy(), rtol=0, atol=1e-3)
+    np.testing.assert_allclose(lp[0].cpu().numpy(), rlp[0].numpy(), rtol=0, atol=1e-3)
+    # predict_LP on identical logits: same cell, same pose row
+    r_max = [45, 60, 45]
+    lp_ref = lp[0].cpu().numpy()
+    pred = predict_LP_batch(lp, spec['LP_slice_point'], r_max)
+    rpred, rbest = od.predict_LP_batch([lp_ref], spec['LP_slice_point'], r_max)
+    np.testing.assert_allclose(pred, rpred, rtol=1e-6, atol=1e-6)
+    assert pred.shape == (3, 7)
+
+
+def test_carlpnet_bf16_and_gluon_file(cuda, tmp_path):
+    from yolo_amd.net import CarLPNet
+    spec, size = _lp_spec(), (64, 96)
+    g = og.build_graph(spec)
+    P = og.init_params(g, seed=5, bn='random')
+    x = np.random.default_rng(6).random((2, 3) + size, dtype=np.float32)
+    net = CarLPNet(spec, dtype='bf16', device=cuda).load_params(P)
+    outs, lp = net(torch.from_numpy(x).to(cuda))
+    routs, rlp = of.forward_torch(g, P, x, sim_bf16=True)
+    f32o, f32lp = of.forward_torch(g, P, x)
+    sim_err = float(np.sqrt(np.mean((rlp[0].numpy() - f32lp[0].numpy()) ** 2)))
+    err = float(np.sqrt(np.mean((lp[0].cpu().numpy() - f32lp[0].numpy()) ** 2)))
+    assert err <= 1.5 * sim_err + 1e-3, (err, sim_err)
+    # the LP branch's parameters travel through the gluon container in registration order (after the car heads)
+    path = str(tmp_path / 'carlp.params')
+    net.save_gluon_params(path)
+    net2 = CarLPNet(spec, dtype='bf16', device=cuda).load_gluon_params(path)
+    outs2, lp2 = net2(torch.from_numpy(x).to(cuda))
+    assert torch.equal(lp[0], lp2[0]) and all(torch.equal(a, b) for a, b in zip(outs, outs2))
+
+
+def test_carlpnet_reference_spec_shapes(cuda):
+    """car_and_LP/v1/spec.yaml at its native 320x512: 6 stages, 80 channels per anchor, LP branch on the 40x64 map."""
+    from yolo_amd.net import CarLPNet
+    spec = dict(layers=[1, 4, 4, 8, 8, 4], channels=[16, 32, 64, 128, 256, 512, 1024], slice_point=[1, 3, 5, 6, 80],
+                all_anchors=[[[0.31242, 0.29083], [0.36752, 0.45009], [0.59300, 0.44627]],
+                             [[0.45821, 0.65497], [0.62137, 0.67607], [0.83896, 0.64288]],
+                             [[0.68232, 0.90531], [1.06267, 0.78875], [0.92839, 1.03793]]],
+                LP_slice_point=[1, 3, 4, 7, 10])
+    net = CarLPNet(spec, dtype='bf16', device=cuda).initialize(2)
+    outs, lp = net(torch.rand((2, 3, 320, 512), device=cuda))
+    assert [tuple(o.shape) for o in outs] == [(2, 20 * 32, 3, 80), (2, 10 * 16, 3, 80), (2, 5 * 8, 3, 80)]
+    assert tuple(lp[0].shape) == (2, 20, 32, 10)
+    assert all(bool(torch.isfinite(t).all()) for t in outs + lp)

@@ -132,3 +132,18 @@ def test_exported_symbol_order_and_shape_check(tmp_path):
     # a file in the other order fails the shape check instead of loading silently wrong
     with pytest.raises(mp.ParamsFormatError):
         mp.from_gluon(g, mp.read_params(p), order='registration')
+
+
+def test_gluon_order_with_lp_branch():
+    spec = dict(MID, LP_slice_point=[1, 3, 4, 7, 10])
+    g = NetGraph(spec)
+    reg = [c.name for c in mp.gluon_conv_order(g, 'registration')]
+    fwd = [c.name for c in mp.gluon_conv_order(g, 'forward')]
+    assert sorted(reg) == sorted(fwd) == sorted(c.name for c in g.convs()) and len(reg) == len(set(reg))
+    # CarLPNet.__init__ (car_and_LP/YOLO.py:47-60) registers LP_branch after the base class's blocks ...
+    assert reg[-31:] == ['lp.%d.%s' % (k, n) for k in range(5) for n in ('b0', 'b1', 'b2', 'b3', 'b4', 'tip')] + ['lp.out']
+    # ... and runs it before the finest detection block (:72-79)
+    assert fwd.index('lp.out') + 1 == fwd.index('heads.2.b0')
+    P = _random_params(g, 2)
+    back = mp.from_gluon(g, mp.to_gluon(g, P))
+    assert all(np.array_equal(back[k], P[k]) for k in P)

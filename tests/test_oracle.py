@@ -183,3 +183,27 @@ def test_plumbing_config1():
     assert best == int(np.argmax(out[0, 0].reshape(-1)))
     assert 0 < pred[0] < 1 and np.all(np.abs(pred[4:7]) <= 40 * np.pi / 180 + 1e-6)
     assert ot.split_render_data(list(range(10)), 4) == [[0, 1], [2, 3, 4], [5, 6], [7, 8, 9]]
+
+
+def test_lp_branch_two_restatements_agree_and_predict_lp():
+    """CarLPNet's LP branch (car_and_LP/YOLO.py:47-95): the torch-fp32 and numpy-fp64 restatements agree, and
+    predict_LP picks the cell with the highest sigmoid(score) and applies LP_pose_activation."""
+    import math
+    from oracle import graph as og, forward as of, detect as od
+    spec = dict(og.spec_micro(), LP_slice_point=[1, 3, 4, 7, 10])
+    g = og.build_graph(spec)
+    assert len(og.conv_list(g)) == len(og.conv_list(og.build_graph(og.spec_micro()))) + 31
+    P = og.init_params(g, 1, 'random')
+    x = np.random.default_rng(2).random((2, 3, 64, 64), dtype=np.float32)
+    (o1, l1), (o2, l2) = of.forward_torch(g, P, x), of.forward_numpy64(g, P, x)
+    assert l1[0].shape == (2, 8, 8, 10)
+    assert max(np.abs(a.numpy() - b).max() for a, b in zip(o1, o2)) < 1e-5
+    assert np.abs(l1[0].numpy() - l2[0]).max() < 1e-5
+    lp = np.zeros((1, 2, 3, 10), np.float32)
+    lp[0, 1, 2, :7] = [2.0, 0.01, -0.02, 0.003, 0.0, 1.0, -1.0]
+    lp[0, 0, 0, 0] = 1.0
+    pred, best = od.predict_LP_batch([lp], [1, 3, 4, 7, 10], [45, 60, 45])
+    assert best.tolist() == [5] and pred.shape == (1, 7)
+    sg = lambda v: 1.0 / (1.0 + math.exp(-v))
+    expect = [sg(2.0), 10.0, -20.0, 3.0, 0.0, (sg(1.0) - 0.5) * 2 * 60 * math.pi / 180, (sg(-1.0) - 0.5) * 2 * 45 * math.pi / 180]
+    np.testing.assert_allclose(pred[0], expect, rtol=1e-5, atol=1e-6)

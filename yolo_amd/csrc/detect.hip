@@ -646,3 +646,58 @@ extern "C" int yolo_predict_lp(const float* out, float* pred, int* best_idx, int
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
+
+// ---- CarLPNet.predict_LP + LP_pose_activation (car_and_LP/YOLO.py:133-169) ----------------------------------
+// out (B, HW, C) float32 NHWC as the LP branch writes it -> pred (B, 7): per image the cell with the highest
+// sigmoid(score) (first index among ties -- the arg-max is taken over the SIGMOID, which saturates), then
+// [sigmoid(score), xy*1000, z*1000, three angles (sigmoid - 0.5) * 2 * r_max * pi / 180].
+__global__ __launch_bounds__(256) void predict_lp_nhwc_kernel(const float* __restrict__ out, float* __restrict__ pred,
+                                                              int* __restrict__ best_idx, int C, int hw, float r0,
+                                                              float r1, float r2) {
+    const int b = blockIdx.x;
+    const float* o = out + (long long)b * hw * C;
+    float bv = -FLT_MAX; int bi = 0x7fffffff;
+    for (int k = threadIdx.x; k < hw; k += blockDim.x) {
+        const float v = sigmoidf_ref(o[(long long)k * C]);
+        if (v > bv) { bv = v; bi = k; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(bv, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        argmax_combine(bv, bi, ov, oi);
+    }
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) argmax_combine(bv, bi, sv[w], si[w]);
+        si[0] = bi;
+        best_idx[b] = bi;
+    }
+    __syncthreads();
+    const int k = si[0];
+    const int c = threadIdx.x;
+    if (c < 7) {
+        float v = o[(long long)k * C + c];
+        if (c == 0) v = sigmoidf_ref(v);
+        else if (c < 4) v = v * 1000.f;
+        else {
+            const float r = c == 4 ? r0 : (c == 5 ? r1 : r2);
+            v = (sigmoidf_ref(v) - 0.5f) * 2.f * r;
+            v = v * 3.14159274101257324f / 180.f;
+        }
+        pred[b * 7 + c] = v;
+    }
+}
+
+extern "C" int yolo_predict_lp_nhwc(const float* out, float* pred, int* best_idx, int B, int hw, int C, float r_max0,
+                                    float r_max1, float r_max2, void* stream) {
+    if (!out || !pred || !best_idx || B <= 0 || hw <= 0 || C < 7) return YOLO_EINVAL;
+    YOLO_LAUNCH(predict_lp_nhwc_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, out, pred, best_idx, C, hw, r_max0,
+                r_max1, r_max2);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}
+

@@ -169,3 +169,19 @@ def predict_LP(batch_out, r_max):
     L.check(L.load().yolo_predict_lp(L.ptr(o), L.ptr(pred), L.ptr(idx), Cc, h, w, float(r_max[0]), float(r_max[1]),
                                      float(r_max[2]), L.stream_ptr()), 'predict_lp')
     return pred.cpu().numpy()
+
+
+def predict_LP_batch(LP_batch_out, LP_slice_point, r_max):
+    """CarLPNet's predict_LP (car_and_LP/YOLO.py:133-169): [ (B,h,w,C) float32 CUDA ] -> np.float32 (B,7) rows
+    [sigmoid(score), x, y, z (x1000), r1, r2, r3 (rad)] of the best cell of every image."""
+    if list(LP_slice_point[:4]) != [1, 3, 4, 7]:
+        raise ValueError('predict_LP expects LP_slice_point [1,3,4,7,C]')
+    o = LP_batch_out[0] if isinstance(LP_batch_out, (list, tuple)) else LP_batch_out
+    o = o.contiguous()
+    B, h, w, Cc = o.shape
+    pred = torch.empty((B, 7), dtype=torch.float32, device=o.device)
+    idx = torch.empty((B,), dtype=torch.int32, device=o.device)
+    L.check(L.load().yolo_predict_lp_nhwc(L.ptr(o), L.ptr(pred), L.ptr(idx), B, h * w, Cc, float(r_max[0]),
+                                          float(r_max[1]), float(r_max[2]), L.stream_ptr()), 'predict_lp_nhwc')
+    return pred.cpu().numpy()
+

@@ -133,13 +133,21 @@ def gluon_conv_order(graph, order='registration'):
         for c1, c2 in res:
             convs += [c1, c2]
     heads = graph.heads                                   # deep -> shallow, as YOLOPyrmaid builds them
+    lp = []
+    for body, tip in getattr(graph, 'lp_blocks', []):
+        lp += list(body) + [tip]
+    if getattr(graph, 'lp_out', None) is not None:
+        lp.append(graph.lp_out)
     if order == 'registration':
         convs += list(graph.transitions)
         for body, tip, out, _ in heads:
             convs += list(body) + [tip]
         convs += [out for _, _, out, _ in heads]
+        convs += lp                                       # CarLPNet registers LP_branch after the base class's blocks
     elif order == 'forward':
         for i, (body, tip, out, _) in enumerate(heads):
+            if i == len(heads) - 1:
+                convs += lp                               # the LP branch runs before the finest detection block
             convs += list(body) + [tip, out]
             if i < len(graph.transitions):
                 convs.append(graph.transitions[i])

@@ -26,6 +26,7 @@ class _Plan(object):
         self.buffers = []    # keeps tensors alive
         self.x_nhwc = None
         self.merged = None
+        self.lp = None       # CarLPNet: (B, h, w, LP channels) float32
         self.offsets = None
         self.act = {}        # name -> (tensor, (N,H,W,C)) for parity taps
 
@@ -221,6 +222,14 @@ class CarNet(object):
         offs = [sum(hw[:k]) for k in range(len(hw))]
         plan.offsets = list(zip(offs, hw))
         for i, (body, tip, outc, nA) in enumerate(g.heads):
+            if g.lp_out is not None and i >= len(g.heads) - 1:
+                # CarLPNet.hybrid_forward (car_and_LP/YOLO.py:72-79): the LP branch reads the finest block's input
+                t, tshp = x, shp
+                for lbody, ltip in g.lp_blocks:
+                    for c in lbody + [ltip]:
+                        t, tshp = self._conv_op(plan, c, t, tshp)
+                plan.lp = torch.empty((tshp[0], tshp[1], tshp[2], g.lp_out.cout), dtype=torch.float32, device=self.device)
+                self._conv_op(plan, g.lp_out, t, tshp, out=plan.lp.data_ptr(), out_f32=True)
             for c in body:
                 x, shp = self._conv_op(plan, c, x, shp)
             route, rshp = x, shp
@@ -262,7 +271,10 @@ class CarNet(object):
                 raise L.YoloError('%s (%s) failed with status %d' % (kind, name, rc))
         self._last_plan = plan
         A = self.graph.heads[0][3]
-        return [plan.merged[:, o:o + n].view(B, n, A, self.graph.per_anchor) for o, n in plan.offsets]
+        outs = [plan.merged[:, o:o + n].view(B, n, A, self.graph.per_anchor) for o, n in plan.offsets]
+        if self.graph.lp_out is not None:
+            return outs, [plan.lp]                 # CarLPNet: (all_output[::-1], [LP_output]), car_and_LP/YOLO.py:95
+        return outs
 
     __call__ = forward
 
@@ -331,3 +343,14 @@ class CarNet(object):
         L.check(self._lib.yolo_nhwc_to_nchw(L.ptr(t), L.ptr(out), N, Cc, H, W, _LIB_DT[self.dtype], L.stream_ptr()),
                 'nhwc_to_nchw')
         return out
+
+
+class CarLPNet(CarNet):
+    """car_and_LP/YOLO.py:47-95: CarNet + the licence-plate branch.  forward(x) -> (outs, [LP_output]) with
+    LP_output (B, h, w, LP_slice_point[-1]) float32 at the finest scale."""
+
+    def __init__(self, spec, *args, **kwargs):
+        if 'LP_slice_point' not in spec:
+            raise ValueError("CarLPNet needs spec['LP_slice_point'] (car_and_LP/v1/spec.yaml)")
+        super(CarLPNet, self).__init__(spec, *args, **kwargs)
+

@@ -64,6 +64,21 @@ class NetGraph(object):
             self.heads.append((body, tip, out, len(anchor)))
             if i > 0:
                 self.transitions.append(ConvSpec('transitions.%d' % (i - 1), pyr[i - 1], ch, 1))
+        # CarLPNet's licence-plate branch (car_and_LP/YOLO.py:47-60): five YOLODetectionBlockV3(channels[-3]) chained
+        # through their tip outputs on the input of the finest detection block + a biased 1x1 to LP_slice_point[-1]
+        self.lp_blocks, self.lp_out = [], None
+        if 'LP_slice_point' in spec:
+            self.lp_slice_point = list(spec['LP_slice_point'])
+            lpc = channels[-3]
+            c_prev = 2 * pyr[-1] if self.num_pyramid > 1 else channels[-1]
+            for k in range(5):
+                body = []
+                for b, (cout, kk) in enumerate([(lpc, 1), (2 * lpc, 3), (lpc, 1), (2 * lpc, 3), (lpc, 1)]):
+                    body.append(ConvSpec('lp.%d.b%d' % (k, b), c_prev, cout, kk))
+                    c_prev = cout
+                self.lp_blocks.append((body, ConvSpec('lp.%d.tip' % k, lpc, 2 * lpc, 3)))
+                c_prev = 2 * lpc
+            self.lp_out = ConvSpec('lp.out', 2 * lpc, self.lp_slice_point[-1], 1, bn=False)
 
     def convs(self):
         out = [self.stem]
@@ -73,7 +88,10 @@ class NetGraph(object):
                 out += [c1, c2]
         for body, tip, o, _ in self.heads:
             out += body + [tip, o]
-        return out + self.transitions
+        out = out + self.transitions
+        for body, tip in self.lp_blocks:
+            out += body + [tip]
+        return out + ([self.lp_out] if self.lp_out is not None else [])
 
     def steps(self):
         """car/YOLO.py:112-116."""
@@ -99,6 +117,12 @@ class NetGraph(object):
                 tot += f(c, hh, ww)[0]
             if i < len(self.transitions):
                 tot += f(self.transitions[i], hh, ww)[0]
+        if self.lp_out is not None:
+            hh, ww = sizes[-1]
+            for body, tip in self.lp_blocks:
+                for c in body + [tip]:
+                    tot += f(c, hh, ww)[0]
+            tot += f(self.lp_out, hh, ww)[0]
         return tot
 
 

@@ -42,6 +42,9 @@ class Trainer(object):
         self.pos_w, self.neg_w, self.car_rotate = positive_weight, negative_weight, car_rotate
         self.t = 0
         g = net.graph
+        if getattr(g, 'lp_out', None) is not None:
+            raise NotImplementedError('the LP-branch losses (car_and_LP/YOLO.py) are not built: train the car heads '
+                                      'with a spec without LP_slice_point')
         self.grid, self.nbox = make_grid(g.anchors, self.size, g.steps())
         self.anchors_ltrb = torch.from_numpy(default_ltrb(g.anchors, self.size, g.steps())).to(self.dev).contiguous()
         # ---- flat parameter / gradient / Adam-state buffers; net.params become views of wflat ------------
