@@ -95,6 +95,10 @@ int yolo_stem_conv_fwd(const float* x_nchw, const float* w_oihw, const float* sc
                        void* y, int N, int H, int W, int Cin, int Cout, int dtype, float slope,
                        void* stream);
 
+/* Synthetic-target compositing of RenderCar.render (car/render_car.py:135-137): out = clip((bg / 255) * (1 - mask) +
+ * fg * mask, 0, 1) over n float32 elements (n % 4 == 0; (B,3,H,W) tensors: bg 0..255, fg and mask 0..1). */
+int yolo_composite(const float* bg, const float* fg, const float* mask, float* out, long long n, void* stream);
+
 /* 2x nearest up-sample of `up` (N,H/2,W/2,C1) + channel concat with `route` (N,H,W,C2) ->
  * (N,H,W,C1+C2), up-sampled channels first: gluoncv _upsample + F.concat, car/utils.py:92-93. */
 int yolo_upsample2x_concat(const void* up, const void* route, void* y, int N, int H, int W,
