@@ -34,7 +34,6 @@ struct ConvArgs {
     int out_f32;
     float slope;
     long long y_bs, y_ps;
-    int dbg;            // unused (kept for ABI stability of the argument block)
     FastDiv d_PW, d_H1, d_TWt, d_Ho, d_HoWo, d_tc, d_tps;   // divisors PW, H+1, TWt, Ho, Ho*Wo, tiles_c, tiles_per_strip
 };
 

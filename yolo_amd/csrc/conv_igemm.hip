@@ -355,8 +355,6 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     a.Cout_pad = round_up(d->Cout, YOLO_COUT_PAD);
     a.nchunks = (d->Cin * es + 63) / 64;
     a.out_f32 = d->out_f32;
-    a.dbg = 0;
-    if (const char* e = getenv("YOLO_DBG")) a.dbg = atoi(e);
     a.slope = d->slope;
     a.y_ps = d->y_pixel_stride ? d->y_pixel_stride : d->Cout;
     a.y_bs = d->y_batch_stride ? d->y_batch_stride : (long long)a.Ho * a.Wo * a.y_ps;

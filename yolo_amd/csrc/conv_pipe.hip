@@ -331,10 +331,6 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
             const int hs = conv_halo_slots(BP, d, a.Ho, a.H, S, (long long)a.N * a.Ho);
             if (hs <= XSLOTS && hs <= best_hs) { best = d; best_hs = hs; }
         }
-        if (const char* e = getenv("YOLO_FORCE_TWT")) {     // experiment knob: force the strip width
-            const int d = atoi(e);
-            if (d > 0 && a.Wo % d == 0 && conv_halo_slots(BP, d, a.Ho, a.H, S, (long long)a.N * a.Ho) <= XSLOTS) best = d;
-        }
         if (best < 0) return YOLO_EUNSUPPORTED;
         a.TWt = best;
         a.PW = (best - 1) * S + 3;

@@ -510,8 +510,7 @@ static void wgrad_bf16_launch(const uint16_t* dy, const uint16_t* x, float* ws, 
     const int tiles_ci = (Cin + BN - 1) / BN, tiles_co = (Cout + BM - 1) / BM, taps = ksize * ksize;
     const long long chunks = ((long long)N * Ho * Wo + WG_KC - 1) / WG_KC;
     const long long tiles = (long long)tiles_ci * tiles_co * taps;
-    long long target = (MI * NI >= 8) ? 512 : 768;               // blocks in flight: 2-3 per CU
-    if (const char* e = getenv("YOLO_WGRAD_BLOCKS")) target = atoi(e);
+    const long long target = 768;                                // blocks in flight: ~3 per CU
     long long slices = (target + tiles - 1) / tiles;
     if (slices > chunks) slices = chunks;
     if (slices < 1) slices = 1;
@@ -860,8 +859,7 @@ static void wgrad_rows_launch(const uint16_t* dy, const uint16_t* x, float* dwt,
     const int tiles = tiles_ci * tiles_co;
     const int gpi = (H + TH - 1) / TH;
     const long long groups = (long long)N * gpi;
-    long long target = 512;                                   // measured best of 256..1024 (2 blocks per CU)
-    if (const char* e = getenv("YOLO_WGRAD_ROWS_BLOCKS")) target = atoi(e);
+    const long long target = 512;                             // measured best of 256..1024 (2 blocks per CU)
     long long nb = (target + tiles - 1) / tiles;              // every block ends with a 64x64x9 atomic tile
     if (nb > groups) nb = groups;
     if (nb < 1) nb = 1;
@@ -926,9 +924,7 @@ extern "C" int yolo_conv_wgrad(const void* dy, const void* x, float* dw_oihw, in
     (void)hipGetLastError();
     const long long wsb = (long long)Cin * Cout * taps * 4;
     const long long total = (long long)Cin * Cout * taps;
-    int strip_max_cin = 64;
-    if (const char* e = getenv("YOLO_WGRAD_STRIP_CIN")) strip_max_cin = atoi(e);
-    if (ksize == 3 && Cin <= strip_max_cin) {
+    if (ksize == 3 && Cin <= 64) {
         (void)hipMemsetAsync(workspace, 0, wsb, st);
         const uint16_t* d16 = (const uint16_t*)dy;
         const uint16_t* x16 = (const uint16_t*)x;
@@ -943,7 +939,7 @@ extern "C" int yolo_conv_wgrad(const void* dy, const void* x, float* dw_oihw, in
     }
     // row-group kernel: wins on the narrow deep maps (26x26: 210 -> 163 us, 13x13: 211 -> 175 us at batch 64); on wider
     // maps its atomic epilogue (one 64x64x9 tile per block) costs more than the saved L2 traffic
-    if (ksize == 3 && stride == 1 && W <= 40 && !getenv("YOLO_WGRAD_NO_ROWS")) {
+    if (ksize == 3 && stride == 1 && W <= 40) {
         (void)hipMemsetAsync(workspace, 0, wsb, st);
         if (wgrad_rows_dispatch((const uint16_t*)dy, (const uint16_t*)x, (float*)workspace, N, H, W, Cin, Cout, ps, st)) {
             YOLO_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
@@ -956,12 +952,8 @@ extern "C" int yolo_conv_wgrad(const void* dy, const void* x, float* dw_oihw, in
         const uint16_t* d16 = (const uint16_t*)dy;
         const uint16_t* x16 = (const uint16_t*)x;
         float* ws = (float*)workspace;
-        int tile = 22;                                        // wider tiles: one wave per SIMD, measured slower
-        if (const char* e = getenv("YOLO_WGRAD_TILE")) tile = atoi(e);
-        if (tile == 44) wgrad_bf16_launch<4, 4>(d16, x16, ws, N, H, W, Cin, Ho, Wo, Cout, ksize, stride, ps, st);
-        else if (tile == 42) wgrad_bf16_launch<4, 2>(d16, x16, ws, N, H, W, Cin, Ho, Wo, Cout, ksize, stride, ps, st);
-        else if (tile == 24) wgrad_bf16_launch<2, 4>(d16, x16, ws, N, H, W, Cin, Ho, Wo, Cout, ksize, stride, ps, st);
-        else wgrad_bf16_launch<2, 2>(d16, x16, ws, N, H, W, Cin, Ho, Wo, Cout, ksize, stride, ps, st);
+        // (256x128 / 128x256 / 256x256 tiles were measured 10-40 % slower: one wave per SIMD)
+        wgrad_bf16_launch<2, 2>(d16, x16, ws, N, H, W, Cin, Ho, Wo, Cout, ksize, stride, ps, st);
     }
     YOLO_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
                 dw_oihw, Cout, Cin, taps, total);
