@@ -180,11 +180,12 @@ class CarNet(object):
 
         # two passes: a short one over every variant, then the three fastest again with 4x the launches -- a single
         # short timing is noisy enough (DVFS, neighbours' tails) to pick a variant that is 5 % slower
+        top, mult = 3, 4
         first = [(t, a) for a in self.ALGOS for t in [time_algo(a, iters)] if t is not None]
         first.sort()
         best, best_t = 1, float('inf')
-        for _, algo in first[:3]:
-            t = time_algo(algo, 4 * iters)
+        for _, algo in first[:top]:
+            t = time_algo(algo, mult * iters)
             if t < best_t:
                 best, best_t = algo, t
         d.algo = 0
