@@ -145,3 +145,40 @@ def test_train_step_bf16(cuda):
     for _ in range(30):
         last = float(tr.train_step(xt, lt).sum())
     assert last < 0.7 * first, (first, last)
+
+
+def test_multiple_objects_per_image_with_collision(cuda):
+    """labels (B, nobj=3, 6+C): the reference's scatter loop (car/YOLO.py:466-478) lets the LAST object that maps
+    to a box overwrite the earlier one; rows with cls < 0 are skipped.  Assignment records, losses and d/d(logits)
+    against the oracle."""
+    import ctypes as C
+    spec, size, g, P, x, lab1, net, tr = _setup(cuda, B=3, seed_lab=11)
+    rng = np.random.default_rng(12)
+    lab = -np.ones((3, 3, 6 + 4), np.float32)
+    for b in range(3):
+        for o in range(3):
+            d = rng.random(4).astype(np.float32); d /= d.sum()
+            lab[b, o, :6] = [int(np.argmax(d)), rng.uniform(.2, .8), rng.uniform(.2, .8), rng.uniform(.2, .9), rng.uniform(.2, .9), 0.1]
+            lab[b, o, 6:] = d
+    lab[0, 2, :5] = lab[0, 0, :5]            # image 0: objects 0 and 2 land on the same box (different class rows)
+    lab[1, 1] = -1                           # image 1: a hole in the middle of the object list
+    lab[2] = -1                              # image 2: no object at all
+    merged = (1.5 * rng.standard_normal((3, tr.nbox // 3, 3, 10))).astype(np.float32)
+    rl, gout, (y, mask, sw) = ot.loss_and_grad_wrt_output(merged, lab, spec, size)
+    assert mask[0].sum() == 2 and mask[1].sum() == 2 and mask[2].sum() == 0
+    lib = tr.lib
+    logits = torch.from_numpy(merged).to(cuda).contiguous()
+    labels = torch.from_numpy(lab).to(cuda)
+    rec = torch.empty((3, 3, 7 + 4), device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.yolo_assign_targets(labels.data_ptr(), tr.anchors_ltrb.data_ptr(), rec.data_ptr(), 3, 3, 4, C.byref(tr.grid), st) == 0
+    r = rec.cpu().numpy()
+    assert r[0, 0, 1] == r[0, 2, 1] and r[1, 1, 0] == 0 and (r[2, :, 0] == 0).all()
+    dl = torch.empty_like(logits); ls = torch.empty((5, 3), device=cuda)
+    s5 = (C.c_float * 5)(0.1, 0.01, 10.0, 0.0, 0.3)
+    assert lib.yolo_loss_fwd_bwd(logits.data_ptr(), rec.data_ptr(), dl.data_ptr(), ls.data_ptr(), 3, tr.nbox, 10, 3, s5, 1.0, 0.1, st) == 0
+    np.testing.assert_allclose(ls.cpu().numpy(), np.stack(rl), rtol=1e-4, atol=1e-8)
+    _close(dl.cpu().numpy().reshape(gout.shape), gout, 1e-4, 'dlogits')
+    # and through the whole step (3 objects per image)
+    losses = tr.train_step(torch.from_numpy(x[:1].repeat(3, 0)).to(cuda), labels, update=False)
+    assert losses.shape == (5, 3) and bool(torch.isfinite(losses).all()) and float(losses[2, 2]) == 0.0
