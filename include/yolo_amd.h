@@ -224,6 +224,17 @@ int yolo_assign_targets(const float* labels, const float* anchors_ltrb, float* r
 int yolo_loss_fwd_bwd(const float* logits, const float* records, float* dlogits, float* losses, int B,
                       int nbox, int C, int nobj, const float* scales5_host, float pos_w, float neg_w,
                       void* stream);
+
+/* CarLPNet's licence-plate branch (licence_plate/LP_detection.py:258-360, car_and_LP/YOLO.py:262-300).
+ * yolo_assign_targets_lp = _find_best_LP + the scatter of _loss_mask_LP: labels (B, nobj, lab_w >= 10) rows
+ * [flag (<0: none), X, Y, Z (mm), r1, r2, r3 (rad), x_px, y_px, ..., type] -> records (B, nobj, 8 + ncls)
+ * [valid, cell = clip(int(y_px/step))*w_ + clip(int(x_px/step)), XYZ/1000, inv_sigmoid(r/r_max/2 + 0.5) x3,
+ * one-hot type].  yolo_loss_lp_fwd_bwd = _score_weight_LP + _get_loss_LP + backward on the LP output
+ * (B, ncell, C) [score, xy(2), z(1), r(3), class(C-7)]: losses (5, B) [LP_score, LP_xy, LP_z, LP_r, LP_class]. */
+int yolo_assign_targets_lp(const float* labels, float* records, int B, int nobj, int lab_w, int ncls, int img_h,
+                           int img_w, int step, float r_max0_deg, float r_max1_deg, float r_max2_deg, void* stream);
+int yolo_loss_lp_fwd_bwd(const float* logits, const float* records, float* dlogits, float* losses, int B,
+                         int ncell, int C, int nobj, const float* scales5, float pos_w, float neg_w, void* stream);
 /* mxnet Adam, t = 1-based update count, rescale = 1/global batch
  * (trainer.step(batch_size), car/YOLO.py:396). */
 int yolo_adam_step(float* w, const float* grad, float* m, float* v, long long n, int t, float lr,

@@ -209,3 +209,114 @@ def train_step_reference(g, P, x, labels, spec, size, scale=DEFAULT_SCALE, sim_b
     sum(l.sum() for l in losses).backward()
     grads = {k: t.grad.numpy() for k, t in Pt.items() if t.requires_grad and t.grad is not None}
     return [l.detach().numpy() for l in losses], grads, merged.detach().numpy()
+
+
+# ---- CarLPNet: the licence-plate losses (licence_plate/LP_detection.py:258-360, car_and_LP/YOLO.py:262-300) ---------
+LP_DEFAULT_SCALE = {'LP_score': 0.1, 'LP_xy': 10.0, 'LP_z': 1.0, 'LP_r': 0.1, 'LP_class': 0.0}   # car_and_LP/v1/spec.yaml
+
+
+def find_best_LP(L, size, step, r_max):
+    """LP_detection.py:258-280.  L: (10,) LP label [flag, X, Y, Z (mm), r1, r2, r3 (rad), x_px, y_px, type].
+    Returns ((h_feature, w_feature), [tX, tY, tZ, tr1, tr2, tr3])."""
+    L = np.asarray(L, f32)
+    h_max, w_max = size[0] // step - 1, size[1] // step - 1
+    h_f = int(np.clip(int(L[8] / f32(step)), 0, h_max))
+    w_f = int(np.clip(int(L[7] / f32(step)), 0, w_max))
+    t = [L[1] / f32(1000.), L[2] / f32(1000.), L[3] / f32(1000.)]
+    for i in range(3):
+        rm = f32(r_max[i] * math.pi / 180.)
+        t.append(inv_sigmoid(L[4 + i] / rm / f32(2.) + f32(0.5)))
+    return (h_f, w_f), np.asarray(t, f32)
+
+
+def loss_mask_LP(labels, size, step, r_max, num_class):
+    """LP_detection.py:282-312.  labels (B, nobj, 10).  Returns ([score, xy, z, r, cls], mask), each (B, h, w, k)."""
+    labels = np.asarray(labels, f32)
+    bs, h_, w_ = labels.shape[0], size[0] // step, size[1] // step
+    score = np.zeros((bs, h_, w_, 1), f32); mask = np.zeros((bs, h_, w_, 1), f32)
+    xy = np.zeros((bs, h_, w_, 2), f32); z = np.zeros((bs, h_, w_, 1), f32)
+    r = np.zeros((bs, h_, w_, 3), f32); cls = np.zeros((bs, h_, w_, num_class), f32)
+    for b in range(bs):
+        for L in labels[b]:
+            if L[0] < 0:
+                continue
+            (hf, wf), p = find_best_LP(L, size, step, r_max)
+            score[b, hf, wf] = 1.0; mask[b, hf, wf] = 1.0
+            xy[b, hf, wf] = p[:2]; z[b, hf, wf] = p[2]; r[b, hf, wf] = p[3:]
+            cls[b, hf, wf, int(L[-1])] = 1
+    return [score, xy, z, r, cls], mask
+
+
+def get_loss_LP(x, y, s_weight, mask, scale=LP_DEFAULT_SCALE):
+    """LP_detection.py:354-360."""
+    T = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+    y = [T(v) for v in y]
+    s_weight, mask = T(s_weight), T(mask)
+    s = logistic_loss(x[0], y[0], s_weight * scale['LP_score'])
+    xy = huber_loss(x[1], y[1], mask * scale['LP_xy'])
+    z = huber_loss(x[2], y[2], mask * scale['LP_z'])
+    r = huber_loss(x[3], y[3], mask * scale['LP_r'])
+    c = softmax_ce_loss(x[4], y[4], mask * scale['LP_class'])
+    return s, xy, z, r, c
+
+
+def lp_loss_and_grad_wrt_output(lp_out, lp_labels, size, step, r_max, slice_point, scale=LP_DEFAULT_SCALE,
+                                positive_weight=1.0, negative_weight=0.1):
+    """Loss vectors and d(sum of LP losses)/d(LP output) for an (B,h,w,C) fp32 LP-branch output."""
+    ncls = slice_point[-1] - slice_point[-2]
+    y, mask = loss_mask_LP(lp_labels, size, step, r_max, ncls)
+    sw = score_weight(mask, positive_weight, negative_weight)
+    out = torch.from_numpy(np.ascontiguousarray(lp_out)).float().requires_grad_(True)
+    xs, i = [], 0
+    for pt in slice_point:
+        xs.append(out[..., i:pt]); i = pt
+    losses = get_loss_LP(xs, y, sw, mask, scale)
+    sum(l.sum() for l in losses).backward()
+    return [l.detach().numpy() for l in losses], out.grad.numpy(), (y, mask)
+
+
+def synthetic_lp_labels(batch, size, seed=4, add_rate=0.5, r_max=(45, 60, 45), num_class=3):
+    """LP targets in LPGenerator.add's layout (licence_plate_render/__init__.py:134-166): (B,1,10)
+    [1, X, Y, Z (mm), r1, r2, r3 (rad), x_px, y_px, type]; rows of -1 = no plate."""
+    rng = np.random.default_rng(seed)
+    lab = -np.ones((batch, 1, 10), f32)
+    for b in range(batch):
+        if rng.random() > add_rate:
+            continue
+        r = [rng.uniform(-0.9, 0.9) * rm * math.pi / 180. for rm in r_max]
+        lab[b, 0] = [1, rng.uniform(-2000, 2000), rng.uniform(-1000, 1000), rng.uniform(2000, 9000), r[0], r[1], r[2],
+                     rng.uniform(0, size[1]), rng.uniform(0, size[0]), rng.integers(0, num_class)]
+    return lab
+
+
+def train_step_reference_lp(g, P, x, labels, lp_labels, spec, size, scale=DEFAULT_SCALE, lp_scale=LP_DEFAULT_SCALE,
+                            sim_bf16=False):
+    """CarLPNet's _train_batch (car_and_LP/YOLO.py:262-300): the five car losses + the five LP losses, one backward."""
+    Pt = {}
+    for k, v in P.items():
+        t = torch.from_numpy(np.ascontiguousarray(v)).clone()
+        if k.endswith(('.weight', '.gamma', '.beta', '.bias')):
+            t.requires_grad_(True)
+        Pt[k] = t
+    outs, lp = forward_torch(g, Pt, x, training=True, sim_bf16=sim_bf16)
+    merged = torch.cat(outs, dim=1)
+    steps = detect.init_steps(spec['layers'], spec['all_anchors'])
+    area = detect.init_area(size, steps)
+    anchors_ltrb = detect.get_default_ltrb(size, steps, spec['all_anchors'])
+    sp = spec['slice_point']
+    y, mask = loss_mask(labels, anchors_ltrb, spec['all_anchors'], size, steps, area, sp[-1] - sp[-2])
+    xs, i = [], 0
+    for pt in sp:
+        xs.append(merged[..., i:pt]); i = pt
+    losses = list(get_loss(xs, y, score_weight(mask), mask, scale))
+    lsp = spec['LP_slice_point']
+    ly, lmask = loss_mask_LP(lp_labels, size, steps[0], spec.get('LP_r_max', [45, 60, 45]), lsp[-1] - lsp[-2])
+    lxs, i = [], 0
+    for pt in lsp:
+        lxs.append(lp[0][..., i:pt]); i = pt
+    losses += list(get_loss_LP(lxs, ly, score_weight(lmask, spec.get('LP_positive_weight', 1.0),
+                                                     spec.get('LP_negative_weight', 0.1)), lmask, lp_scale))
+    sum(l.sum() for l in losses).backward()
+    grads = {k: t.grad.numpy() for k, t in Pt.items() if t.requires_grad and t.grad is not None}
+    return [l.detach().numpy() for l in losses], grads, merged.detach().numpy(), lp[0].detach().numpy()
+

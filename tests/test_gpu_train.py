@@ -182,3 +182,88 @@ def test_multiple_objects_per_image_with_collision(cuda):
     # and through the whole step (3 objects per image)
     losses = tr.train_step(torch.from_numpy(x[:1].repeat(3, 0)).to(cuda), labels, update=False)
     assert losses.shape == (5, 3) and bool(torch.isfinite(losses).all()) and float(losses[2, 2]) == 0.0
+
+
+# ---- CarLPNet: joint car + licence-plate training step (car_and_LP/YOLO.py:262-300) ------------------------------
+def _lp_setup(cuda, B=4, dtype='f32'):
+    from yolo_amd.net import CarLPNet
+    from yolo_amd.train import Trainer
+    spec = dict(og.spec_micro(), LP_slice_point=[1, 3, 4, 7, 10], LP_r_max=[45, 60, 45])
+    size = (64, 96)
+    g = og.build_graph(spec)
+    P = og.init_params(g, seed=0, bn='random')
+    x = np.random.default_rng(2).random((B, 3) + size, dtype=np.float32)
+    lab = ot.synthetic_labels(B, seed=1, render_rate=0.25, num_class=4)
+    lpl = ot.synthetic_lp_labels(B, size, seed=2, add_rate=0.75)
+    lpl[0, 0, 7:9] = [size[1] + 40.0, -3.0]                      # a plate centre outside the image: clipped to the edge cell
+    lpl[0, 0, 0] = 1
+    net = CarLPNet(spec, dtype=dtype, device=cuda).load_params(P)
+    tr = Trainer(net, size, lp_r_max=spec['LP_r_max'])
+    return spec, size, g, P, x, lab, lpl, net, tr
+
+
+def test_lp_assignment_and_losses(cuda):
+    import ctypes as C
+    spec, size, g, P, x, lab, lpl, net, tr = _lp_setup(cuda)
+    B = x.shape[0]
+    step = od.init_steps(spec['layers'], spec['all_anchors'])[0]
+    fh, fw = size[0] // step, size[1] // step
+    lp_out = (1.5 * np.random.default_rng(5).standard_normal((B, fh, fw, 10))).astype(np.float32)
+    scale = {'LP_score': 0.1, 'LP_xy': 10.0, 'LP_z': 1.0, 'LP_r': 0.1, 'LP_class': 0.3}     # (class term switched on)
+    rl, gout, (y, mask) = ot.lp_loss_and_grad_wrt_output(lp_out, lpl, size, step, spec['LP_r_max'], spec['LP_slice_point'], scale)
+    lib = tr.lib
+    st = torch.cuda.current_stream().cuda_stream
+    labels = torch.from_numpy(lpl).to(cuda)
+    rec = torch.empty((B, 1, 8 + 3), device=cuda)
+    assert lib.yolo_assign_targets_lp(labels.data_ptr(), rec.data_ptr(), B, 1, 10, 3, size[0], size[1], step, 45.0, 60.0, 45.0, st) == 0
+    r = rec.cpu().numpy()
+    for b in range(B):
+        if lpl[b, 0, 0] < 0:
+            assert r[b, 0, 0] == 0
+            continue
+        (hf, wf), p = ot.find_best_LP(lpl[b, 0], size, step, spec['LP_r_max'])
+        assert r[b, 0, 0] == 1 and int(r[b, 0, 1]) == hf * fw + wf               # bit-exact cell
+        np.testing.assert_allclose(r[b, 0, 2:8], p, rtol=1e-5, atol=1e-6)
+        assert r[b, 0, 8:].tolist() == [1.0 if c == int(lpl[b, 0, -1]) else 0.0 for c in range(3)]
+    assert int(r[0, 0, 1]) == 0 * fw + (fw - 1)                                    # clipped to row 0, last column
+    logits = torch.from_numpy(lp_out.reshape(B, fh * fw, 10)).to(cuda).contiguous()
+    dl = torch.empty_like(logits); ls = torch.empty((5, B), device=cuda)
+    s5 = (C.c_float * 5)(0.1, 10.0, 1.0, 0.1, 0.3)
+    assert lib.yolo_loss_lp_fwd_bwd(logits.data_ptr(), rec.data_ptr(), dl.data_ptr(), ls.data_ptr(), B, fh * fw, 10, 1, s5, 1.0, 0.1, st) == 0
+    np.testing.assert_allclose(ls.cpu().numpy(), np.stack(rl), rtol=1e-4, atol=1e-8)
+    _close(dl.cpu().numpy().reshape(gout.shape), gout, 1e-4, 'd lp logits')
+
+
+def test_carlpnet_train_step(cuda):
+    spec, size, g, P, x, lab, lpl, net, tr = _lp_setup(cuda)
+    xt, lt, lpt = torch.from_numpy(x).to(cuda), torch.from_numpy(lab).to(cuda), torch.from_numpy(lpl).to(cuda)
+    losses = tr.train_step(xt, lt, lp_labels=lpt, update=False)
+    rl, rg, rmerged, rlp = ot.train_step_reference_lp(g, P, x, lab, lpl, spec, size)
+    assert losses.shape == (10, x.shape[0])
+    np.testing.assert_allclose(losses.cpu().numpy(), np.stack(rl), rtol=2e-3, atol=1e-7)
+    grads = tr.grads()
+    assert set(grads) == set(rg)
+    rel = {}
+    for name in sorted(rg):
+        a, b = grads[name].cpu().numpy().astype(np.float64), rg[name].astype(np.float64)
+        rel[name] = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
+    # The LP path of this randomly initialised net is chaotic in train mode (30 more layers, BatchNorm statistics over
+    # 384 samples): perturbing the ORACLE's input by 1e-6 relative moves its own LP output by 2e-3 and its gradients
+    # by 3 % (median).  So: parameters whose gradient does not pass through the chaotic part must match tightly --
+    # the LP output conv and last tip (fed by the strictly tested LP loss kernel), and the finest car head (car
+    # gradient only) -- and everything else must agree in direction.
+    worst = max(rel, key=rel.get)
+    assert rel[worst] < 0.3, (worst, rel[worst])
+    tight = [n for n in rel if n.startswith(('lp.out.', 'lp.4.tip.weight', 'heads.2.'))]
+    assert len(tight) >= 20 and max(rel[n] for n in tight) < 2e-3, max((rel[n], n) for n in tight)
+    lp_names = [n for n in rel if n.startswith('lp.')]
+    assert len(lp_names) == 30 * 3 + 2
+    for name in rg:
+        a, b = grads[name].cpu().numpy().astype(np.float64).ravel(), rg[name].astype(np.float64).ravel()
+        assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30) > 0.95, name
+    with pytest.raises(ValueError):
+        tr.train_step(xt, lt, update=False)                                        # LP labels are required
+    first = float(tr.train_step(xt, lt, lp_labels=lpt).sum())
+    for _ in range(30):
+        last = float(tr.train_step(xt, lt, lp_labels=lpt).sum())
+    assert last < 0.7 * first, (first, last)

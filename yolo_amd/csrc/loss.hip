@@ -112,20 +112,26 @@ extern "C" int yolo_assign_targets(const float* labels, const float* anchors_ltr
 // losses + gradient w.r.t. the logits
 // ------------------------------------------------------------------------------------------------
 struct LossCfg {
-    float s_score, s_yx, s_hw, s_rot, s_cls;     // spec `scale` (car/v1/spec.yaml:31-35); rot is 0 unless car_rotate
+    float s_score, s_g1, s_g2, s_g3, s_cls;      // spec `scale` of the score / three Huber groups / class terms
     float pos_w, neg_w;                          // positive_weight / negative_weight
+    int nh, g1, g2;                              // Huber channels 1..nh in three groups of g1, g2, nh-g1-g2
 };
 
-// logits (B, nbox, C): [obj, ty, tx, th, tw, rot, cls...];  dlogits same shape;  losses (5, B) accumulated
-// atomically (caller zero-fills).  One thread per box.
+// logits (B, nbox, C): [score | Huber group 1 | group 2 | group 3 | cls...];  dlogits same shape;  losses (5, B)
+// accumulated atomically (caller zero-fills).  One thread per box.  record per (image, object):
+// [valid, box index, Huber targets (nh), cls (C-1-nh)].
+//   car head (car/YOLO.py:491-498):          nh = 5: yx (2), hw (2), rot (1)
+//   LP branch (LP_detection.py:354-360):     nh = 6: xy (2), z (1), r (3)
 __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ logits, const float* __restrict__ rec,
                                                    float* __restrict__ dlogits, float* __restrict__ losses, int B,
                                                    int nbox, int C, int nobj, LossCfg cfg) {
     const int b = blockIdx.y;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    const int ncls = C - 6;
-    const int recw = REC_HEAD + ncls;
-    float l_s = 0.f, l_yx = 0.f, l_hw = 0.f, l_r = 0.f, l_c = 0.f;
+    const int nh = cfg.nh;
+    const int ncls = C - 1 - nh;
+    const int rhead = 2 + nh;
+    const int recw = rhead + ncls;
+    float l_s = 0.f, l_1 = 0.f, l_2 = 0.f, l_3 = 0.f, l_c = 0.f;
     if (k < nbox) {
         const float* p = logits + ((long long)b * nbox + k) * C;
         float* d = dlogits + ((long long)b * nbox + k) * C;
@@ -145,45 +151,49 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ log
             l_s = l * w * inv_n;
             d[0] = (1.f / (1.f + expf(-x)) - y) * w * inv_n;
         }
-        // yx / hw / rot: HuberLoss(rho=1), weight = mask * scale, mean over (N,A,k)
+        // Huber groups: HuberLoss(rho=1), weight = mask * scale, mean over (N,A,k) with k the group width
         {
-            const float w_yx = mask * cfg.s_yx * inv_n * 0.5f, w_hw = mask * cfg.s_hw * inv_n * 0.5f;
-            const float w_r = mask * cfg.s_rot * inv_n;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
+            const int g3 = nh - cfg.g1 - cfg.g2;
+            const float w1 = mask * cfg.s_g1 * inv_n / (float)cfg.g1;
+            const float w2 = mask * cfg.s_g2 * inv_n / (float)cfg.g2;
+            const float w3 = mask * cfg.s_g3 * inv_n / (float)(g3 > 0 ? g3 : 1);
+            for (int j = 0; j < nh; ++j) {
                 const float y = R ? R[2 + j] : 0.f;
                 const float df = p[1 + j] - y, ad = fabsf(df);
                 const float l = ad > 1.f ? ad - 0.5f : 0.5f * ad * ad;
                 const float gr = ad > 1.f ? (df > 0.f ? 1.f : -1.f) : df;
-                const float w = j < 2 ? w_yx : (j < 4 ? w_hw : w_r);
-                if (j < 2) l_yx += l * w; else if (j < 4) l_hw += l * w; else l_r += l * w;
+                const int grp = j < cfg.g1 ? 0 : (j < cfg.g1 + cfg.g2 ? 1 : 2);
+                const float w = grp == 0 ? w1 : (grp == 1 ? w2 : w3);
+                if (grp == 0) l_1 += l * w; else if (grp == 1) l_2 += l * w; else l_3 += l * w;
                 d[1 + j] = gr * w;
             }
         }
         // class: soft-label softmax cross-entropy, weight = mask * scale, mean over (N,A,1)
         {
             const float w = mask * cfg.s_cls * inv_n;
+            const float* pc = p + 1 + nh;
+            float* dc = d + 1 + nh;
             if (R) {
                 float m = -FLT_MAX;
-                for (int c = 0; c < ncls; ++c) m = fmaxf(m, p[6 + c]);
+                for (int c = 0; c < ncls; ++c) m = fmaxf(m, pc[c]);
                 float se = 0.f, sy = 0.f;
-                for (int c = 0; c < ncls; ++c) { se += expf(p[6 + c] - m); sy += R[REC_HEAD + c]; }
+                for (int c = 0; c < ncls; ++c) { se += expf(pc[c] - m); sy += R[rhead + c]; }
                 const float lse = m + logf(se);
                 float l = 0.f;
                 for (int c = 0; c < ncls; ++c) {
-                    const float y = R[REC_HEAD + c];
-                    l -= y * (p[6 + c] - lse);
-                    d[6 + c] = (expf(p[6 + c] - lse) * sy - y) * w;
+                    const float y = R[rhead + c];
+                    l -= y * (pc[c] - lse);
+                    dc[c] = (expf(pc[c] - lse) * sy - y) * w;
                 }
                 l_c = l * w;
             } else {
-                for (int c = 0; c < ncls; ++c) d[6 + c] = 0.f;
+                for (int c = 0; c < ncls; ++c) dc[c] = 0.f;
             }
         }
     }
     // block reduction of the five partial losses -> one atomic per block per loss
     __shared__ float red[5][4];
-    float v[5] = {l_s, l_yx, l_hw, l_r, l_c};
+    float v[5] = {l_s, l_1, l_2, l_3, l_c};
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
 #pragma unroll
@@ -192,17 +202,16 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ log
     }
     __syncthreads();
     if (threadIdx.x < 5) {
-        const float s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-        atomicAdd(&losses[threadIdx.x * B + b], s);
+        const float s_ = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        atomicAdd(&losses[threadIdx.x * B + b], s_);
     }
 }
 
-extern "C" int yolo_loss_fwd_bwd(const float* logits, const float* records, float* dlogits, float* losses, int B,
-                                 int nbox, int C, int nobj, const float* scales5, float pos_w, float neg_w,
-                                 void* stream) {
-    if (!logits || !records || !dlogits || !losses || !scales5 || B <= 0 || nbox <= 0 || C < 6 || nobj <= 0)
-        return YOLO_EINVAL;
-    LossCfg cfg{scales5[0], scales5[1], scales5[2], scales5[3], scales5[4], pos_w, neg_w};
+static int loss_launch(const float* logits, const float* records, float* dlogits, float* losses, int B, int nbox, int C,
+                       int nobj, const float* scales5, float pos_w, float neg_w, int nh, int g1, int g2, void* stream) {
+    if (!logits || !records || !dlogits || !losses || !scales5 || B <= 0 || nbox <= 0 || nobj <= 0) return YOLO_EINVAL;
+    if (nh < 2 || g1 < 1 || g2 < 1 || g1 + g2 > nh || C < 1 + nh) return YOLO_EINVAL;
+    LossCfg cfg{scales5[0], scales5[1], scales5[2], scales5[3], scales5[4], pos_w, neg_w, nh, g1, g2};
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
     (void)hipMemsetAsync(losses, 0, sizeof(float) * 5 * B, st);
@@ -210,4 +219,55 @@ extern "C" int yolo_loss_fwd_bwd(const float* logits, const float* records, floa
                 nobj, cfg);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
+}
+
+extern "C" int yolo_loss_fwd_bwd(const float* logits, const float* records, float* dlogits, float* losses, int B,
+                                 int nbox, int C, int nobj, const float* scales5, float pos_w, float neg_w,
+                                 void* stream) {
+    if (C < 6) return YOLO_EINVAL;
+    return loss_launch(logits, records, dlogits, losses, B, nbox, C, nobj, scales5, pos_w, neg_w, 5, 2, 2, stream);
+}
+
+// ---- CarLPNet: licence-plate targets and losses (LP_detection.py:258-360) -----------------------------------------
+// record per (image, object): [valid, cell index h_f*w_+w_f, tX, tY, tZ, tr1, tr2, tr3, one-hot class (ncls)]
+__global__ void assign_lp_kernel(const float* __restrict__ labels, float* __restrict__ rec, int total, int lab_w, int ncls,
+                                 int fh, int fw, float step, float rm0, float rm1, float rm2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float* L = labels + (long long)i * lab_w;
+    float* R = rec + (long long)i * (8 + ncls);
+    if (L[0] < 0.f) { R[0] = 0.f; return; }
+    int hf = (int)(L[8] / step), wf = (int)(L[7] / step);          // int(): truncation, as the reference
+    hf = min(max(hf, 0), fh - 1);
+    wf = min(max(wf, 0), fw - 1);
+    R[0] = 1.f;
+    R[1] = (float)(hf * fw + wf);
+    R[2] = L[1] / 1000.f; R[3] = L[2] / 1000.f; R[4] = L[3] / 1000.f;
+    const float rm[3] = {rm0, rm1, rm2};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const float sg = L[4 + q] / rm[q] / 2.f + 0.5f;
+        R[5 + q] = -logf(1.f / sg - 1.f);                            // nd_inv_sigmoid, yolo_gluon.py:365
+    }
+    const int cls = (int)L[lab_w - 1];
+    for (int c = 0; c < ncls; ++c) R[8 + c] = c == cls ? 1.f : 0.f;
+}
+
+extern "C" int yolo_assign_targets_lp(const float* labels, float* records, int B, int nobj, int lab_w, int ncls, int img_h,
+                                      int img_w, int step, float r_max0_deg, float r_max1_deg, float r_max2_deg,
+                                      void* stream) {
+    if (!labels || !records || B <= 0 || nobj <= 0 || lab_w < 10 || ncls < 1 || step <= 0) return YOLO_EINVAL;
+    const int total = B * nobj;
+    const float k = 3.14159265358979323846f / 180.f;
+    YOLO_LAUNCH(assign_lp_kernel, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, labels, records, total, lab_w,
+                ncls, img_h / step, img_w / step, (float)step, r_max0_deg * k, r_max1_deg * k, r_max2_deg * k);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}
+
+extern "C" int yolo_loss_lp_fwd_bwd(const float* logits, const float* records, float* dlogits, float* losses, int B,
+                                    int ncell, int C, int nobj, const float* scales5, float pos_w, float neg_w,
+                                    void* stream) {
+    if (C < 8) return YOLO_EINVAL;
+    return loss_launch(logits, records, dlogits, losses, B, ncell, C, nobj, scales5, pos_w, neg_w, 6, 2, 1, stream);
 }

@@ -71,6 +71,8 @@ SIGNATURES = {
     'yolo_add': (_i, [_vp, _vp, _vp, _ll, _i, _vp]),
     'yolo_assign_targets': (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(GridDesc), _vp]),
     'yolo_loss_fwd_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(C.c_float), _f, _f, _vp]),
+    'yolo_assign_targets_lp': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
+    'yolo_loss_lp_fwd_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(C.c_float), _f, _f, _vp]),
     'yolo_adam_step': (_i, [_vp, _vp, _vp, _vp, _ll, _i, _f, _f, _f, _f, _f, _vp]),
 }
 

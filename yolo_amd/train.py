@@ -18,6 +18,7 @@ from .detect import make_grid, default_ltrb
 from .spec import BN_EPS, BN_MOMENTUM, LEAKY_SLOPE
 
 DEFAULT_SCALE = {'score': 0.1, 'box_yx': 0.01, 'box_hw': 10.0, 'rotate': 0.0, 'class': 0.3}   # car/v1/spec.yaml:31-35
+LP_DEFAULT_SCALE = {'LP_score': 0.1, 'LP_xy': 10.0, 'LP_z': 1.0, 'LP_r': 0.1, 'LP_class': 0.0}   # car_and_LP/v1/spec.yaml
 
 
 class _T(object):
@@ -30,7 +31,8 @@ class _T(object):
 
 class Trainer(object):
     def __init__(self, net, size, scale=None, learning_rate=1e-3, positive_weight=1.0, negative_weight=0.1,
-                 car_rotate=False, beta1=0.9, beta2=0.999, eps=1e-8):
+                 car_rotate=False, beta1=0.9, beta2=0.999, eps=1e-8, lp_scale=None, lp_r_max=(45, 60, 45),
+                 lp_positive_weight=1.0, lp_negative_weight=0.1):
         # dtype of activations and activation gradients: 'f32' (parity path) or 'bf16' (MFMA bf16 convolutions,
         # transposing-read weight gradient); master weights, weight gradients, BN statistics and Adam are fp32.
         self.net, self.size = net, (int(size[0]), int(size[1]))
@@ -40,11 +42,12 @@ class Trainer(object):
         self.scale = dict(DEFAULT_SCALE if scale is None else scale)
         self.lr, self.b1, self.b2, self.eps = learning_rate, beta1, beta2, eps
         self.pos_w, self.neg_w, self.car_rotate = positive_weight, negative_weight, car_rotate
+        # CarLPNet (car_and_LP/v1/spec.yaml): scales of the five LP losses, LP_r_max, LP score weights
+        self.lp_scale = dict(LP_DEFAULT_SCALE if lp_scale is None else lp_scale)
+        self.lp_r_max = tuple(float(v) for v in lp_r_max)
+        self.lp_pos_w, self.lp_neg_w = lp_positive_weight, lp_negative_weight
         self.t = 0
         g = net.graph
-        if getattr(g, 'lp_out', None) is not None:
-            raise NotImplementedError('the LP-branch losses (car_and_LP/YOLO.py) are not built: train the car heads '
-                                      'with a spec without LP_slice_point')
         self.grid, self.nbox = make_grid(g.anchors, self.size, g.steps())
         self.anchors_ltrb = torch.from_numpy(default_ltrb(g.anchors, self.size, g.steps())).to(self.dev).contiguous()
         # ---- flat parameter / gradient / Adam-state buffers; net.params become views of wflat ------------
@@ -154,7 +157,26 @@ class Trainer(object):
         P.merged = torch.empty((B, tot, AC), dtype=torch.float32, device=self.dev)
         P.dmerged = torch.empty_like(P.merged)
         P.tot, P.AC, P.A = tot, AC, A
+        P.lp = P.dlp = None
         for i, (body, tip, outc, nA) in enumerate(g.heads):
+            if g.lp_out is not None and i >= len(g.heads) - 1:
+                # CarLPNet's LP branch (car_and_LP/YOLO.py:72-79): reads the input of the finest detection block
+                t = x
+                for lbody, ltip in g.lp_blocks:
+                    for c in lbody + [ltip]:
+                        t = conv_bn(c, t)
+                lc = g.lp_out
+                hw_lp = t.shape[1] * t.shape[2]
+                P.lp = torch.empty((B, hw_lp, lc.cout), dtype=torch.float32, device=self.dev)
+                P.dlp = torch.empty_like(P.lp)
+                wp, wd, ones, bias, zeros = self._prep[lc.name]
+                d = self._conv_desc(t.val, t.shape, wp, ones, bias, P.lp.data_ptr(), lc.cin, lc.cout, 1, 1, out_f32=1)
+                self._tune(d)
+                cpad = (lc.cout + 7) // 8 * 8
+                P.fwd.append(dict(kind='out', c=lc, x=t, desc=d, hw=hw_lp, cpad=cpad,
+                                  src=(P.dlp.data_ptr(), hw_lp * lc.cout, lc.cout),
+                                  dyp=torch.empty((B * hw_lp, cpad), dtype=self.tdt, device=self.dev)))
+                P.lp_hw = (t.shape[1], t.shape[2])
             for c in body:
                 x = conv_bn(c, x)
             route = x
@@ -165,7 +187,8 @@ class Trainer(object):
             d = self._conv_desc(t.val, t.shape, wp, ones, bias, yptr, outc.cin, outc.cout, 1, 1, out_f32=1, y_bs=tot * AC, y_ps=AC)
             self._tune(d)
             cpad = (outc.cout + 7) // 8 * 8
-            P.fwd.append(dict(kind='out', c=outc, x=t, desc=d, off=offs[k], hw=hw[k], cpad=cpad,
+            P.fwd.append(dict(kind='out', c=outc, x=t, desc=d, hw=hw[k], cpad=cpad,
+                              src=(P.dmerged.data_ptr() + offs[k] * AC * 4, tot * AC, AC),
                               dyp=torch.empty((B * hw[k], cpad), dtype=self.tdt, device=self.dev)))
             if i >= len(g.heads) - 1:
                 break
@@ -253,8 +276,8 @@ class Trainer(object):
             if kind == 'out':
                 c, xin = op['c'], op['x']
                 hw, cpad = op['hw'], op['cpad']
-                src = P.dmerged.data_ptr() + op['off'] * P.AC * 4
-                L.check(lib.yolo_gather_rows(src, L.ptr(op['dyp']), B, hw, c.cout, cpad, P.tot * P.AC, P.AC, self.ldt, st), 'gather')
+                src, src_bs, src_ps = op['src']            # this output's slice of d(loss)/d(logits), fp32
+                L.check(lib.yolo_gather_rows(src, L.ptr(op['dyp']), B, hw, c.cout, cpad, src_bs, src_ps, self.ldt, st), 'gather')
                 L.check(lib.yolo_bias_grad(L.ptr(op['dyp']), L.ptr(self.gview[c.name + '.bias']), B * hw, c.cout, cpad, self.ldt, st), 'db')
                 N, Hh, Ww, Cx = xin.shape
                 L.check(lib.yolo_conv_wgrad(L.ptr(op['dyp']), L.ptr(xin.val), L.ptr(self.gview[c.name + '.weight']),
@@ -296,7 +319,7 @@ class Trainer(object):
                 self.buckets.done([c.name + '.weight', c.name + '.gamma', c.name + '.beta'])
 
     # ---- one training step -----------------------------------------------------------------------------------
-    def train_step(self, images, labels, global_batch=None, update=True):
+    def train_step(self, images, labels, global_batch=None, update=True, lp_labels=None):
         """images (B,3,H,W) float32 CUDA; labels (B,nobj,6+ncls) float32 CUDA [cls,y,x,h,w,rot,dist...],
         cls < 0 = no object.  Returns losses (5,B) [score, box_yx, box_hw, rotate, class] (device)."""
         lib, st = self.lib, L.stream_ptr()
@@ -319,6 +342,26 @@ class Trainer(object):
         L.check(lib.yolo_loss_fwd_bwd(L.ptr(P.merged), L.ptr(rec), L.ptr(P.dmerged), L.ptr(losses), B, self.nbox, C_, nobj,
                                       s5, self.pos_w, self.neg_w, st), 'loss')
         self._last = (P, rec)
+        if self.net.graph.lp_out is not None:
+            # the five LP losses of CarLPNet's _train_batch (car_and_LP/YOLO.py:262-300, LP_detection.py:258-360)
+            if lp_labels is None:
+                raise ValueError('a CarLPNet step needs lp_labels (B, nobj, 10): rows of -1 = no plate')
+            g = self.net.graph
+            lp_labels = lp_labels.to(self.dev, torch.float32).contiguous()
+            nlp, lw = lp_labels.shape[1], lp_labels.shape[2]
+            LPC = g.lp_out.cout
+            ncl = LPC - 7
+            lrec = torch.empty((B, nlp, 8 + ncl), dtype=torch.float32, device=self.dev)
+            step = g.steps()[0]
+            L.check(lib.yolo_assign_targets_lp(L.ptr(lp_labels), L.ptr(lrec), B, nlp, lw, ncl, H, W, step,
+                                               self.lp_r_max[0], self.lp_r_max[1], self.lp_r_max[2], st), 'assign lp')
+            lp_losses = torch.empty((5, B), dtype=torch.float32, device=self.dev)
+            ls = self.lp_scale
+            l5 = (C.c_float * 5)(ls['LP_score'], ls['LP_xy'], ls['LP_z'], ls['LP_r'], ls['LP_class'])
+            L.check(lib.yolo_loss_lp_fwd_bwd(L.ptr(P.lp), L.ptr(lrec), L.ptr(P.dlp), L.ptr(lp_losses), B, P.lp.shape[1],
+                                             LPC, nlp, l5, self.lp_pos_w, self.lp_neg_w, st), 'lp loss')
+            losses = torch.cat([losses, lp_losses], dim=0)
+            self._last = (P, rec, lrec)
         self._backward(P, exchange=update)
         if update:
             self.buckets.wait()                                    # KVStore sum-reduce of trainer.step (RCCL), bucketed
