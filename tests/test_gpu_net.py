@@ -227,3 +227,12 @@ def test_carlpnet_reference_spec_shapes(cuda):
     assert [tuple(o.shape) for o in outs] == [(2, 20 * 32, 3, 80), (2, 10 * 16, 3, 80), (2, 5 * 8, 3, 80)]
     assert tuple(lp[0].shape) == (2, 20, 32, 10)
     assert all(bool(torch.isfinite(t).all()) for t in outs + lp)
+
+
+def test_rejects_sizes_the_pyramid_cannot_merge(cuda):
+    from yolo_amd.net import CarNet
+    net = CarNet(og.spec_micro(), dtype='bf16', device=cuda).initialize(1)
+    with pytest.raises(ValueError):
+        net(torch.rand((1, 3, 72, 96), device=cuda))             # 72 is not a multiple of 32
+    with pytest.raises(ValueError):
+        net(torch.rand((1, 3, 64, 96), device=cuda).double())

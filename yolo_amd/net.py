@@ -267,6 +267,10 @@ class CarNet(object):
             raise ValueError('expected a (B,3,H,W) float32 CUDA tensor')
         x = x.contiguous()
         B, _, H, W = x.shape
+        down = 2 ** len(self.graph.stages)
+        if H % down or W % down:
+            # (the reference fails in F.concat for such sizes: the up-sampled map no longer matches its route)
+            raise ValueError('image size %dx%d is not a multiple of the total stride %d' % (H, W, down))
         key = (B, H, W)
         plan = self._plans.get(key)
         if plan is None:
