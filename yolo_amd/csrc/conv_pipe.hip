@@ -101,7 +101,16 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     // 3x3: the X DMAs of the next chunk are spread over the phases of this chunk (phase q issues
     // j = q, q+PPC, ...)
 
-    constexpr int PIPE_BYTES = XBUFS * X_STAGE + 3 * W_STAGE;
+    // 3x3 weight ring: 4 slots (loads run 3 phases ahead: K loop -4..-9 % cycles vs 3 slots, measured with the phase
+    // stamps; 5 slots are slower again) wherever the extra slot does not cost a co-resident block per CU
+#ifndef YOLO_WRING
+#define YOLO_WRING 4
+#endif
+    constexpr int EPI_BYTES_ = WAVES_P * WAVES_C * YOLO_EPI_WAVE_BYTES;
+    constexpr int LDS3 = XBUFS * X_STAGE + 3 * W_STAGE > EPI_BYTES_ ? XBUFS * X_STAGE + 3 * W_STAGE : EPI_BYTES_;
+    constexpr int LDSN = XBUFS * X_STAGE + YOLO_WRING * W_STAGE > EPI_BYTES_ ? XBUFS * X_STAGE + YOLO_WRING * W_STAGE : EPI_BYTES_;
+    constexpr int WR = (KS == 3 && LDSN <= 163840 && 163840 / LDSN == 163840 / LDS3) ? YOLO_WRING : 3;
+    constexpr int PIPE_BYTES = XBUFS * X_STAGE + WR * W_STAGE;
     constexpr int EPI_BYTES = NW * YOLO_EPI_WAVE_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)smem;
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     auto issue_w1 = [&](int gp, int j) {
         const int g = min(gp, nphase - 1);
         glds16(wsrc + (long long)g * wplane + (long long)j * NT * 16,
-               wave_lds + W_OFF + (gp % 3) * W_STAGE + j * NT * 16);
+               wave_lds + W_OFF + (gp % WR) * W_STAGE + j * NT * 16);
     };
     auto issue_w = [&](int gp) {
 #pragma unroll
@@ -194,7 +203,8 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     if constexpr (KS == 3) {
 #pragma unroll
         for (int j = 0; j < XL; ++j) issue_x(j, 0, 0);
-        issue_w(1);
+#pragma unroll
+        for (int g = 1; g < WR - 1; ++g) issue_w(g);
     } else {
 #pragma unroll
         for (int j = 0; j < XL; ++j) issue_x(j, 0, 0);
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    if constexpr (KS == 3) wait_vmcnt<WL>();
+    if constexpr (KS == 3) wait_vmcnt<(WR - 2) * WL>();
     else wait_vmcnt<WL + XL>();
     __builtin_amdgcn_s_barrier();
     STAMP(1);
@@ -244,11 +254,11 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
                 if constexpr (KS == 3) issue_x(q, c + 1, (c + 1) & 1);
                 else issue_x(k, gp + 2, (gp + 2) % 3);
             } else {
-                issue_w1(gp + 2, k - nx);
+                issue_w1(gp + WR - 1, k - nx);
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-        const char* Wl = smem + W_OFF + (gp % 3) * W_STAGE;
+        const char* Wl = smem + W_OFF + (gp % WR) * W_STAGE;
         const char* Xl = smem + ((KS == 3) ? (c & 1) : (gp % 3)) * X_STAGE;
         int bx[NI];
 #pragma unroll
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         }
         // phase gp+1's data must have landed: everything except what this phase issued for gp+2 (the
         // input DMAs are issued before the weight DMAs, so leaving WL outstanding covers them too)
-        if constexpr (KS == 3) wait_vmcnt<WL>();
+        if constexpr (KS == 3) wait_vmcnt<(WR - 2) * WL>();
         else wait_vmcnt<WL + XL>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);      // keep the next phase's address math out of this phase (VGPR pressure)
