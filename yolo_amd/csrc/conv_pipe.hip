@@ -95,7 +95,15 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     constexpr int X_STAGE = XSLOTS * 64;
     constexpr int XL = X_STAGE / (NT * 16);              // LDS-DMAs per thread per X tile
     static_assert(X_STAGE % (NT * 16) == 0, "input stage must be whole DMAs");
-    constexpr int XBUFS = (KS == 3) ? 2 : 3;
+    // 1x1: depth of the X and W rings (loads run R1-1 phases ahead): 4 where that keeps the blocks per CU, else 3
+#ifndef YOLO_RING1
+#define YOLO_RING1 4
+#endif
+    constexpr int EPI1_ = WAVES_P * WAVES_C * YOLO_EPI_WAVE_BYTES;
+    constexpr int L13_ = 3 * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) > EPI1_ ? 3 * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) : EPI1_;
+    constexpr int L1N_ = YOLO_RING1 * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) > EPI1_ ? YOLO_RING1 * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) : EPI1_;
+    constexpr int R1 = (L1N_ <= 163840 && 163840 / L1N_ == 163840 / L13_) ? YOLO_RING1 : 3;
+    constexpr int XBUFS = (KS == 3) ? 2 : R1;
     static_assert(KS == 3 || XSLOTS == BP, "1x1: one slot per pixel");
     constexpr int W_OFF = XBUFS * X_STAGE;
     // 3x3: the X DMAs of the next chunk are spread over the phases of this chunk (phase q issues
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     constexpr int EPI_BYTES_ = WAVES_P * WAVES_C * YOLO_EPI_WAVE_BYTES;
     constexpr int LDS3 = XBUFS * X_STAGE + 3 * W_STAGE > EPI_BYTES_ ? XBUFS * X_STAGE + 3 * W_STAGE : EPI_BYTES_;
     constexpr int LDSN = XBUFS * X_STAGE + YOLO_WRING * W_STAGE > EPI_BYTES_ ? XBUFS * X_STAGE + YOLO_WRING * W_STAGE : EPI_BYTES_;
-    constexpr int WR = (KS == 3 && LDSN <= 163840 && 163840 / LDSN == 163840 / LDS3) ? YOLO_WRING : 3;
+    constexpr int WR = (KS == 3) ? ((LDSN <= 163840 && 163840 / LDSN == 163840 / LDS3) ? YOLO_WRING : 3) : R1;
     constexpr int PIPE_BYTES = XBUFS * X_STAGE + WR * W_STAGE;
     constexpr int EPI_BYTES = NW * YOLO_EPI_WAVE_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES];
@@ -209,8 +217,11 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
 #pragma unroll
         for (int j = 0; j < XL; ++j) issue_x(j, 0, 0);
 #pragma unroll
-        for (int j = 0; j < XL; ++j) issue_x(j, 1, 1);
-        issue_w(1);
+        for (int g = 1; g < R1 - 1; ++g) {
+#pragma unroll
+            for (int j = 0; j < XL; ++j) issue_x(j, g, g);
+            issue_w(g);
+        }
     }
     // ---- per-lane MFMA operand bases ------------------------------------------------------------
     int slot00[NI];
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     if constexpr (KS == 3) wait_vmcnt<(WR - 2) * WL>();
-    else wait_vmcnt<WL + XL>();
+    else wait_vmcnt<(R1 - 2) * (WL + XL)>();
     __builtin_amdgcn_s_barrier();
     STAMP(1);
 
@@ -252,14 +263,14 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
             __builtin_amdgcn_sched_barrier(0);
             if (k < nx) {
                 if constexpr (KS == 3) issue_x(q, c + 1, (c + 1) & 1);
-                else issue_x(k, gp + 2, (gp + 2) % 3);
+                else issue_x(k, gp + R1 - 1, (gp + R1 - 1) % R1);
             } else {
                 issue_w1(gp + WR - 1, k - nx);
             }
             __builtin_amdgcn_sched_barrier(0);
         };
         const char* Wl = smem + W_OFF + (gp % WR) * W_STAGE;
-        const char* Xl = smem + ((KS == 3) ? (c & 1) : (gp % 3)) * X_STAGE;
+        const char* Xl = smem + ((KS == 3) ? (c & 1) : (gp % R1)) * X_STAGE;
         int bx[NI];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         // phase gp+1's data must have landed: everything except what this phase issued for gp+2 (the
         // input DMAs are issued before the weight DMAs, so leaving WL outstanding covers them too)
         if constexpr (KS == 3) wait_vmcnt<(WR - 2) * WL>();
-        else wait_vmcnt<WL + XL>();
+        else wait_vmcnt<(R1 - 2) * (WL + XL)>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);      // keep the next phase's address math out of this phase (VGPR pressure)
     };
