@@ -30,6 +30,40 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
     const int l31 = lane & 31, h = lane >> 5;
     const float slope = a.slope;
 
+    if (a.out_f32 && a.res == nullptr && (a.Cout % 2) == 0 && (a.y_ps % 2) == 0 && (a.y_bs % 2) == 0 &&
+        ((size_t)a.y % 8) == 0) {
+        // ---- fp32 head logits (YOLOOutput, Cout = A*C = 90: rows of 360 bytes, 8-byte aligned) ---------------
+        // same LDS transpose, then 8-byte stores: a wave writes 2 pixel rows x (WN couts x 4 B) contiguous bytes per
+        // pass instead of 4-byte stores scattered over 32 rows (the per-element path below)
+        constexpr int LPR2 = WN / 2, RPP2 = 64 / LPR2, NPASS2 = 32 / RPP2;
+        const int col2 = lane % LPR2, rowa = lane / LPR2;
+        const int co2 = co_w + col2 * 2;
+        const bool ok2 = co2 < a.Cout;
+        const float sc0 = a.scale[co2], sc1 = a.scale[co2 + 1], bi0 = a.bias[co2], bi1 = a.bias[co2 + 1];
+        long long* ytab2 = (long long*)(wsm + 32 * RS);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            if (h == 0) ytab2[l31] = yoff[ni];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+                    *(f32x4*)(wsm + l31 * RS + (mi * 32 + 8 * g + 4 * h) * 4) = v;
+                }
+#pragma unroll
+            for (int k = 0; k < NPASS2; ++k) {
+                const int row = rowa + k * RPP2;
+                const long long yo2 = ok2 ? ytab2[row] : -1;
+                const float2 t2 = *(const float2*)(wsm + row * RS + col2 * 8);
+                float2 o2;
+                o2.x = leaky(t2.x * sc0 + bi0, slope);
+                o2.y = leaky(t2.y * sc1 + bi1, slope);
+                if (yo2 >= 0) *(float2*)(a.y + (yo2 + co2) * 4) = o2;
+            }
+        }
+        return;
+    }
     if (a.out_f32 || (a.Cout % CPL) != 0 || ((a.y_ps * ES) % 16) != 0 || ((a.y_bs * ES) % 16) != 0) {
         // ---- generic path: arbitrary Cout / strides / fp32 logits (small head-output layers) -----
 #pragma unroll
