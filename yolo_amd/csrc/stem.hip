@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
                                                         int N, int H, int W, int Cout, float slope, int tiles_x,
                                                         int tiles_y) {
     __shared__ __attribute__((aligned(16))) uint2 tile[(STEM_TH + 2) * STEM_PW];
-    __shared__ __attribute__((aligned(16))) uint2 obuf[4 * 64 * (MI * 32 * 2 + 8) / 8];
+    __shared__ __attribute__((aligned(16))) uint2 obuf[4 * 64 * (MI * 32 * 2 + 16) / 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     int b = blockIdx.x;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     }
     __syncthreads();
 
-    constexpr int OP = (MI * 32 * 2 + 8);              // LDS pitch per output pixel: bf16 couts + 8 B (conflict-free b64)
+    constexpr int OP = (MI * 32 * 2 + 16);             // LDS pitch per output pixel: bf16 couts + 16 B pad (16-byte aligned rows)
     char* ot = (char*)obuf + wave * (64 * OP);
     const int upp = Cout / 4;                          // 8-byte units per output pixel
     const int npx = min(STEM_TW, W - x0);
@@ -127,9 +127,19 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
             }
         }
         uint16_t* yrow = y + (((long long)n * H + oy) * W + x0) * Cout;
-        for (int u = lane; u < npx * upp; u += 64) {   // same-wave LDS write -> read -> (next row's) write: in order
-            const int px = u / upp, q = u - px * upp;
-            *(uint2*)(yrow + (long long)px * Cout + q * 4) = *(const uint2*)(ot + px * OP + q * 8);
+        // same-wave LDS write -> read -> (next row's) write: in order.  16-byte stores where the row allows it
+        // (half the store instructions of the 8-byte version: the kernel is store-issue bound)
+        if ((Cout & 7) == 0) {
+            const int upp16 = Cout / 8;
+            for (int u = lane; u < npx * upp16; u += 64) {
+                const int px = u / upp16, q = u - px * upp16;
+                *(uint4*)(yrow + (long long)px * Cout + q * 8) = *(const uint4*)(ot + px * OP + q * 16);
+            }
+        } else {
+            for (int u = lane; u < npx * upp; u += 64) {
+                const int px = u / upp, q = u - px * upp;
+                *(uint2*)(yrow + (long long)px * Cout + q * 4) = *(const uint2*)(ot + px * OP + q * 8);
+            }
         }
     }
 }
