@@ -114,12 +114,14 @@ S2_CASES = [
 ]
 
 
-@pytest.mark.parametrize('algo', [9, 10])
+@pytest.mark.parametrize('algo', [9, 10, 16, 17, 18])
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('case', S2_CASES)
 def test_conv_pipe_stride2(lib, cuda, case, dtype, algo):
     x, w, scale, bias, r = _mk(case, 6)
-    y = run_conv(lib, cuda, x, w, scale, bias, 2, 0.1, dtype, algo=algo)
+    y = run_conv(lib, cuda, x, w, scale, bias, 2, 0.1, dtype, algo=algo, expect_rc=None if algo >= 16 else 0)
+    if y is None:
+        pytest.skip('halo tile of this shape does not fit the smaller buffer of this variant')
     ref = ref_conv(x, w, scale, bias, 2, 0.1, bf16=(dtype == 'bf16'))
     assert not np.isnan(y).any()
     if dtype == 'f32':

@@ -303,7 +303,7 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
 // between the variants' inner loops.  The per-variant factors are measured (tools/conv_bench.py).
 static int conv_auto_algo(const ConvArgs& a, int ks, int stride, int dtype) {
     if ((a.Cin * elem_size(dtype)) % 64 || (ks == 1 && a.nchunks < 2)) return 1;
-    if (stride == 2) return ks == 3 ? (a.Cout > 128 ? 10 : 9) : 1;
+    if (stride == 2) return ks == 3 ? (a.Cout > 128 ? 18 : 9) : 1;      // (18 = 10 with the 4-slot weight ring)
     struct V { int algo, bp, bc, bpc; float f; bool k1; };
     static const V vs[] = {{2, 256, 256, 1, 1.00f, true}, {3, 256, 128, 1, 1.10f, true}, {4, 128, 128, 2, 1.05f, true},
                            {6, 192, 256, 1, 1.00f, false}, {8, 192, 128, 2, 1.05f, true}};
@@ -373,7 +373,11 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
         const int pick = conv_auto_algo(a, d->ksize, d->stride, d->dtype);
         if (pick >= 2) {
             ConvArgs b = a;
-            const int rc = conv_pipe_dispatch(b, d->ksize, d->stride, d->dtype, pick, st, nm);
+            int rc = conv_pipe_dispatch(b, d->ksize, d->stride, d->dtype, pick, st, nm);
+            if (rc == YOLO_EUNSUPPORTED && pick == 18) {
+                b = a;
+                rc = conv_pipe_dispatch(b, d->ksize, d->stride, d->dtype, 10, st, nm);
+            }
             if (rc != YOLO_EUNSUPPORTED) return rc;
         }
     }

@@ -384,7 +384,8 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
 //   4: 4 waves, 128 px x 128 cout (wave tile 64x64)    5: 8 waves, 128 px x 256 cout (wave tile 128x32)
 //   6: 8 waves, 192 px x 256 cout (wave tile 96x64)    7: 8 waves, 192 px x 128 cout (wave tile 96x32)
 //   8: 4 waves, 192 px x 128 cout (wave tile 96x64)    -- 192-pixel tiles exist to cut tile quantisation
-//   9 / 10: 3x3 stride 2, 8 waves, 128 px x 128 / 256 cout
+//   9 / 10: 3x3 stride 2, 8 waves, 128 px x 128 / 256 cout; 17 / 16: the same with a smaller halo buffer and a
+//           4-slot weight ring
 //   11: 4 waves, 64 px x 128 cout; 12 (1x1 only): 4 waves, 64 px x 256 cout -- small-M layers (13x13 maps at
 //       batch 32 have 5408 pixels: more, smaller tiles fill the chip)
 template <typename T>
@@ -394,6 +395,11 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
         switch (algo) {
             case 9: return launch_pipe<T, 3, 2, 4, 1, 2, 896, 2>(a, st, nm);     // 8 waves, 128 px x 128 cout
             case 10: return launch_pipe<T, 3, 2, 4, 2, 2, 896, 2>(a, st, nm);    // 8 waves, 128 px x 256 cout
+            // same tiles with a 640-slot halo buffer (enough for every strip shape of the 416/608 families): leaves room
+            // for the 4th weight-ring slot
+            case 16: return launch_pipe<T, 3, 2, 4, 2, 2, 640, 2>(a, st, nm);
+            case 17: return launch_pipe<T, 3, 2, 4, 1, 2, 640, 2>(a, st, nm);
+            case 18: return launch_pipe<T, 3, 2, 4, 2, 2, 768, 2>(a, st, nm);    // (768 slots: tiles that cross image boundaries)
         }
         return YOLO_EUNSUPPORTED;
     }
