@@ -175,6 +175,16 @@ int yolo_nms(const float* rows, int B, int nbox, int C, int mode, float valid_th
 int yolo_pack_conv_weights_dgrad(const float* w_oihw, void* packed, int Cout_f, int Cin_f, int ksize,
                                  int dtype, void* stream);
 
+/* Every conv of a network packed in ONE launch (the training step re-packs all images after each update).
+ * items_device: device array of n_items records { const float* w_oihw; void* packed; int Cout, Cin, ksize, dgrad; }
+ * (32 bytes each; dgrad = 1: the data-gradient image of the FORWARD conv (Cin, Cout swapped as in
+ * yolo_pack_conv_weights_dgrad's arguments)); first_block_device: n_items + 1 prefix sums of
+ * yolo_pack_batch_blocks(Cout, Cin, ksize, dtype) over the items; total_blocks = the last prefix. */
+typedef struct yolo_pack_item { const float* w_oihw; void* packed; int Cout, Cin, ksize, dgrad; } yolo_pack_item;
+long long yolo_pack_batch_blocks(int Cout, int Cin, int ksize, int dtype);
+int yolo_pack_conv_weights_batch(const void* items_device, const long long* first_block_device, int n_items,
+                                 long long total_blocks, int dtype, void* stream);
+
 /* Gluon BatchNorm in training mode fused with LeakyReLU (+ residual add):
  * batch mean / biased variance over (N,H,W) of the NHWC conv output y (npix x C, dtype; C % 8 == 0),
  * z = lrelu(gamma*(y-mean)*invstd + beta) [+ residual]; running stats r = momentum*r + (1-momentum)*batch

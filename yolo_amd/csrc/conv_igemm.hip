@@ -388,38 +388,97 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
 // ------------------------------------------------------------------------------------------
 // Weight packing: OIHW f32 -> [chunk][tap][Cout_pad][64 B], 16-byte units XOR-swizzled
 // ------------------------------------------------------------------------------------------
+extern "C" long long yolo_packed_weight_bytes(int Cout, int Cin, int ksize, int dtype);
+
+// one element of the packed image: idx over [chunk][tap][Cout_pad][64 B / sizeof(T)]
+template <typename T>
+__device__ __forceinline__ void pack_one(const float* __restrict__ w, T* __restrict__ out, long long idx, int Cout, int Cin,
+                                         int ks, int Cout_pad, int dgrad) {
+    constexpr int CH = 64 / sizeof(T);       // channels per chunk
+    constexpr int UE = 16 / sizeof(T);       // elements per 16-byte unit
+    const int e = (int)(idx % CH);
+    long long r = idx / CH;
+    const int co = (int)(r % Cout_pad);
+    r /= Cout_pad;
+    const int tap = (int)(r % (ks * ks));
+    const int chunk = (int)(r / (ks * ks));
+    const int punit = e / UE, within = e % UE;
+    const int lunit = punit ^ ((co >> 2) & 3);            // physical unit holds this logical unit
+    const int ci = chunk * CH + lunit * UE + within;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) {
+        if (!dgrad) {
+            v = w[((long long)(co * Cin + ci) * ks + tap / ks) * ks + tap % ks];
+        } else {
+            // data-gradient image: rows = forward INPUT channels, K = forward OUTPUT channels, taps flipped
+            // (w is the forward OIHW tensor with O = Cin here, I = Cout here)
+            v = w[((long long)(ci * Cout + co) * ks + (ks - 1 - tap / ks)) * ks + (ks - 1 - tap % ks)];
+        }
+    }
+    if constexpr (sizeof(T) == 2)
+        ((uint16_t*)out)[idx] = (uint16_t)f32_to_bf16_bits(v);
+    else
+        out[idx] = v;
+}
+
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin,
                                     int ks, int Cout_pad, int nchunks, int dgrad) {
-    constexpr int CH = 64 / sizeof(T);       // channels per chunk
-    constexpr int UE = 16 / sizeof(T);       // elements per 16-byte unit
+    constexpr int CH = 64 / sizeof(T);
     const long long total = (long long)nchunks * ks * ks * Cout_pad * CH;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int e = (int)(idx % CH);
-        long long r = idx / CH;
-        const int co = (int)(r % Cout_pad);
-        r /= Cout_pad;
-        const int tap = (int)(r % (ks * ks));
-        const int chunk = (int)(r / (ks * ks));
-        const int punit = e / UE, within = e % UE;
-        const int lunit = punit ^ ((co >> 2) & 3);            // physical unit holds this logical unit
-        const int ci = chunk * CH + lunit * UE + within;
-        float v = 0.f;
-        if (co < Cout && ci < Cin) {
-            if (!dgrad) {
-                v = w[((long long)(co * Cin + ci) * ks + tap / ks) * ks + tap % ks];
-            } else {
-                // data-gradient image: rows = forward INPUT channels, K = forward OUTPUT channels, taps flipped
-                // (w is the forward OIHW tensor with O = Cin here, I = Cout here)
-                v = w[((long long)(ci * Cout + co) * ks + (ks - 1 - tap / ks)) * ks + (ks - 1 - tap % ks)];
-            }
-        }
-        if constexpr (sizeof(T) == 2)
-            ((uint16_t*)out)[idx] = (uint16_t)f32_to_bf16_bits(v);
-        else
-            out[idx] = v;
+         idx += (long long)gridDim.x * blockDim.x)
+        pack_one<T>(w, out, idx, Cout, Cin, ks, Cout_pad, dgrad);
+}
+
+// every conv of a network in ONE launch (the training step re-packs ~150 images after each optimiser update: as
+// separate launches that was 1.3 ms of mostly launch overhead).  Block b belongs to the item i with
+// first_block[i] <= b < first_block[i+1] and packs elements [4096*(b - first_block[i]), +4096) of it.
+struct PackItem { const float* w; void* packed; int Cout, Cin, ksize, dgrad; };
+static_assert(sizeof(PackItem) == 32, "yolo_pack_item layout");
+constexpr int PACK_BLOCK_ELEMS = 4096;
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackItem* __restrict__ items,
+                                                                 const long long* __restrict__ first_block, int n) {
+    constexpr int CH = 64 / sizeof(T);
+    int lo = 0, hi = n;                                   // first_block[lo] <= blockIdx.x < first_block[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (first_block[mid] <= (long long)blockIdx.x) lo = mid; else hi = mid;
     }
+    const PackItem it = items[lo];
+    const int Cout_pad = round_up(it.Cout, YOLO_COUT_PAD);
+    const int nchunks = (it.Cin * (int)sizeof(T) + 63) / 64;
+    const long long total = (long long)nchunks * it.ksize * it.ksize * Cout_pad * CH;
+    const long long base = ((long long)blockIdx.x - first_block[lo]) * PACK_BLOCK_ELEMS;
+#pragma unroll 4
+    for (int k = 0; k < PACK_BLOCK_ELEMS / 256; ++k) {
+        const long long idx = base + k * 256 + threadIdx.x;
+        if (idx < total) pack_one<T>(it.w, (T*)it.packed, idx, it.Cout, it.Cin, it.ksize, Cout_pad, it.dgrad);
+    }
+}
+
+extern "C" long long yolo_pack_batch_blocks(int Cout, int Cin, int ksize, int dtype) {
+    const long long bytes = yolo_packed_weight_bytes(Cout, Cin, ksize, dtype);
+    if (bytes < 0) return bytes;
+    return (bytes / elem_size(dtype) + PACK_BLOCK_ELEMS - 1) / PACK_BLOCK_ELEMS;
+}
+
+extern "C" int yolo_pack_conv_weights_batch(const void* items_device, const long long* first_block_device, int n_items,
+                                            long long total_blocks, int dtype, void* stream) {
+    if (!items_device || !first_block_device || n_items <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffLL)
+        return YOLO_EINVAL;
+    if (dtype == YOLO_BF16)
+        YOLO_LAUNCH(pack_weights_batch_kernel<bf16_t>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                    (const PackItem*)items_device, first_block_device, n_items);
+    else if (dtype == YOLO_F32)
+        YOLO_LAUNCH(pack_weights_batch_kernel<float>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                    (const PackItem*)items_device, first_block_device, n_items);
+    else
+        return YOLO_EINVAL;
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
 }
 
 extern "C" long long yolo_packed_weight_bytes(int Cout, int Cin, int ksize, int dtype) {

@@ -60,6 +60,8 @@ SIGNATURES = {
     'yolo_nms_from_scores': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'yolo_nms': (_i, [_vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'yolo_pack_conv_weights_dgrad': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'yolo_pack_batch_blocks': (_ll, [_i, _i, _i, _i]),
+    'yolo_pack_conv_weights_batch': (_i, [_vp, _vp, _i, _ll, _i, _vp]),
     'yolo_bn_train_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _f, _f, _i, _vp]),
     'yolo_bn_train_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _i, _vp]),
     'yolo_conv_wgrad_workspace_bytes': (_ll, [_i, _i, _i, _i]),

@@ -85,22 +85,34 @@ class Trainer(object):
 
     # ---- weight images for the forward and data-gradient convolutions (re-packed after every update) ----
     def _repack(self):
+        """Forward and data-gradient weight images of every conv, re-packed after each update in ONE launch
+        (yolo_pack_conv_weights_batch) over a device-resident table built on first use."""
         lib, st = self.lib, L.stream_ptr()
-        for c in self.net.graph.convs():
-            w = self.pview[c.name + '.weight']
-            ent = self._prep.get(c.name)
-            if ent is None:
+        if not self._prep:
+            items = np.zeros(0, dtype=[('w', '<u8'), ('packed', '<u8'), ('cout', '<i4'), ('cin', '<i4'), ('k', '<i4'), ('dgrad', '<i4')])
+            recs, first = [], [0]
+            for c in self.net.graph.convs():
+                w = self.pview[c.name + '.weight']
                 wp = torch.empty(lib.yolo_packed_weight_bytes(c.cout, c.cin, c.k, self.ldt), dtype=torch.uint8, device=self.dev)
                 wd = torch.empty(lib.yolo_packed_weight_bytes(c.cin, c.cout, c.k, self.ldt), dtype=torch.uint8, device=self.dev)
                 cp = lib.yolo_padded_channels(max(c.cout, c.cin))
                 ones = torch.zeros(cp, dtype=torch.float32, device=self.dev); ones[:max(c.cout, c.cin)] = 1.0
                 bias = torch.zeros(cp, dtype=torch.float32, device=self.dev)
-                ent = self._prep[c.name] = (wp, wd, ones, bias, torch.zeros(cp, dtype=torch.float32, device=self.dev))
-            wp, wd, ones, bias, zeros = ent
-            L.check(lib.yolo_pack_conv_weights(L.ptr(w), L.ptr(wp), c.cout, c.cin, c.k, self.ldt, st), 'pack')
-            L.check(lib.yolo_pack_conv_weights_dgrad(L.ptr(w), L.ptr(wd), c.cout, c.cin, c.k, self.ldt, st), 'pack dgrad')
+                self._prep[c.name] = (wp, wd, ones, bias, torch.zeros(cp, dtype=torch.float32, device=self.dev))
+                # (the dgrad record carries the arguments of yolo_pack_conv_weights_dgrad after its swap: rows = Cin_f)
+                recs.append((w.data_ptr(), wp.data_ptr(), c.cout, c.cin, c.k, 0))
+                first.append(first[-1] + lib.yolo_pack_batch_blocks(c.cout, c.cin, c.k, self.ldt))
+                recs.append((w.data_ptr(), wd.data_ptr(), c.cin, c.cout, c.k, 1))
+                first.append(first[-1] + lib.yolo_pack_batch_blocks(c.cin, c.cout, c.k, self.ldt))
+            items = np.array(recs, dtype=items.dtype)
+            self._pack_items = torch.from_numpy(items.view(np.uint8).copy()).to(self.dev)
+            self._pack_first = torch.tensor(first, dtype=torch.int64, device=self.dev)
+            self._pack_n, self._pack_blocks = len(recs), first[-1]
+        L.check(lib.yolo_pack_conv_weights_batch(L.ptr(self._pack_items), L.ptr(self._pack_first), self._pack_n,
+                                                 self._pack_blocks, self.ldt, st), 'pack batch')
+        for c in self.net.graph.convs():
             if not c.bn:
-                bias[:c.cout].copy_(self.pview[c.name + '.bias'])
+                self._prep[c.name][3][:c.cout].copy_(self.pview[c.name + '.bias'])
 
     # ---- plan ---------------------------------------------------------------------------------------------
     def _new(self, shape):
