@@ -144,7 +144,7 @@ def test_wgrad_bf16_transposing_reads(lib, cuda, case):
     y.backward(rb(dy))
     xd, dyd = to_nhwc(x, 'bf16', cuda), to_nhwc(dy, 'bf16', cuda)
     dw = torch.ones((Cout, Cin, k, k), device=cuda)               # accumulates into the existing gradient
-    ws = torch.empty(lib.yolo_conv_wgrad_workspace_bytes(Cin, Cout, k, L.BF16), dtype=torch.uint8, device=cuda)
+    ws = torch.zeros(lib.yolo_conv_wgrad_workspace_bytes(Cin, Cout, k, L.BF16), dtype=torch.uint8, device=cuda)
     st = torch.cuda.current_stream().cuda_stream
     assert lib.yolo_conv_wgrad(dyd.data_ptr(), xd.data_ptr(), dw.data_ptr(), N, H, W, Cin, Cout, k, s, 0, L.BF16,
                                ws.data_ptr(), st) == 0

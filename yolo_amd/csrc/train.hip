@@ -516,7 +516,6 @@ static void wgrad_bf16_launch(const uint16_t* dy, const uint16_t* x, float* ws, 
     if (slices < 1) slices = 1;
     const int cps = (int)((chunks + slices - 1) / slices);
     slices = (chunks + cps - 1) / cps;
-    if (slices > 1) (void)hipMemsetAsync(ws, 0, (size_t)Cin * Cout * taps * 4, st);
     YOLO_LAUNCH((wgrad_bf16_kernel<MI, NI>), dim3((unsigned)(tiles_ci * tiles_co), taps, (unsigned)slices), dim3(256), 0, st,
                 dy, x, ws, N, H, W, Cin, Ho, Wo, Cout, ksize, stride, ps, tiles_ci, cps, slices > 1 ? 1 : 0,
                 make_fastdiv((unsigned)Ho * Wo), make_fastdiv((unsigned)Wo));
@@ -891,13 +890,15 @@ static bool wgrad_rows_dispatch(const uint16_t* dy, const uint16_t* x, float* dw
 }
 
 // dw_oihw[co][ci][tap] += dwt[tap][co][ci]
-__global__ void wgrad_finish_kernel(const float* __restrict__ dwt, float* __restrict__ dw, int Cout, int Cin, int taps,
+__global__ void wgrad_finish_kernel(float* __restrict__ dwt, float* __restrict__ dw, int Cout, int Cin, int taps,
                                     long long total) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;     // over [co][ci][tap]
     if (i >= total) return;
     const int tap = (int)(i % taps);
     const long long cc = i / taps;                                             // co*Cin + ci
-    dw[i] += dwt[(long long)tap * Cout * Cin + cc];
+    const long long j = (long long)tap * Cout * Cin + cc;
+    dw[i] += dwt[j];
+    dwt[j] = 0.f;                                    // leave the workspace zeroed for the next call (no memset launch)
 }
 
 extern "C" long long yolo_conv_wgrad_workspace_bytes(int Cin, int Cout, int ksize, int dtype) {
@@ -922,17 +923,15 @@ extern "C" int yolo_conv_wgrad(const void* dy, const void* x, float* dw_oihw, in
     const int taps = ksize * ksize;
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
-    const long long wsb = (long long)Cin * Cout * taps * 4;
     const long long total = (long long)Cin * Cout * taps;
     if (ksize == 3 && Cin <= 64) {
-        (void)hipMemsetAsync(workspace, 0, wsb, st);
         const uint16_t* d16 = (const uint16_t*)dy;
         const uint16_t* x16 = (const uint16_t*)x;
         float* ws = (float*)workspace;
         // CO_F = 1 (144 accumulator registers): CO_F = 2 needs 288 and spills
         if (stride == 2) wgrad_strip_launch<1, 2, 1>(d16, x16, ws, N, H, W, Cin, Ho, Wo, Cout, ps, st);
         else wgrad_strip_launch<1, 1, 2>(d16, x16, ws, N, H, W, Cin, Ho, Wo, Cout, ps, st);
-        YOLO_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
+        YOLO_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (float*)workspace,
                     dw_oihw, Cout, Cin, taps, total);
         YOLO_LAUNCH_CHECK();
         return YOLO_OK;
@@ -940,10 +939,9 @@ extern "C" int yolo_conv_wgrad(const void* dy, const void* x, float* dw_oihw, in
     // row-group kernel: wins on the narrow deep maps (26x26: 210 -> 163 us, 13x13: 211 -> 175 us at batch 64); on wider
     // maps its atomic epilogue (one 64x64x9 tile per block) costs more than the saved L2 traffic
     if (ksize == 3 && stride == 1 && W <= 40) {
-        (void)hipMemsetAsync(workspace, 0, wsb, st);
         if (wgrad_rows_dispatch((const uint16_t*)dy, (const uint16_t*)x, (float*)workspace, N, H, W, Cin, Cout, ps, st)) {
             YOLO_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                        (const float*)workspace, dw_oihw, Cout, Cin, taps, total);
+                        (float*)workspace, dw_oihw, Cout, Cin, taps, total);
             YOLO_LAUNCH_CHECK();
             return YOLO_OK;
         }
@@ -955,7 +953,7 @@ extern "C" int yolo_conv_wgrad(const void* dy, const void* x, float* dw_oihw, in
         // (256x128 / 128x256 / 256x256 tiles were measured 10-40 % slower: one wave per SIMD)
         wgrad_bf16_launch<2, 2>(d16, x16, ws, N, H, W, Cin, Ho, Wo, Cout, ksize, stride, ps, st);
     }
-    YOLO_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
+    YOLO_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (float*)workspace,
                 dw_oihw, Cout, Cin, taps, total);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;

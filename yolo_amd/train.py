@@ -80,7 +80,7 @@ class Trainer(object):
         cmax = max(c.cout for c in g.convs())
         self.ws = torch.zeros(3 * cmax, dtype=torch.float64, device=self.dev)
         wsb = max(self.lib.yolo_conv_wgrad_workspace_bytes(max(c.cin, 8), c.cout, c.k, self.ldt) for c in g.convs())
-        self.wg_ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=self.dev)
+        self.wg_ws = torch.zeros(max(wsb, 16), dtype=torch.uint8, device=self.dev)       # (kept zeroed by the library)
         self._repack()
 
     # ---- weight images for the forward and data-gradient convolutions (re-packed after every update) ----
