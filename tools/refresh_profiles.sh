@@ -20,9 +20,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o p --
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_f -o p -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --tune-cache $TC > /dev/null 2>> $OUT/${TAG}_bench.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_w -o p -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --tune-cache $TC > /dev/null 2>> $OUT/${TAG}_bench.err
 python tools/pmc_traffic.py $OUT/${TAG}_pmc_f $OUT/${TAG}_pmc_w 32 416 $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_summary.txt 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_m -o p -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --tune-cache $TC > /dev/null 2>> $OUT/${TAG}_bench.err
+python tools/pmc_mfma.py $OUT/${TAG}_pmc_m $OUT/${TAG}_pmc_mfma.json >> $OUT/${TAG}_pmc_summary.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_train -o p -- python bench.py --mode train --steps 10 --warmup 2 --tune-cache $OUT/${TAG}_tune_train.json > $OUT/${TAG}_train_bench_profiled.json 2>> $OUT/${TAG}_bench.err
 cp $OUT/${TAG}_prof/p_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv 2>/dev/null
 cp $OUT/${TAG}_prof_train/p_kernel_stats.csv $OUT/${TAG}_train_kernel_stats.csv 2>/dev/null
-rm -rf $OUT/${TAG}_prof $OUT/${TAG}_prof_train $OUT/${TAG}_pmc_f $OUT/${TAG}_pmc_w
+rm -rf $OUT/${TAG}_prof $OUT/${TAG}_prof_train $OUT/${TAG}_pmc_f $OUT/${TAG}_pmc_w $OUT/${TAG}_pmc_m
 ls -la $OUT | grep ${TAG}_
 tail -c 600 $OUT/${TAG}_bench.json
