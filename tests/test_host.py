@@ -100,3 +100,22 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(L, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(L.YoloError):
         L.load()
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r01_bench.json is the line bench.py printed on the GPU box: it must carry every field of the driver's
+    contract, the roofline of the dominant kernel and the CPU baseline."""
+    import json, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r01_bench.json')
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['unit'] == 'images/s' and d['scaling'] == 'weak' and d['higher_is_better'] is True and d['vs_baseline'] is None
+    assert d['data'] == 'synthetic' and d['dtype'] == 'bf16' and 'workload' in d['config'] and 'model' not in d['config']
+    r = d['roofline']
+    assert r['bound'] in ('mfma', 'hbm') and r['unit'] in ('TFLOP/s', 'GB/s')
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and (r['traffic'] is None or r['traffic'] > 0)
+    c = d['cpu_baseline']
+    assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['sample']
+    assert abs(d['value'] - d['n_gpus'] * d['config']['global_batch'] / d['n_gpus'] / (d['ms_per_step'] / 1e3)) / d['value'] < 0.01
