@@ -76,7 +76,30 @@ def train_fixture():
                         adam=np.stack(traj))
 
 
+def lp_fixture():
+    """CarLPNet (car_and_LP/YOLO.py): LP-branch output of the micro net, predict_LP rows, LP targets and losses."""
+    spec = dict(og.spec_micro(), LP_slice_point=[1, 3, 4, 7, 10], LP_r_max=[45, 60, 45])
+    size = (64, 96)
+    g = og.build_graph(spec)
+    P = og.init_params(g, seed=3, bn='random')
+    x = np.random.default_rng(4).random((3, 3) + size, dtype=np.float32)
+    outs, lp = of.forward_torch(g, P, x)
+    o64, lp64 = of.forward_numpy64(g, P, x)
+    assert np.abs(lp[0].numpy() - lp64[0]).max() < 1e-5, 'restatements disagree'
+    pred, best = od.predict_LP_batch([lp[0].numpy()], spec['LP_slice_point'], spec['LP_r_max'])
+    lpl = ot.synthetic_lp_labels(3, size, seed=2, add_rate=1.0)
+    step = od.init_steps(spec['layers'], spec['all_anchors'])[0]
+    scale = {'LP_score': 0.1, 'LP_xy': 10.0, 'LP_z': 1.0, 'LP_r': 0.1, 'LP_class': 0.3}
+    losses, gout, (y, mask) = ot.lp_loss_and_grad_wrt_output(lp[0].numpy(), lpl, size, step, spec['LP_r_max'],
+                                                             spec['LP_slice_point'], scale)
+    cells = [ot.find_best_LP(lpl[b, 0], size, step, spec['LP_r_max'])[0] for b in range(3)]
+    np.savez_compressed(os.path.join(HERE, 'lp_micro.npz'), lp_out=lp[0].numpy(), pred=pred, best=best, lp_labels=lpl,
+                        losses=np.stack(losses), grad_sum=np.asarray([np.abs(gout).sum()]), grad_sel=gout.reshape(-1)[::37],
+                        cells=np.asarray(cells))
+
+
 if __name__ == '__main__':
+    lp_fixture()
     forward_fixture('forward_micro_identity', og.spec_micro(), (64, 96), 2, 0, 'identity', True)
     forward_fixture('forward_micro_random', og.spec_micro(), (64, 96), 2, 0, 'random', True)
     forward_fixture('forward_test_yaml', og.spec_test_yaml(), (192, 256), 1, 0, 'random', False)

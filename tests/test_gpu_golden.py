@@ -51,3 +51,39 @@ def test_detect_vs_golden(cuda):
     iou = get_iou(torch.from_numpy(ltrb).to(cuda), torch.from_numpy(z['target'])).cpu().numpy().reshape(-1)
     assert int(np.argmax(iou)) == int(z['iou_argmax'][0])
     np.testing.assert_allclose(iou[z['sel']], z['iou_sel'], rtol=1e-6, atol=1e-7)
+
+
+def test_lp_branch_vs_golden(cuda):
+    """CarLPNet fixture (tests/golden/lp_micro.npz): LP-branch output, predict_LP rows, LP cells and losses."""
+    import ctypes as C
+    from yolo_amd.net import CarLPNet
+    from yolo_amd.detect import predict_LP_batch
+    from yolo_amd import lib as L
+    z = np.load(os.path.join(GOLD, 'lp_micro.npz'))
+    spec = dict(og.spec_micro(), LP_slice_point=[1, 3, 4, 7, 10], LP_r_max=[45, 60, 45])
+    size = (64, 96)
+    P = og.init_params(og.build_graph(spec), seed=3, bn='random')
+    x = np.random.default_rng(4).random((3, 3) + size, dtype=np.float32)
+    net = CarLPNet(spec, dtype='f32', device=cuda).load_params(P)
+    outs, lp = net(torch.from_numpy(x).to(cuda))
+    np.testing.assert_allclose(lp[0].cpu().numpy(), z['lp_out'], rtol=0, atol=1e-3)
+    # post-processing and losses on the FIXTURE's logits: exact cells, tight values
+    gold = torch.from_numpy(z['lp_out']).to(cuda)
+    pred = predict_LP_batch([gold], spec['LP_slice_point'], spec['LP_r_max'])
+    np.testing.assert_allclose(pred, z['pred'], rtol=1e-6, atol=1e-6)
+    lib = L.load()
+    st = torch.cuda.current_stream().cuda_stream
+    labels = torch.from_numpy(z['lp_labels']).to(cuda)
+    rec = torch.empty((3, 1, 8 + 3), device=cuda)
+    step = od.init_steps(spec['layers'], spec['all_anchors'])[0]
+    assert lib.yolo_assign_targets_lp(labels.data_ptr(), rec.data_ptr(), 3, 1, 10, 3, size[0], size[1], step, 45.0, 60.0, 45.0, st) == 0
+    fw = size[1] // step
+    assert [int(v) for v in rec[:, 0, 1].cpu()] == [int(h * fw + w) for h, w in z['cells']]      # bit-exact cells
+    logits = gold.reshape(3, -1, 10).contiguous()
+    dl = torch.empty_like(logits); ls = torch.empty((5, 3), device=cuda)
+    s5 = (C.c_float * 5)(0.1, 10.0, 1.0, 0.1, 0.3)
+    assert lib.yolo_loss_lp_fwd_bwd(logits.data_ptr(), rec.data_ptr(), dl.data_ptr(), ls.data_ptr(), 3, logits.shape[1], 10, 1, s5, 1.0, 0.1, st) == 0
+    np.testing.assert_allclose(ls.cpu().numpy(), z['losses'], rtol=1e-4, atol=1e-8)
+    g = dl.cpu().numpy()
+    np.testing.assert_allclose(np.abs(g).sum(), z['grad_sum'][0], rtol=1e-4)
+    np.testing.assert_allclose(g.reshape(-1)[::37], z['grad_sel'], rtol=1e-3, atol=1e-7)

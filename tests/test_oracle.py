@@ -207,3 +207,20 @@ def test_lp_branch_two_restatements_agree_and_predict_lp():
     sg = lambda v: 1.0 / (1.0 + math.exp(-v))
     expect = [sg(2.0), 10.0, -20.0, 3.0, 0.0, (sg(1.0) - 0.5) * 2 * 60 * math.pi / 180, (sg(-1.0) - 0.5) * 2 * 45 * math.pi / 180]
     np.testing.assert_allclose(pred[0], expect, rtol=1e-5, atol=1e-6)
+
+
+def test_lp_golden():
+    """The committed LP fixture reproduces from the oracle (make_golden.py: lp_fixture)."""
+    from oracle import graph as og, forward as of, detect as od, train as ot
+    z = np.load(os.path.join(GOLD, 'lp_micro.npz'))
+    spec = dict(og.spec_micro(), LP_slice_point=[1, 3, 4, 7, 10], LP_r_max=[45, 60, 45])
+    size = (64, 96)
+    g = og.build_graph(spec)
+    P = og.init_params(g, seed=3, bn='random')
+    x = np.random.default_rng(4).random((3, 3) + size, dtype=np.float32)
+    outs, lp = of.forward_torch(g, P, x)
+    np.testing.assert_allclose(lp[0].numpy(), z['lp_out'], rtol=0, atol=1e-5)
+    pred, best = od.predict_LP_batch([z['lp_out']], spec['LP_slice_point'], spec['LP_r_max'])
+    np.testing.assert_array_equal(best, z['best'])
+    np.testing.assert_allclose(pred, z['pred'], rtol=1e-6)
+    assert np.array_equal(ot.synthetic_lp_labels(3, size, seed=2, add_rate=1.0), z['lp_labels'])
