@@ -219,8 +219,15 @@ class Trainer(object):
         for op in P.fwd:
             if op['kind'] == 'conv_bn':
                 c = op['c']
-                L.check(lib.yolo_conv_fwd(C.byref(op['desc']), st), 'conv ' + c.name)
                 y, z = op['yraw'], op['z']
+                g = self.net.graph
+                if c is g.stem and self.ldt == L.BF16 and c.cin == 3 and c.cout % 4 == 0 and c.cout <= 64:
+                    # the fused NCHW-image stem kernel of the inference path (identity scale/bias, linear): raw y
+                    wp, wd, ones, bias, zeros = self._prep[c.name]
+                    L.check(lib.yolo_stem_conv_fwd(images.data_ptr(), L.ptr(self.pview[c.name + '.weight']), L.ptr(ones),
+                                                   L.ptr(zeros), L.ptr(y.val), B, H, W, 3, c.cout, self.ldt, 1.0, st), 'stem')
+                else:
+                    L.check(lib.yolo_conv_fwd(C.byref(op['desc']), st), 'conv ' + c.name)
                 npix = y.shape[0] * y.shape[1] * y.shape[2]
                 p = self.net.params
                 L.check(lib.yolo_bn_train_fwd(L.ptr(y.val), L.ptr(p[c.name + '.gamma']), L.ptr(p[c.name + '.beta']),
