@@ -175,6 +175,20 @@ int yolo_nms(const float* rows, int B, int nbox, int C, int mode, float valid_th
 int yolo_pack_conv_weights_dgrad(const float* w_oihw, void* packed, int Cout_f, int Cin_f, int ksize,
                                  int dtype, void* stream);
 
+/* Sub-pixel form of the data gradient of a 3x3 stride-2 pad-1 convolution (Cout_f, Cin_f) -- the down-sampling convs of
+ * every stage, basic_yolo.py:24 -- for even input sizes: instead of zero-dilating dy (4x the arithmetic), the four
+ * sub-pixel phases of dx are four output-channel blocks of one 2x2-window convolution over dy:
+ *   dx[n, 2m+a, 2n+b, c] = sum_{ty,tx in {0,1}} sum_k W'[(2a+b) Cin_f + c][k][ty][tx] dy[n, m+ty, n+tx, k]   (zero beyond)
+ * with W'[..a..][k][ty] = W[k][c][1] for (a,ty) = (0,0), W[k][c][2] for (1,0), W[k][c][0] for (1,1), 0 for (0,1)
+ * (likewise b/tx).  yolo_pack_conv_weights_dgrad_s2 writes that image (yolo_packed_weight_bytes(4 Cin_f, Cout_f, 2,
+ * dtype) bytes; batch records: Cout = 4 Cin_f, Cin = Cout_f, ksize = 2, dgrad = 2).  yolo_conv_dgrad_s2 runs it:
+ * d->x = dy (N,H,W,Cin = Cout_f), d->Cout = 4 Cin_f, d->y = dx (N,2H,2W,Cin_f) dense, d->residual = a gradient to
+ * accumulate onto (same shape as dx) or NULL, d->scale / d->bias over 4 Cin_f (padded) channels, ksize / stride /
+ * strides ignored; bf16 only.  YOLO_EUNSUPPORTED (Cin_f % 8, Cout_f % 32, halo does not fit): use yolo_dilate2x +
+ * yolo_conv_fwd instead.  d->algo: 0 = heuristic, or one of 2 / 6 / 10 / 4 (256 / 192 / 128 px x 256, 128 x 128). */
+int yolo_pack_conv_weights_dgrad_s2(const float* w_oihw, void* packed, int Cout_f, int Cin_f, int dtype, void* stream);
+int yolo_conv_dgrad_s2(const yolo_conv_desc* d, void* stream);
+
 /* Every conv of a network packed in ONE launch (the training step re-packs all images after each update).
  * items_device: device array of n_items records { const float* w_oihw; void* packed; int Cout, Cin, ksize, dgrad; }
  * (32 bytes each; dgrad = 1: the data-gradient image of the FORWARD conv (Cin, Cout swapped as in

@@ -152,6 +152,57 @@ def test_wgrad_bf16_transposing_reads(lib, cuda, case):
     np.testing.assert_allclose(dw.cpu().numpy() - 1.0, ref, rtol=1e-3, atol=2e-3 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize('case', [(2, 32, 16, 24, 64), (3, 64, 26, 26, 128), (2, 8, 12, 20, 32), (1, 128, 52, 52, 256),
+                                  (4, 256, 26, 26, 512), (70, 32, 4, 4, 64), (1, 40, 6, 10, 96), (2, 64, 2, 2, 32)])
+def test_dgrad_s2_subpixel(lib, cuda, case):
+    """yolo_conv_dgrad_s2: the data gradient of a 3x3 stride-2 conv as ONE 2x2-window conv over dy whose four
+    output-channel blocks are the four sub-pixel phases of dx -- against torch autograd on the bf16-rounded operands,
+    every tile variant, with and without accumulation into an existing gradient."""
+    N, Cin, H, W, Cout = case                                   # forward conv: (N,Cin,H,W) -> (N,Cout,H/2,W/2)
+    x, w, dy, _, _ = _ref((N, Cin, H, W, Cout, 3, 2), 5)
+    rb = lambda a: torch.from_numpy(a).to(torch.bfloat16).float()
+    xt = torch.from_numpy(x).requires_grad_(True)
+    F.conv2d(xt, rb(w), None, stride=2, padding=1).backward(rb(dy))
+    ref = xt.grad.numpy()
+    st = torch.cuda.current_stream().cuda_stream
+    wd = torch.empty(lib.yolo_packed_weight_bytes(4 * Cin, Cout, 2, L.BF16), dtype=torch.uint8, device=cuda)
+    assert lib.yolo_pack_conv_weights_dgrad_s2(torch.from_numpy(w).to(cuda).data_ptr(), wd.data_ptr(), Cout, Cin, L.BF16, st) == 0
+    dyd = to_nhwc(dy, 'bf16', cuda)
+    cp = lib.yolo_padded_channels(4 * Cin)
+    ones = torch.ones(cp, device=cuda); zeros = torch.zeros(cp, device=cuda)
+    ran = 0
+    for algo in (0, 2, 6, 10, 4):
+        out = torch.full((N, H, W, Cin), float('nan'), dtype=torch.bfloat16, device=cuda)
+        d = L.ConvDesc()
+        d.x, d.w_packed, d.scale, d.bias, d.y = dyd.data_ptr(), wd.data_ptr(), ones.data_ptr(), zeros.data_ptr(), out.data_ptr()
+        d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.dtype, d.slope = N, H // 2, W // 2, Cout, 4 * Cin, 2, 1, L.BF16, 1.0
+        d.algo = algo
+        rc = lib.yolo_conv_dgrad_s2(C.byref(d), st)
+        if algo and rc == L.EUNSUPPORTED:
+            continue
+        assert rc == 0, (algo, rc)
+        ran += 1
+        got = from_nhwc(out)
+        assert np.isfinite(got).all(), algo
+        np.testing.assert_allclose(got, ref, rtol=1e-2, atol=1e-2 * np.abs(ref).max(), err_msg='algo %d' % algo)
+        d.residual = out.data_ptr()                              # accumulate in place
+        assert lib.yolo_conv_dgrad_s2(C.byref(d), st) == 0
+        np.testing.assert_allclose(from_nhwc(out), 2 * ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max(), err_msg='acc algo %d' % algo)
+    assert ran >= 2                                              # the heuristic and at least one explicit variant
+
+
+def test_dgrad_s2_rejects(lib, cuda):
+    d = L.ConvDesc()
+    buf = torch.zeros(1 << 16, device=cuda)
+    d.x = d.w_packed = d.scale = d.bias = d.y = buf.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Cout, d.dtype, d.slope = 1, 4, 4, 32, 4 * 12, L.BF16, 1.0     # Cin_f = 12: not a multiple of 8
+    assert lib.yolo_conv_dgrad_s2(C.byref(d), None) == L.EUNSUPPORTED
+    d.Cout, d.dtype = 4 * 16, L.F32
+    assert lib.yolo_conv_dgrad_s2(C.byref(d), None) == L.EUNSUPPORTED
+    d.dtype, d.slope = L.BF16, 2.0
+    assert lib.yolo_conv_dgrad_s2(C.byref(d), None) == L.EINVAL
+
+
 def test_bn_train_bf16(lib, cuda):
     N, H, W, Cc = 3, 13, 13, 64
     rng = np.random.default_rng(5)

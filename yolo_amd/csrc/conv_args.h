@@ -32,6 +32,7 @@ struct ConvArgs {
     int TWt, nstrips, tiles_per_strip, PW, total_i;
     int nchunks, tiles_c;
     int out_f32;
+    int d2s;        // 1: Cout = 4 sub-pixel phases x Cout/4 channels, stored depth-to-space into (N,2Ho,2Wo,Cout/4)
     float slope;
     long long y_bs, y_ps;
     FastDiv d_PW, d_H1, d_TWt, d_Ho, d_HoWo, d_tc, d_tps;   // divisors PW, H+1, TWt, Ho, Ho*Wo, tiles_c, tiles_per_strip
@@ -48,14 +49,15 @@ static inline void conv_args_fastdiv(ConvArgs& a) {
 struct NameOut { char* buf; int len; };
 
 // Worst-case number of LDS slots of the zero-padded input halo tile for a BP-pixel output tile on
-// strips of width d (stride S, 3x3, pad 1).
-static inline int conv_halo_slots(int BP, int d, int Ho, int H, int S, long long total_rows) {
+// strips of width d (stride S; KS = 3: 3x3, pad 1; KS = 2: 2x2 window anchored at the output pixel, zero row / column
+// after the last).
+static inline int conv_halo_slots(int BP, int d, int Ho, int H, int S, long long total_rows, int KS = 3) {
     long long nro = (BP - 1 + d - 1) / d + 1;
     if (nro > total_rows) nro = total_rows;
     const long long nb = (nro - 1 + Ho - 1) / Ho;
     const int extra = H + 1 - Ho * S;
-    const long long NR = (long long)S * (nro - 1) + 3 + nb * (extra > 0 ? extra : 0);
-    const int PW = (d - 1) * S + 3;
+    const long long NR = (long long)S * (nro - 1) + KS + nb * (extra > 0 ? extra : 0);
+    const int PW = (d - 1) * S + KS;
     return (int)(NR * PW);
 }
 

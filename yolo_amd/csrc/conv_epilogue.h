@@ -104,6 +104,14 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
     const int row0 = lane / LPR;
     const int co = co_w + col * CPL;
     const bool co_ok = co < a.Cout;
+    // element offset of this lane's channel run inside its pixel; sub-pixel mode (a.d2s, the stride-2 data gradient):
+    // channel block ph = co / C of 4 x C is pixel (ph >> 1, ph & 1) of the 2x2 output patch (C % CPL == 0 is checked
+    // by the host)
+    long long cofs = co;
+    if (a.d2s) {
+        const int C4 = a.Cout >> 2, ph = co / C4;
+        cofs = (long long)((ph >> 1) * 2 * a.Wo + (ph & 1)) * C4 + (co - ph * C4);
+    }
     float sc[CPL], bi[CPL];
 #pragma unroll
     for (int q = 0; q < CPL / 4; ++q) {
@@ -128,7 +136,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
 #pragma unroll
             for (int k = 0; k < NPASS; ++k) {
                 rv[ni & 1][k] = make_uint4(0, 0, 0, 0);
-                if (yo[ni & 1][k] >= 0) rv[ni & 1][k] = *(const uint4*)(a.res + (yo[ni & 1][k] + co) * ES);
+                if (yo[ni & 1][k] >= 0) rv[ni & 1][k] = *(const uint4*)(a.res + (yo[ni & 1][k] + cofs) * ES);
             }
         }
     };
@@ -177,7 +185,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                 ov = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
                                 __float_as_uint(v[3]));
             }
-            if (yo[ni & 1][k] >= 0) *(uint4*)(a.y + (yo[ni & 1][k] + co) * ES) = ov;
+            if (yo[ni & 1][k] >= 0) *(uint4*)(a.y + (yo[ni & 1][k] + cofs) * ES) = ov;
         }
     }
 }

@@ -355,6 +355,7 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     a.Cout_pad = round_up(d->Cout, YOLO_COUT_PAD);
     a.nchunks = (d->Cin * es + 63) / 64;
     a.out_f32 = d->out_f32;
+    a.d2s = 0;
     a.slope = d->slope;
     a.y_ps = d->y_pixel_stride ? d->y_pixel_stride : d->Cout;
     a.y_bs = d->y_batch_stride ? d->y_batch_stride : (long long)a.Ho * a.Wo * a.y_ps;
@@ -385,6 +386,51 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     return launch_dtype<float>(a, d->ksize, d->stride, st, nm);
 }
 
+// Data gradient of a 3x3 stride-2 pad-1 convolution without the zero-dilated dy: the four sub-pixel phases of dx are
+// four output-channel blocks of ONE 2x2-window convolution over dy (16 instead of 36 tap-products per dy pixel) whose
+// epilogue stores depth-to-space.  Even H/W of dx only (2H x 2W); bf16; pipelined variants only -- callers fall back
+// to yolo_dilate2x + yolo_conv_fwd on YOLO_EUNSUPPORTED.
+extern "C" int yolo_conv_dgrad_s2(const yolo_conv_desc* d, void* stream) {
+    if (!d || !d->x || !d->w_packed || !d->scale || !d->bias || !d->y) return YOLO_EINVAL;
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->algo < 0) return YOLO_EINVAL;
+    if (!(d->slope >= 0.f && d->slope <= 1.f)) return YOLO_EINVAL;
+    if (d->dtype != YOLO_BF16 || d->out_f32 || d->y_pixel_stride || d->y_batch_stride) return YOLO_EUNSUPPORTED;
+    if ((d->Cout % 32) || (d->Cin * 2) % 64) return YOLO_EUNSUPPORTED;      // a lane's 8 couts stay inside one phase
+    ConvArgs a;
+    a.x = (const char*)d->x; a.wp = (const char*)d->w_packed; a.scale = d->scale; a.bias = d->bias;
+    a.res = (const char*)d->residual; a.y = (char*)d->y;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
+    a.Ho = d->H; a.Wo = d->W;
+    a.Cout_pad = round_up(d->Cout, YOLO_COUT_PAD);
+    a.nchunks = (d->Cin * 2 + 63) / 64;
+    a.out_f32 = 0; a.d2s = 1; a.slope = d->slope;
+    a.y_ps = d->Cout / 4;
+    a.y_bs = (long long)a.Ho * a.Wo * d->Cout;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->algo) return conv_pipe_dispatch(a, 2, 1, d->dtype, d->algo, st, nullptr);
+    // rounds x tile cost as in conv_auto_algo, then the first variant whose halo fits
+    struct V { int algo, bp, bc, bpc; };
+    static const V vs[] = {{2, 256, 256, 1}, {6, 192, 256, 1}, {10, 128, 256, 1}, {4, 128, 128, 2}};
+    const long long px = (long long)a.N * a.Ho * a.Wo;
+    double cost[4];
+    for (int i = 0; i < 4; ++i) {
+        const long long tiles = ((px + vs[i].bp - 1) / vs[i].bp) * ((a.Cout + vs[i].bc - 1) / vs[i].bc);
+        const long long slots = 256LL * vs[i].bpc;
+        cost[i] = (double)((tiles + slots - 1) / slots) * vs[i].bp * vs[i].bc * vs[i].bpc;
+    }
+    bool used[4] = {false, false, false, false};
+    for (int k = 0; k < 4; ++k) {
+        int b = -1;
+        for (int i = 0; i < 4; ++i)
+            if (!used[i] && (b < 0 || cost[i] < cost[b])) b = i;
+        used[b] = true;
+        ConvArgs t = a;
+        const int rc = conv_pipe_dispatch(t, 2, 1, d->dtype, vs[b].algo, st, nullptr);
+        if (rc != YOLO_EUNSUPPORTED) return rc;
+    }
+    return YOLO_EUNSUPPORTED;
+}
+
 // ------------------------------------------------------------------------------------------
 // Weight packing: OIHW f32 -> [chunk][tap][Cout_pad][64 B], 16-byte units XOR-swizzled
 // ------------------------------------------------------------------------------------------
@@ -409,10 +455,19 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ w, T* __restr
     if (co < Cout && ci < Cin) {
         if (!dgrad) {
             v = w[((long long)(co * Cin + ci) * ks + tap / ks) * ks + tap % ks];
-        } else {
+        } else if (dgrad == 1) {
             // data-gradient image: rows = forward INPUT channels, K = forward OUTPUT channels, taps flipped
             // (w is the forward OIHW tensor with O = Cin here, I = Cout here)
             v = w[((long long)(ci * Cout + co) * ks + (ks - 1 - tap / ks)) * ks + (ks - 1 - tap % ks)];
+        } else {
+            // sub-pixel data gradient of a 3x3 stride-2 pad-1 conv (ks == 2, Cout = 4 x Cin_f, Cin = Cout_f):
+            // dx[2m+a][2n+b][c] = sum_{ty,tx,k} W'[(a,b,c)][k][ty][tx] dy[m+ty][n+tx][k].  From y[o] = sum_t w[t] x[2o+t-1]:
+            // the even position (a = 0) only meets tap 1 of output m; the odd one meets tap 2 of m and tap 0 of m+1.
+            const int Cf = Cout >> 2, ph = co / Cf, cf = co - ph * Cf;
+            const int ty = tap >> 1, tx = tap & 1;
+            const int ky = (ph >> 1) == 0 ? (ty == 0 ? 1 : -1) : (ty == 0 ? 2 : 0);
+            const int kx = (ph & 1) == 0 ? (tx == 0 ? 1 : -1) : (tx == 0 ? 2 : 0);
+            if (ky >= 0 && kx >= 0) v = w[((long long)(ci * Cf + cf) * 3 + ky) * 3 + kx];
         }
     }
     if constexpr (sizeof(T) == 2)
@@ -482,7 +537,7 @@ extern "C" int yolo_pack_conv_weights_batch(const void* items_device, const long
 }
 
 extern "C" long long yolo_packed_weight_bytes(int Cout, int Cin, int ksize, int dtype) {
-    if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return YOLO_EINVAL;
+    if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 2 && ksize != 3)) return YOLO_EINVAL;
     const int nchunks = (Cin * elem_size(dtype) + 63) / 64;
     return (long long)nchunks * ksize * ksize * round_up(Cout, YOLO_COUT_PAD) * 64;
 }
@@ -503,9 +558,19 @@ extern "C" int yolo_pack_conv_weights_dgrad(const float* w_oihw, void* packed, i
     return pack_impl(w_oihw, packed, Cin_f, Cout_f, ksize, dtype, 1, stream);
 }
 
+// Weight image of the SUB-PIXEL data gradient of a 3x3 stride-2 forward conv (Cout_f, Cin_f): a 2x2-window conv with
+// 4 x Cin_f output channels (phase-major) over Cout_f input channels, consumed by yolo_conv_dgrad_s2.
+// Size = yolo_packed_weight_bytes(4 * Cin_f, Cout_f, 2, dtype).
+extern "C" int yolo_pack_conv_weights_dgrad_s2(const float* w_oihw, void* packed, int Cout_f, int Cin_f, int dtype,
+                                               void* stream) {
+    if (Cin_f <= 0 || Cin_f > (1 << 28)) return YOLO_EINVAL;
+    return pack_impl(w_oihw, packed, 4 * Cin_f, Cout_f, 2, dtype, 2, stream);
+}
+
 static int pack_impl(const float* w_oihw, void* packed, int Cout, int Cin, int ksize, int dtype, int dgrad,
                      void* stream) {
     if (!w_oihw || !packed) return YOLO_EINVAL;
+    if ((ksize == 2) != (dgrad == 2)) return YOLO_EINVAL;
     const long long bytes = yolo_packed_weight_bytes(Cout, Cin, ksize, dtype);
     if (bytes < 0) return (int)bytes;
     const int Cout_pad = round_up(Cout, YOLO_COUT_PAD);

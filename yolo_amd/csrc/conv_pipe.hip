@@ -88,7 +88,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     constexpr int BC = WAVES_C * MI * 32;
     constexpr int NTAP = KS * KS;
     constexpr int PPC = NTAP / PT;                       // phases per K-chunk
-    static_assert(NTAP % PT == 0 && (KS == 3 || PT == 1), "phase shape");
+    static_assert(NTAP % PT == 0 && (KS != 1 || PT == 1), "phase shape");
     constexpr int W_STAGE = PT * BC * 64;                // bytes per weight ring slot
     constexpr int WL = W_STAGE / (NT * 16);              // LDS-DMAs per thread per phase (weights)
     static_assert(W_STAGE % (NT * 16) == 0, "weight stage must be whole DMAs");
@@ -103,8 +103,9 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     constexpr int L13_ = 3 * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) > EPI1_ ? 3 * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) : EPI1_;
     constexpr int L1N_ = YOLO_RING1 * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) > EPI1_ ? YOLO_RING1 * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) : EPI1_;
     constexpr int R1 = (L1N_ <= 163840 && 163840 / L1N_ == 163840 / L13_) ? YOLO_RING1 : 3;
-    constexpr int XBUFS = (KS == 3) ? 2 : R1;
-    static_assert(KS == 3 || XSLOTS == BP, "1x1: one slot per pixel");
+    constexpr int XBUFS = (KS != 1) ? 2 : R1;
+    static_assert(KS != 1 || XSLOTS == BP, "1x1: one slot per pixel");
+    constexpr int PAD = KS / 2 - (KS == 2 ? 1 : 0);          // 3x3: 1; 2x2 (sub-pixel data gradient) and 1x1: 0
     constexpr int W_OFF = XBUFS * X_STAGE;
     // 3x3: the X DMAs of the next chunk are spread over the phases of this chunk (phase q issues
     // j = q, q+PPC, ...)
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     constexpr int EPI_BYTES_ = WAVES_P * WAVES_C * YOLO_EPI_WAVE_BYTES;
     constexpr int LDS3 = XBUFS * X_STAGE + 3 * W_STAGE > EPI_BYTES_ ? XBUFS * X_STAGE + 3 * W_STAGE : EPI_BYTES_;
     constexpr int LDSN = XBUFS * X_STAGE + YOLO_WRING * W_STAGE > EPI_BYTES_ ? XBUFS * X_STAGE + YOLO_WRING * W_STAGE : EPI_BYTES_;
-    constexpr int WR = (KS == 3) ? ((LDSN <= 163840 && 163840 / LDSN == 163840 / LDS3) ? YOLO_WRING : 3) : R1;
+    constexpr int WR = (KS != 1) ? ((LDSN <= 163840 && 163840 / LDSN == 163840 / LDS3) ? YOLO_WRING : 3) : R1;
     constexpr int PIPE_BYTES = XBUFS * X_STAGE + WR * W_STAGE;
     constexpr int EPI_BYTES = NW * YOLO_EPI_WAVE_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES];
@@ -140,14 +141,14 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     const int row_bytes = a.Cin * (int)sizeof(T);
 
     int Rin_lo = 0, HS = XSLOTS, x0 = 0;
-    if constexpr (KS == 3) {
+    if constexpr (KS != 1) {
         const int i_last = min(i0 + BP, a.total_i) - 1;
         const int r_first = fdiv(i0, a.d_TWt), r_last = fdiv(i_last, a.d_TWt);
         const int n_f = fdiv(r_first, a.d_Ho), n_l = fdiv(r_last, a.d_Ho);
         Rin_lo = n_f * (H + 1) + (r_first - n_f * Ho) * S;
-        const int Rin_hi = n_l * (H + 1) + (r_last - n_l * Ho) * S + 2;
+        const int Rin_hi = n_l * (H + 1) + (r_last - n_l * Ho) * S + KS - 1;
         HS = (Rin_hi - Rin_lo + 1) * PW;
-        x0 = strip * TWt * S - 1;
+        x0 = strip * TWt * S - PAD;
     }
 
     const char* wsrc = a.wp + (long long)co0 * 64 + tid * 16;
@@ -192,13 +193,13 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         const int slot = u >> 2, part = u & 3;
         bool valid;
         long long off;
-        if constexpr (KS == 3) {
+        if constexpr (KS != 1) {
             const int rr = fdiv(slot, a.d_PW), cc = slot - rr * PW;
             const int Rr = Rin_lo + rr;
             const int n = fdiv(Rr, a.d_H1);
-            const int yy = Rr - n * (H + 1) - 1;
+            const int yy = Rr - n * (H + 1) - PAD;
             const int xx = x0 + cc;
-            valid = slot < HS && yy >= 0 && n < a.N && xx >= 0 && xx < W;
+            valid = slot < HS && yy >= 0 && yy < H && n < a.N && xx >= 0 && xx < W;
             off = ((long long)(n * H + yy) * W + xx) * row_bytes;
         } else {
             const int i = i0 + slot;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         const int lp = (part ^ ((slot >> 2) & 3)) * 16;
         xo[j] = valid ? (unsigned)(off + lp) : 0xffffffffu;
     }
-    if constexpr (KS == 3) {
+    if constexpr (KS != 1) {
 #pragma unroll
         for (int j = 0; j < XL; ++j) issue_x(j, 0, 0);
 #pragma unroll
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     for (int ni = 0; ni < NI; ++ni) {
         const int i = i0 + (wave_p * NI + ni) * 32 + l31;
         const int ii = (i < a.total_i) ? i : i0;
-        if constexpr (KS == 3) {
+        if constexpr (KS != 1) {
             const int r = fdiv(ii, a.d_TWt);
             const int tx = ii - r * TWt;
             const int n = fdiv(r, a.d_Ho);
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    if constexpr (KS == 3) wait_vmcnt<(WR - 2) * WL>();
+    if constexpr (KS != 1) wait_vmcnt<(WR - 2) * WL>();
     else wait_vmcnt<(R1 - 2) * (WL + XL)>();
     __builtin_amdgcn_s_barrier();
     STAMP(1);
@@ -256,13 +257,13 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     constexpr int NM = 2 * MI * NI;                     // MFMA "steps" per phase (one 16-byte operand pair each)
     auto phase = [&](auto shift_c, int c, int q, int gp) {
         constexpr int SHIFT = decltype(shift_c)::value;
-        const int nx = (KS == 3) ? (q < XL ? 1 : 0) : XL;          // input DMAs of this phase
+        const int nx = (KS != 1) ? (q < XL ? 1 : 0) : XL;          // input DMAs of this phase
         const int nd = nx + WL;
         const int stride = (NM - SHIFT) / (nd > 0 ? nd : 1) > 0 ? (NM - SHIFT) / (nd > 0 ? nd : 1) : 1;
         auto issue_item = [&](int k) {
             __builtin_amdgcn_sched_barrier(0);
             if (k < nx) {
-                if constexpr (KS == 3) issue_x(q, c + 1, (c + 1) & 1);
+                if constexpr (KS != 1) issue_x(q, c + 1, (c + 1) & 1);
                 else issue_x(k, gp + R1 - 1, (gp + R1 - 1) % R1);
             } else {
                 issue_w1(gp + WR - 1, k - nx);
@@ -270,11 +271,11 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
             __builtin_amdgcn_sched_barrier(0);
         };
         const char* Wl = smem + W_OFF + (gp % WR) * W_STAGE;
-        const char* Xl = smem + ((KS == 3) ? (c & 1) : (gp % R1)) * X_STAGE;
+        const char* Xl = smem + ((KS != 1) ? (c & 1) : (gp % R1)) * X_STAGE;
         int bx[NI];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-            const int slot = (KS == 3) ? slot00[ni] + (q / 3) * PW + (q % 3) : slot00[ni];
+            const int slot = (KS != 1) ? slot00[ni] + (q / KS) * PW + (q % KS) : slot00[ni];
             bx[ni] = slot * 64 + ((h ^ ((slot >> 2) & 3)) << 4);
         }
 #pragma unroll
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         }
         // phase gp+1's data must have landed: everything except what this phase issued for gp+2 (the
         // input DMAs are issued before the weight DMAs, so leaving WL outstanding covers them too)
-        if constexpr (KS == 3) wait_vmcnt<(WR - 2) * WL>();
+        if constexpr (KS != 1) wait_vmcnt<(WR - 2) * WL>();
         else wait_vmcnt<(R1 - 2) * (WL + XL)>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);      // keep the next phase's address math out of this phase (VGPR pressure)
@@ -319,11 +320,13 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     for (int ni = 0; ni < NI; ++ni) {
         const int i = i0 + (wave_p * NI + ni) * 32 + l31;
         int n, pix;
-        if constexpr (KS == 3) {
+        if constexpr (KS != 1) {
             const int r = fdiv(min(i, a.total_i - 1), a.d_TWt);
             const int tx = min(i, a.total_i - 1) - r * TWt;
             n = fdiv(r, a.d_Ho);
             pix = (r - n * Ho) * Wo + strip * TWt + tx;
+            // sub-pixel output: pixel (oy, ox) owns the 2x2 patch at (2 oy, 2 ox) of the (2Ho, 2Wo) map (y_ps = Cout / 4)
+            if (a.d2s) pix = (r - n * Ho) * 4 * Wo + 2 * (strip * TWt + tx);
         } else {
             n = fdiv(min(i, a.total_i - 1), a.d_HoWo);
             pix = min(i, a.total_i - 1) - n * (Ho * Wo);
@@ -345,16 +348,16 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
 template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1>
 static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     constexpr int BP = WAVES_P * NI * 32, BC = WAVES_C * MI * 32;
-    if (KS == 3) {
+    if (KS != 1) {
         int best = -1, best_hs = 1 << 30;
         for (int d = 1; d <= a.Wo; ++d) {
             if (a.Wo % d) continue;
-            const int hs = conv_halo_slots(BP, d, a.Ho, a.H, S, (long long)a.N * a.Ho);
+            const int hs = conv_halo_slots(BP, d, a.Ho, a.H, S, (long long)a.N * a.Ho, KS);
             if (hs <= XSLOTS && hs <= best_hs) { best = d; best_hs = hs; }
         }
         if (best < 0) return YOLO_EUNSUPPORTED;
         a.TWt = best;
-        a.PW = (best - 1) * S + 3;
+        a.PW = (best - 1) * S + KS;
     } else {
         a.TWt = a.Wo;
         a.PW = a.Wo;
@@ -403,6 +406,18 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
         }
         return YOLO_EUNSUPPORTED;
     }
+    if (ks == 2) {
+        // 2x2 window (yolo_conv_dgrad_s2, bf16 only): four phases per K chunk
+        if constexpr (sizeof(T) == 2) {
+            switch (algo) {
+                case 2: return launch_pipe<T, 2, 2, 4, 2, 4, 512>(a, st, nm);    // 256 px x 256 cout
+                case 6: return launch_pipe<T, 2, 2, 4, 2, 3, 384>(a, st, nm);    // 192 px x 256 cout
+                case 10: return launch_pipe<T, 2, 2, 4, 2, 2, 384>(a, st, nm);   // 128 px x 256 cout
+                case 4: return launch_pipe<T, 2, 2, 2, 2, 2, 256>(a, st, nm);    // 128 px x 128 cout, 4 waves
+            }
+        }
+        return YOLO_EUNSUPPORTED;
+    }
     if (ks == 3) {
         switch (algo) {
             case 2: return launch_pipe<T, 3, 2, 4, 2, 4, 512>(a, st, nm);
@@ -429,7 +444,8 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
 }
 
 int conv_pipe_dispatch(ConvArgs& a, int ks, int stride, int dtype, int algo, hipStream_t st, const NameOut* nm) {
-    if ((ks != 1 && ks != 3) || (stride != 1 && !(ks == 3 && stride == 2))) return YOLO_EUNSUPPORTED;
+    if ((ks != 1 && ks != 2 && ks != 3) || (stride != 1 && !(ks == 3 && stride == 2))) return YOLO_EUNSUPPORTED;
+    if (a.d2s && ks != 2) return YOLO_EUNSUPPORTED;
     if ((a.Cin * elem_size(dtype)) % 64) return YOLO_EUNSUPPORTED;
     if (ks == 1 && a.nchunks < 2) return YOLO_EUNSUPPORTED;     // a 1x1 needs >= 2 phases; a 3x3 has 9 per chunk
     if ((long long)a.N * a.H * a.W * a.Cin * elem_size(dtype) >= 0xffffff00LL) return YOLO_EUNSUPPORTED;

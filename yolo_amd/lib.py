@@ -12,6 +12,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('YOLO_AMD_LIB') or os.path.join(CSRC, 'libyolo_amd.so')   # override: experiment builds
 
 F32, BF16 = 0, 1
+OK, EINVAL, EUNSUPPORTED = 0, -1, -2
 
 
 class YoloError(RuntimeError):
@@ -60,6 +61,8 @@ SIGNATURES = {
     'yolo_nms_from_scores': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'yolo_nms': (_i, [_vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'yolo_pack_conv_weights_dgrad': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'yolo_pack_conv_weights_dgrad_s2': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'yolo_conv_dgrad_s2': (_i, [C.POINTER(ConvDesc), _vp]),
     'yolo_pack_batch_blocks': (_ll, [_i, _i, _i, _i]),
     'yolo_pack_conv_weights_batch': (_i, [_vp, _vp, _i, _ll, _i, _vp]),
     'yolo_bn_train_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _f, _f, _i, _vp]),

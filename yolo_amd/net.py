@@ -157,23 +157,25 @@ class CarNet(object):
             plan.act[c.name] = (out, (N, ho, wo, c.cout))
         return out, (N, ho, wo, c.cout)
 
-    def _measure_algo(self, d, iters=5):
+    def _measure_algo(self, d, iters=5, fn=None, algos=None):
         """Fastest conv variant for this layer shape (cached).  Outputs are overwritten while timing,
-        which is harmless: the plan has not run yet."""
+        which is harmless: the plan has not run yet.  fn / algos: another entry point taking the same descriptor
+        (yolo_conv_dgrad_s2, with d.ksize = 2 as the cache key's mark) and its variant ids; 1 = none ran."""
         key = (d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.out_f32, bool(d.residual), d.dtype)
         if key in self._algo_cache:
             return self._algo_cache[key]
         lib, st = self._lib, L.stream_ptr()
+        fn = fn or lib.yolo_conv_fwd
 
         def time_algo(algo, n):
             d.algo = algo
-            if lib.yolo_conv_fwd(C.byref(d), st) != 0:
+            if fn(C.byref(d), st) != 0:
                 return None
-            lib.yolo_conv_fwd(C.byref(d), st)
+            fn(C.byref(d), st)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(n):
-                lib.yolo_conv_fwd(C.byref(d), st)
+                fn(C.byref(d), st)
             e1.record()
             e1.synchronize()
             return e0.elapsed_time(e1) / n
@@ -181,7 +183,7 @@ class CarNet(object):
         # two passes: a short one over every variant, then the three fastest again with 4x the launches -- a single
         # short timing is noisy enough (DVFS, neighbours' tails) to pick a variant that is 5 % slower
         top, mult = 3, 4
-        first = [(t, a) for a in self.ALGOS for t in [time_algo(a, iters)] if t is not None]
+        first = [(t, a) for a in (algos or self.ALGOS) for t in [time_algo(a, iters)] if t is not None]
         first.sort()
         best, best_t = 1, float('inf')
         for _, algo in first[:top]:

@@ -7,6 +7,7 @@ kernels re-used for the data gradient on flipped weights); torch owns memory, th
 process group only.  One process per GPU; BN statistics stay local to the GPU (no SyncBN,
 car/YOLO.py:94-96).
 """
+import os
 import ctypes as C
 
 import numpy as np
@@ -75,6 +76,7 @@ class Trainer(object):
         self.buckets = parallel.GradBuckets(self.gflat, names, offs, sizes, nbuckets=4)
         net._prepared = {}
         self._prep = {}
+        self._prep_s2 = {}          # conv name -> (sub-pixel dgrad weight image, ones, zeros); see _dgrad
         self._plans = {}
         self._dgrad_algo = {}
         cmax = max(c.cout for c in g.convs())
@@ -104,6 +106,15 @@ class Trainer(object):
                 first.append(first[-1] + lib.yolo_pack_batch_blocks(c.cout, c.cin, c.k, self.ldt))
                 recs.append((w.data_ptr(), wd.data_ptr(), c.cin, c.cout, c.k, 1))
                 first.append(first[-1] + lib.yolo_pack_batch_blocks(c.cin, c.cout, c.k, self.ldt))
+                if (c.k == 3 and c.stride == 2 and self.ldt == L.BF16 and c.cin % 8 == 0 and c.cout % 32 == 0
+                        and not os.environ.get('YOLO_TRAIN_DILATED_DGRAD')):      # (the knob keeps the old form for A/B runs)
+                    # sub-pixel data gradient (yolo_conv_dgrad_s2): 2x2-window image with 4 x Cin_f output channels
+                    w2 = torch.empty(lib.yolo_packed_weight_bytes(4 * c.cin, c.cout, 2, self.ldt), dtype=torch.uint8, device=self.dev)
+                    cp4 = lib.yolo_padded_channels(4 * c.cin)
+                    ones4 = torch.zeros(cp4, dtype=torch.float32, device=self.dev); ones4[:4 * c.cin] = 1.0
+                    self._prep_s2[c.name] = (w2, ones4, torch.zeros(cp4, dtype=torch.float32, device=self.dev))
+                    recs.append((w.data_ptr(), w2.data_ptr(), 4 * c.cin, c.cout, 2, 2))
+                    first.append(first[-1] + lib.yolo_pack_batch_blocks(4 * c.cin, c.cout, 2, self.ldt))
             items = np.array(recs, dtype=items.dtype)
             self._pack_items = torch.from_numpy(items.view(np.uint8).copy()).to(self.dev)
             self._pack_first = torch.tensor(first, dtype=torch.int64, device=self.dev)
@@ -255,6 +266,33 @@ class Trainer(object):
         lib, st = self.lib, L.stream_ptr()
         wp, wd, ones, bias, zeros = self._prep[c.name]
         N, Hh, Ww, Cx = xin.shape
+        s2 = self._prep_s2.get(c.name) if c.stride == 2 else None
+        if s2 is not None and Hh == 2 * dy_shape[1] and Ww == 2 * dy_shape[2] and cin_of_dy == c.cout:
+            # sub-pixel form: one 2x2-window conv over dy writes the four phases of dx (no dilated copy, 16/36 of the MFMAs)
+            if not xin.ready:
+                out, resid = torch.empty(xin.shape, dtype=self.tdt, device=self.dev), None
+            else:
+                out, resid = xin.grad, xin.grad
+            d = self._conv_desc(dy, dy_shape, s2[0], s2[1], s2[2], out, cin_of_dy, 4 * Cx, 2, 1, residual=resid)
+            rc = None
+            if getattr(self.net, 'tune', None) == 'measure':
+                key = ('s2', dy_shape, cin_of_dy, Cx, resid is not None)
+                if key not in self._dgrad_algo:
+                    scratch = torch.zeros(xin.shape, dtype=self.tdt, device=self.dev)
+                    dm = self._conv_desc(dy, dy_shape, s2[0], s2[1], s2[2], scratch, cin_of_dy, 4 * Cx, 2, 1,
+                                         residual=scratch if resid is not None else None)
+                    self._dgrad_algo[key] = self.net._measure_algo(dm, fn=lib.yolo_conv_dgrad_s2, algos=(2, 6, 10, 4))
+                d.algo = self._dgrad_algo[key]
+                if d.algo == 1:
+                    rc = L.EUNSUPPORTED
+            if rc is None:
+                rc = lib.yolo_conv_dgrad_s2(C.byref(d), st)
+            if rc == 0:
+                xin.grad, xin.ready = out, True
+                return
+            if rc != L.EUNSUPPORTED:
+                L.check(rc, 'dgrad_s2 ' + c.name)
+            del self._prep_s2[c.name]              # no variant fits this shape: the dilated form from now on
         if c.stride == 2:
             dil = torch.empty((N, Hh, Ww, cin_of_dy), dtype=self.tdt, device=self.dev)
             L.check(lib.yolo_dilate2x(L.ptr(dy), L.ptr(dil), N, Hh, Ww, dy_shape[1], dy_shape[2], cin_of_dy, self.ldt, st), 'dilate')
