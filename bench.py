@@ -102,7 +102,8 @@ def bench_train(args, spec, size, B, rank, world, dev, dist):
     bucket all-reduced over RCCL (one exchange per step), identical Adam on every rank."""
     from yolo_amd.net import CarNet
     from yolo_amd.train import Trainer
-    net = CarNet(spec, dtype=args.dtype, device=dev, tune='measure', tune_cache=args.tune_cache).initialize(seed=1234)
+    net = CarNet(spec, dtype=args.dtype, device=dev, tune='measure', tune_cache=args.tune_cache,
+                 fuse_stem=not args.no_fuse_stem).initialize(seed=1234)
     tr = Trainer(net, size)
     gen = torch.Generator(device='cpu').manual_seed(100 + rank)
     x = torch.rand((B, 3) + size, generator=gen).to(dev)
@@ -160,6 +161,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-fuse-stem', action='store_true', help='run the stem and the first down-sampling conv as two kernels (A/B)')
     ap.add_argument('--tune-cache', default=None, help='JSON file remembering the measured per-layer kernel choices')
     ap.add_argument('--post', default='top1', choices=['top1', 'nms'],
                     help="post-processing inside the timed step: 'top1' = the reference's predict (decode + per-image arg-max);"
@@ -192,7 +194,8 @@ def main():
     B = args.batch or (64 if args.mode == 'train' else 32)
     if args.mode == 'train':
         return bench_train(args, spec, size, B, rank, world, dev, dist)
-    net = CarNet(spec, dtype=args.dtype, device=dev, tune='measure', tune_cache=args.tune_cache).initialize(seed=1234)
+    net = CarNet(spec, dtype=args.dtype, device=dev, tune='measure', tune_cache=args.tune_cache,
+                 fuse_stem=not args.no_fuse_stem).initialize(seed=1234)
     net.prepare()
     det = Detector(spec, size, net.graph.steps(), device=dev)
     gen = torch.Generator(device='cpu').manual_seed(100 + rank)

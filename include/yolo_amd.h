@@ -95,6 +95,15 @@ int yolo_stem_conv_fwd(const float* x_nchw, const float* w_oihw, const float* sc
                        void* y, int N, int H, int W, int Cin, int Cout, int dtype, float slope,
                        void* stream);
 
+/* The first TWO layers fused for inference: the stem above and the first stage's down-sampling _conv2d (basic_yolo.py:24,
+ * Conv3x3 s2 p1, C1 -> C2) + folded BN + LeakyReLU -> y (N,(H-1)/2+1,(W-1)/2+1,C2) bf16 NHWC; the full-resolution
+ * C1-channel map between them stays in LDS.  w1_oihw (C1,3,3,3) float32; w2_packed = yolo_pack_conv_weights image of
+ * the (C2,C1,3,3) conv.  Bit-identical to yolo_stem_conv_fwd followed by yolo_conv_fwd.  C1 == 32, C2 == 64 and
+ * YOLO_BF16 only (YOLO_EUNSUPPORTED otherwise: run the two layers separately). */
+int yolo_stem_down_fwd(const float* x_nchw, const float* w1_oihw, const float* scale1, const float* bias1,
+                       const void* w2_packed, const float* scale2, const float* bias2, void* y, int N, int H, int W,
+                       int C1, int C2, int dtype, float slope, void* stream);
+
 /* Synthetic-target compositing of RenderCar.render (car/render_car.py:135-137): out = clip((bg / 255) * (1 - mask) +
  * fg * mask, 0, 1) over n float32 elements (n % 4 == 0; (B,3,H,W) tensors: bg 0..255, fg and mask 0..1). */
 int yolo_composite(const float* bg, const float* fg, const float* mask, float* out, long long n, void* stream);

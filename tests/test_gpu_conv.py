@@ -167,3 +167,60 @@ def test_conv_stream_rejects_ineligible(lib, cuda):
     x, w, scale, bias, r = _mk(case, 8)
     run_conv(lib, cuda, x, w, scale, bias, 1, 0.1, 'bf16', algo=13, expect_rc=-2)
     run_conv(lib, cuda, x[:, :64], w[:, :64], scale, bias, 1, 0.1, 'f32', algo=13, expect_rc=-2)
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 96), (1, 37, 61), (3, 8, 8), (1, 200, 250), (2, 24, 248), (1, 2, 2), (5, 33, 130)])
+def test_stem_down_fused_is_bit_identical(lib, cuda, shape):
+    """yolo_stem_down_fwd (stem 3->32 + first down-sampling conv 32->64 in one kernel, the 32-channel map kept in LDS)
+    against the two separate kernels it replaces: same operand / accumulation order and rounding points, so the outputs
+    must be bit-identical -- odd sizes, strips at the 62-pixel limit, several row slices, and against the oracle."""
+    import ctypes as C
+    import torch
+    from yolo_amd import lib as L
+    N, H, W = shape
+    rng = np.random.default_rng(11)
+    x = rng.random((N, 3, H, W)).astype(np.float32)
+    w1 = (rng.standard_normal((32, 3, 3, 3)) / 5).astype(np.float32)
+    w2 = (rng.standard_normal((64, 32, 3, 3)) / 17).astype(np.float32)
+    s1, b1 = rng.uniform(0.5, 1.5, 32).astype(np.float32), rng.uniform(-0.5, 0.5, 32).astype(np.float32)
+    s2, b2 = rng.uniform(0.5, 1.5, 64).astype(np.float32), rng.uniform(-0.5, 0.5, 64).astype(np.float32)
+    st = torch.cuda.current_stream().cuda_stream
+    dev = cuda
+    xd = torch.from_numpy(x).to(dev)
+    w1d, w2d = torch.from_numpy(w1).to(dev), torch.from_numpy(w2).to(dev)
+    wp2 = torch.empty(lib.yolo_packed_weight_bytes(64, 32, 3, L.BF16), dtype=torch.uint8, device=dev)
+    assert lib.yolo_pack_conv_weights(w2d.data_ptr(), wp2.data_ptr(), 64, 32, 3, L.BF16, st) == 0
+    pad = lambda v: torch.cat([torch.from_numpy(v), torch.zeros(lib.yolo_padded_channels(len(v)) - len(v))]).to(dev)
+    s1d, b1d, s2d, b2d = pad(s1), pad(b1), pad(s2), pad(b2)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    # the two-kernel path
+    mid = torch.empty((N, H, W, 32), dtype=torch.bfloat16, device=dev)
+    assert lib.yolo_stem_conv_fwd(xd.data_ptr(), w1d.data_ptr(), s1d.data_ptr(), b1d.data_ptr(), mid.data_ptr(), N, H, W, 3, 32,
+                                  L.BF16, 0.1, st) == 0
+    two = torch.full((N, Ho, Wo, 64), float('nan'), dtype=torch.bfloat16, device=dev)
+    d = L.ConvDesc()
+    d.x, d.w_packed, d.scale, d.bias, d.y = mid.data_ptr(), wp2.data_ptr(), s2d.data_ptr(), b2d.data_ptr(), two.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.dtype, d.slope = N, H, W, 32, 64, 3, 2, L.BF16, 0.1
+    assert lib.yolo_conv_fwd(C.byref(d), st) == 0
+    one = torch.full((N, Ho, Wo, 64), float('nan'), dtype=torch.bfloat16, device=dev)
+    assert lib.yolo_stem_down_fwd(xd.data_ptr(), w1d.data_ptr(), s1d.data_ptr(), b1d.data_ptr(), wp2.data_ptr(), s2d.data_ptr(),
+                                  b2d.data_ptr(), one.data_ptr(), N, H, W, 32, 64, L.BF16, 0.1, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(one.view(torch.int16), two.view(torch.int16))
+    # and the oracle of the pair (rounding-aware)
+    r1 = ref_conv(x, w1, s1, b1, 1, 0.1, bf16=True)
+    r2 = ref_conv(r1, w2, s2, b2, 2, 0.1, bf16=True)
+    got = one.float().permute(0, 3, 1, 2).cpu().numpy()
+    np.testing.assert_allclose(got, r2, rtol=2e-2, atol=2e-2 * np.abs(r2).max())
+
+
+def test_stem_down_rejects(lib, cuda):
+    import torch
+    from yolo_amd import lib as L
+    b = torch.zeros(4096, device=cuda)
+    p = b.data_ptr()
+    args = lambda c1, c2, dt, slope: (p, p, p, p, p, p, p, p, 1, 8, 8, c1, c2, dt, slope, None)
+    assert lib.yolo_stem_down_fwd(*args(16, 64, L.BF16, 0.1)) == L.EUNSUPPORTED
+    assert lib.yolo_stem_down_fwd(*args(32, 128, L.BF16, 0.1)) == L.EUNSUPPORTED
+    assert lib.yolo_stem_down_fwd(*args(32, 64, L.F32, 0.1)) == L.EUNSUPPORTED
+    assert lib.yolo_stem_down_fwd(*args(32, 64, L.BF16, 1.5)) == L.EINVAL

@@ -236,3 +236,20 @@ def test_rejects_sizes_the_pyramid_cannot_merge(cuda):
         net(torch.rand((1, 3, 72, 96), device=cuda))             # 72 is not a multiple of 32
     with pytest.raises(ValueError):
         net(torch.rand((1, 3, 64, 96), device=cuda).double())
+
+
+def test_fused_stem_matches_unfused(cuda):
+    """CarNet(fuse_stem=True) (default) runs the stem and the first down-sampling conv as one kernel on the D53 spec;
+    the logits must be bit-identical to the layer-by-layer plan."""
+    from yolo_amd.net import CarNet
+    from yolo_amd.spec import darknet53_spec
+    x = torch.rand((2, 3, 224, 288), device=cuda)
+    outs = []
+    for fuse in (True, False):
+        net = CarNet(darknet53_spec(), dtype='bf16', device=cuda, fuse_stem=fuse).initialize(5)
+        o = net(x)
+        kinds = [op[0] for op in net._last_plan.ops]
+        assert ('stem_down' in kinds) == fuse and ('stem' in kinds) == (not fuse)
+        outs.append([t.clone() for t in o])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -34,7 +34,8 @@ class _Plan(object):
 class CarNet(object):
     ALGOS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18)     # yolo_conv_desc.algo ids tried by tune='measure'
 
-    def __init__(self, spec, num_sync_bn_devices=-1, dtype='bf16', device='cuda:0', tune='auto', tune_cache=None):
+    def __init__(self, spec, num_sync_bn_devices=-1, dtype='bf16', device='cuda:0', tune='auto', tune_cache=None,
+                 fuse_stem=True):
         # num_sync_bn_devices is accepted for signature parity; the reference always passes -1
         # (no SyncBN, car/YOLO.py:94-96).
         if dtype not in _TORCH_DT:
@@ -47,6 +48,9 @@ class CarNet(object):
         if tune not in ('auto', 'measure'):
             raise ValueError("tune must be 'auto' or 'measure'")
         self.tune = tune
+        # fuse_stem: run the stem and the first down-sampling conv as one kernel where yolo_stem_down_fwd takes the
+        # shape (32 -> 64, bf16); the stem's own output is then not materialised (no 'stem' parity tap)
+        self.fuse_stem = bool(fuse_stem)
         self._algo_cache = {}
         # optional JSON file remembering measured choices (so a profiled run launches only the chosen kernels)
         self._tune_cache = tune_cache
@@ -201,7 +205,23 @@ class CarNet(object):
         g = self.graph
         plan = _Plan()
         tdt = _TORCH_DT[self.dtype]
-        if g.stem.cin == 3 and g.stem.cout % 4 == 0 and g.stem.cout <= 64 and self.dtype == 'bf16':
+        fused_down = None
+        d0 = g.stages[0][0] if g.stages else None
+        if (self.fuse_stem and self.dtype == 'bf16' and d0 is not None and g.stem.cin == 3 and g.stem.k == 3
+                and g.stem.stride == 1 and g.stem.bn and (g.stem.cout, d0.cin, d0.cout, d0.k, d0.stride, d0.bn) == (32, 32, 64, 3, 2, True)):
+            # stem + first down-sampling conv in one kernel (yolo_stem_down_fwd): the 32-channel full-resolution map
+            # between them never reaches HBM
+            _, s1, b1 = self._prepared[g.stem.name]
+            wp2, s2, b2 = self._prepared[d0.name]
+            ho, wo = d0.out_hw(H, W)
+            x = torch.empty((B, ho, wo, d0.cout), dtype=tdt, device=self.device)
+            shp = (B, ho, wo, d0.cout)
+            plan.buffers.append(x)
+            plan.ops.append(('stem_down', (L.ptr(self.params[g.stem.name + '.weight']), L.ptr(s1), L.ptr(b1), L.ptr(wp2),
+                                           L.ptr(s2), L.ptr(b2), L.ptr(x), B, H, W, g.stem.cout, d0.cout), d0.name))
+            plan.act[d0.name] = (x, shp)
+            fused_down = d0
+        elif g.stem.cin == 3 and g.stem.cout % 4 == 0 and g.stem.cout <= 64 and self.dtype == 'bf16':
             # fused image-layout change + first conv (yolo_stem_conv_fwd): reads the NCHW image directly
             _, sscale, sbias = self._prepared[g.stem.name]
             x = torch.empty((B, H, W, g.stem.cout), dtype=tdt, device=self.device)
@@ -216,7 +236,8 @@ class CarNet(object):
         routes = []
         nst = len(g.stages)
         for i, (down, res) in enumerate(g.stages):
-            x, shp = self._conv_op(plan, down, x, shp)
+            if down is not fused_down:
+                x, shp = self._conv_op(plan, down, x, shp)
             for c1, c2 in res:
                 mid, mshp = self._conv_op(plan, c1, x, shp)
                 x, shp = self._conv_op(plan, c2, mid, mshp, residual=x)
@@ -300,6 +321,9 @@ class CarNet(object):
         if kind == 'stem':
             w, sc, bi, y, B, H, W, cin, cout = payload
             return lib.yolo_stem_conv_fwd(x.data_ptr(), w, sc, bi, y, B, H, W, cin, cout, dt, LEAKY_SLOPE, st)
+        if kind == 'stem_down':
+            w1, s1, b1, wp2, s2, b2, y, B, H, W, c1, c2 = payload
+            return lib.yolo_stem_down_fwd(x.data_ptr(), w1, s1, b1, wp2, s2, b2, y, B, H, W, c1, c2, dt, LEAKY_SLOPE, st)
         return lib.yolo_upsample2x_concat(*payload, dt, st)
 
     def plan_kernels(self, B, H, W):
@@ -317,6 +341,12 @@ class CarNet(object):
             if kind == 'stem':
                 c = by_name[name]
                 out.append((name, 'stem_conv_kernel', 2 * c.cin * 9 * c.cout * payload[4] * payload[5] * payload[6]))
+                continue
+            if kind == 'stem_down':
+                B_, H_, W_ = payload[7], payload[8], payload[9]
+                c = by_name[name]
+                ho, wo = c.out_hw(H_, W_)
+                out.append((name, 'stem_down_kernel', 2 * 3 * 9 * payload[10] * B_ * H_ * W_ + 2 * c.cin * 9 * c.cout * ho * wo * B_))
                 continue
             if kind != 'conv':
                 out.append((name, kind, 0))
