@@ -83,6 +83,10 @@ class Trainer(object):
         self.ws = torch.zeros(3 * cmax, dtype=torch.float64, device=self.dev)
         wsb = max(self.lib.yolo_conv_wgrad_workspace_bytes(max(c.cin, 8), c.cout, c.k, self.ldt) for c in g.convs())
         self.wg_ws = torch.zeros(max(wsb, 16), dtype=torch.uint8, device=self.dev)       # (kept zeroed by the library)
+        # weight gradients run on a side stream: they are off the backward pass's critical path (dy -> data gradient ->
+        # previous layer's BN backward) and MFMA-bound, while the BN passes they overlap are HBM-bound
+        self._side = torch.cuda.Stream(device=self.dev)
+        self._overlap = not os.environ.get('YOLO_TRAIN_SERIAL_WGRAD')          # (the knob keeps the serial order for A/B runs)
         self._repack()
 
     # ---- weight images for the forward and data-gradient convolutions (re-packed after every update) ----
@@ -317,11 +321,41 @@ class Trainer(object):
         L.check(lib.yolo_conv_fwd(C.byref(d), st), 'dgrad ' + c.name)
         xin.grad, xin.ready = out, True
 
+    def _wgrad(self, dy, names, launch):
+        """Run launch(stream) -- a weight-gradient call reading dy, which the current stream has just produced -- on the
+        side stream (all of them, in order: they share one workspace).  The gradient buckets hear about `names` one
+        layer later, once the current stream has been made to wait for that layer's side-stream work."""
+        main = torch.cuda.current_stream()
+        if not self._overlap:
+            launch(main.cuda_stream)
+            self.buckets.done(names)
+            return
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self._side.wait_event(ready)
+        if isinstance(dy, torch.Tensor):
+            dy.record_stream(self._side)
+        with torch.cuda.stream(self._side):
+            launch(self._side.cuda_stream)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        self._flush_wgrad()
+        self._pending_wgrad = (names, done)
+
+    def _flush_wgrad(self):
+        if self._pending_wgrad is not None:
+            names, done = self._pending_wgrad
+            self._pending_wgrad = None
+            if self.buckets.active():
+                torch.cuda.current_stream().wait_event(done)
+                self.buckets.done(names)
+
     def _backward(self, P, exchange=True):
         lib, st = self.lib, L.stream_ptr()
         g = self.net.graph
         self.gflat.zero_()
         self.buckets.reset(enabled=exchange)
+        self._pending_wgrad = None
         for op in P.fwd:
             for k in ('x', 'z', 'up', 'route', 'cat', 'res'):
                 t = op.get(k)
@@ -337,10 +371,10 @@ class Trainer(object):
                 L.check(lib.yolo_gather_rows(src, L.ptr(op['dyp']), B, hw, c.cout, cpad, src_bs, src_ps, self.ldt, st), 'gather')
                 L.check(lib.yolo_bias_grad(L.ptr(op['dyp']), L.ptr(self.gview[c.name + '.bias']), B * hw, c.cout, cpad, self.ldt, st), 'db')
                 N, Hh, Ww, Cx = xin.shape
-                L.check(lib.yolo_conv_wgrad(L.ptr(op['dyp']), L.ptr(xin.val), L.ptr(self.gview[c.name + '.weight']),
-                                            N, Hh, Ww, Cx, c.cout, 1, 1, cpad, self.ldt, L.ptr(self.wg_ws), st), 'wgrad out')
+                self._wgrad(op['dyp'], [c.name + '.weight', c.name + '.bias'], lambda s_, c=c, op=op, xin=xin, N=N, Hh=Hh, Ww=Ww, Cx=Cx, cpad=cpad: L.check(
+                    lib.yolo_conv_wgrad(L.ptr(op['dyp']), L.ptr(xin.val), L.ptr(self.gview[c.name + '.weight']),
+                                        N, Hh, Ww, Cx, c.cout, 1, 1, cpad, self.ldt, L.ptr(self.wg_ws), s_), 'wgrad out'))
                 self._dgrad(c, op['dyp'], (N, Hh, Ww, cpad), xin, cpad)
-                self.buckets.done([c.name + '.weight', c.name + '.bias'])
             elif kind == 'upcat':
                 up, r, cat = op['up'], op['route'], op['cat']
                 if not up.ready:
@@ -364,16 +398,23 @@ class Trainer(object):
                 if op['res'] is not None:
                     self._accum(op['res'], dz)          # the residual branch receives dz unchanged
                 N, Hh, Ww, Cx = xin.shape
+                names = [c.name + '.weight', c.name + '.gamma', c.name + '.beta']
                 if c is g.stem:
-                    dw8 = torch.zeros((c.cout, 8, 3, 3), dtype=torch.float32, device=self.dev)
-                    L.check(lib.yolo_conv_wgrad(L.ptr(dy), L.ptr(xin.val), L.ptr(dw8), N, Hh, Ww, 8, c.cout, 3, 1, 0, self.ldt,
-                                                L.ptr(self.wg_ws), st), 'wgrad stem')
-                    self.gview[c.name + '.weight'].copy_(dw8[:, :3])
+                    def stem_wgrad(s_, c=c, dy=dy, xin=xin, N=N, Hh=Hh, Ww=Ww):
+                        # (torch ops below run on the stream _wgrad has made current)
+                        dw8 = torch.zeros((c.cout, 8, 3, 3), dtype=torch.float32, device=self.dev)
+                        L.check(lib.yolo_conv_wgrad(L.ptr(dy), L.ptr(xin.val), L.ptr(dw8), N, Hh, Ww, 8, c.cout, 3, 1, 0, self.ldt,
+                                                    L.ptr(self.wg_ws), s_), 'wgrad stem')
+                        self.gview[c.name + '.weight'].copy_(dw8[:, :3])
+                    self._wgrad(dy, names, stem_wgrad)
                 else:
-                    L.check(lib.yolo_conv_wgrad(L.ptr(dy), L.ptr(xin.val), L.ptr(self.gview[c.name + '.weight']), N, Hh, Ww,
-                                                Cx, c.cout, c.k, c.stride, 0, self.ldt, L.ptr(self.wg_ws), st), 'wgrad ' + c.name)
+                    self._wgrad(dy, names, lambda s_, c=c, dy=dy, xin=xin, N=N, Hh=Hh, Ww=Ww, Cx=Cx: L.check(
+                        lib.yolo_conv_wgrad(L.ptr(dy), L.ptr(xin.val), L.ptr(self.gview[c.name + '.weight']), N, Hh, Ww,
+                                            Cx, c.cout, c.k, c.stride, 0, self.ldt, L.ptr(self.wg_ws), s_), 'wgrad ' + c.name))
                     self._dgrad(c, dy, y.shape, xin, c.cout)
-                self.buckets.done([c.name + '.weight', c.name + '.gamma', c.name + '.beta'])
+        self._flush_wgrad()
+        if self._overlap:
+            torch.cuda.current_stream().wait_stream(self._side)
 
     # ---- one training step -----------------------------------------------------------------------------------
     def train_step(self, images, labels, global_batch=None, update=True, lp_labels=None):
