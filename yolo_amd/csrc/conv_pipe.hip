@@ -79,7 +79,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // they are interleaved between the MFMAs, and the second half of the waves (which shares SIMDs with
 // the first half) issues them at shifted positions, so a wave stuck in a DMA issue is covered by its
 // SIMD partner's MFMAs.
-template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1>
+template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1, int RD = 0>
 __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvArgs a) {
     constexpr int PT = 1;
     constexpr int NW = WAVES_P * WAVES_C;
@@ -102,7 +102,11 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     constexpr int EPI1_ = WAVES_P * WAVES_C * YOLO_EPI_WAVE_BYTES;
     constexpr int L13_ = 3 * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) > EPI1_ ? 3 * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) : EPI1_;
     constexpr int L1N_ = YOLO_RING1 * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) > EPI1_ ? YOLO_RING1 * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) : EPI1_;
-    constexpr int R1 = (L1N_ <= 163840 && 163840 / L1N_ == 163840 / L13_) ? YOLO_RING1 : 3;
+    // RD != 0 (1x1 only): an explicit ring depth.  The small-map 1x1 layers are bound by the latency of their loads (a
+    // 64 x 128 tile has 12 KB per phase: 32 phases of K = 1024 took ~1000 cycles each with 3 phases in flight), so
+    // some variants trade co-resident blocks for a deeper ring.
+    constexpr int R1 = RD ? RD : ((L1N_ <= 163840 && 163840 / L1N_ == 163840 / L13_) ? YOLO_RING1 : 3);
+    static_assert(RD == 0 || KS == 1, "explicit ring depth: 1x1 only");
     constexpr int XBUFS = (KS != 1) ? 2 : R1;
     static_assert(KS != 1 || XSLOTS == BP, "1x1: one slot per pixel");
     constexpr int PAD = KS / 2 - (KS == 2 ? 1 : 0);          // 3x3: 1; 2x2 (sub-pixel data gradient) and 1x1: 0
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1>
+template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1, int RD = 0>
 static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     constexpr int BP = WAVES_P * NI * 32, BC = WAVES_C * MI * 32;
     if (KS != 1) {
@@ -372,11 +376,11 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
     conv_args_fastdiv(a);
     if (name) {
-        snprintf(name->buf, name->len, "void conv_pipe_kernel<%s, %d, %d, %d, %d, %d, %d, %d>(ConvArgs)",
-                 sizeof(T) == 2 ? "bf16_t" : "float", KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S);
+        snprintf(name->buf, name->len, "void conv_pipe_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d>(ConvArgs)",
+                 sizeof(T) == 2 ? "bf16_t" : "float", KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD);
         return YOLO_OK;
     }
-    YOLO_LAUNCH((conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S>), dim3((unsigned)grid),
+    YOLO_LAUNCH((conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD>), dim3((unsigned)grid),
                 dim3(WAVES_P * WAVES_C * 64), 0, st, a);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
@@ -438,6 +442,10 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
             case 8: return launch_pipe<T, 1, 2, 2, 2, 3, 192>(a, st, nm);
             case 11: return launch_pipe<T, 1, 2, 2, 2, 1, 64>(a, st, nm);
             case 12: return launch_pipe<T, 1, 1, 4, 2, 2, 64>(a, st, nm);
+            // deep-ring variants (one block per CU, 5-7 phases of loads in flight)
+            case 19: return launch_pipe<T, 1, 1, 4, 2, 2, 64, 1, 7>(a, st, nm);      // 64 px x 256 cout
+            case 20: return launch_pipe<T, 1, 2, 2, 2, 1, 64, 1, 8>(a, st, nm);      // 64 px x 128 cout
+            case 21: return launch_pipe<T, 1, 2, 2, 2, 2, 128, 1, 6>(a, st, nm);     // 128 px x 128 cout
         }
     }
     return YOLO_EUNSUPPORTED;
