@@ -204,8 +204,8 @@ def main():
     def step():
         outs = net(x)
         if args.post == 'nms':
-            rows = det.decode(outs)
-            kept, ks, cnt = det.nms(rows, mode='class')
+            rows, scores = det.decode_scores(outs, mode='class')
+            kept, ks, cnt = det.nms(rows, mode='class', scores=scores)
             return kept, cnt
         return det.predict_device(outs)
 

@@ -166,6 +166,10 @@ long long yolo_nms_workspace_bytes(int B, int nbox, int ncls, int mode, int topk
  * chip-wide passes over all images instead of one block per image (same result; ~6x faster at 608x608). */
 long long yolo_nms_select_workspace_bytes(int B);
 int yolo_nms_scores(const float* rows, float* scores, int B, int nbox, int C, int mode, void* stream);
+/* yolo_decode + yolo_nms_scores in one pass over the logits (the logits are read once; bit-identical results):
+ * out (B,N,A,C) -> rows (B,nbox,C) and scores as above. */
+int yolo_decode_scores(const float* out, float* rows, float* scores, int B, int C, const yolo_grid_desc* g, int mode,
+                       void* stream);
 int yolo_nms_from_scores(const float* rows, const float* scores, int B, int nbox, int C,
                          int cand_per_box, float valid_thresh, float iou_thresh, int topk,
                          int post_nms, int* kept, float* kept_scores, int* kept_count,

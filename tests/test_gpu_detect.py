@@ -182,3 +182,21 @@ def test_nms_list_overflow_falls_back(cuda):
             assert torch.equal(x, y)
         rk, _ = od.nms(rows[1].cpu().numpy(), mode, scores=scores[1].cpu().numpy())
         assert a[0][1, :int(a[2][1])].cpu().tolist() == rk.tolist()
+
+
+@pytest.mark.parametrize('mode', ['obj', 'class'])
+@pytest.mark.parametrize('size,B', [((416, 416), 3), ((608, 608), 2), ((320, 512), 1)])
+def test_decode_scores_fused_is_bit_identical(cuda, mode, size, B):
+    """yolo_decode_scores (one pass over the logits) against yolo_decode + yolo_nms_scores: identical bits, including a
+    last block that holds fewer than 256 boxes."""
+    det, outs, syxhw, _ = _setup(size, B, 41, cuda, scale=2.0)
+    dev = [torch.from_numpy(o).to(cuda) for o in outs]
+    rows = det.decode(dev)
+    scores = det.nms_scores(rows, mode)
+    rows2, scores2 = det.decode_scores(dev, mode)
+    assert torch.equal(rows.view(torch.int32), rows2.view(torch.int32))
+    assert torch.equal(scores.view(torch.int32), scores2.view(torch.int32))
+    a = det.nms(rows, mode, scores=scores)
+    b = det.nms(rows2, mode, scores=scores2)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)

@@ -233,6 +233,61 @@ extern "C" int yolo_nms_scores(const float* rows, float* scores, int B, int nbox
     return YOLO_OK;
 }
 
+// ---- decode + NMS scores in one pass over the logits ------------------------------------------------
+// yolo_decode followed by yolo_nms_scores reads the logits, writes the rows, reads the rows again and writes the
+// scores (665 MB at 608x608 bs 64, 380 us); here a block stages 256 boxes through LDS once (coalesced both ways), one
+// thread per box decodes its row IN the staged copy (box constants computed once per box, not once per coordinate)
+// and derives its class scores from it.  Same functions, same operation order: bit-identical to the two calls.
+__global__ __launch_bounds__(256) void decode_scores_kernel(const float* __restrict__ out, float* __restrict__ rows,
+                                                            float* __restrict__ scores, int C, int ncls, int mode,
+                                                            int nbox, long long nboxes, GridDev g) {
+    extern __shared__ float sm[];                        // 256*C floats of rows, then 256*ncls of scores
+    const long long k0 = blockIdx.x * 256LL;
+    const int nb = (int)min(256LL, nboxes - k0);
+    for (int i = threadIdx.x; i < nb * C; i += 256) sm[i] = out[k0 * C + i];
+    __syncthreads();
+    float* so = sm + 256 * C;
+    if ((int)threadIdx.x < nb) {
+        float* p = sm + threadIdx.x * C;
+        const int k = (int)((k0 + threadIdx.x) % nbox);
+        float s, y, x, h, w, l, r, t, b;
+        box_consts(g, k, s, y, x, h, w);
+        decode_axis(p[2], p[4], s, x, (float)g.img_w, w, l, r);
+        decode_axis(p[1], p[3], s, y, (float)g.img_h, h, t, b);
+        const float obj = sigmoidf_ref(p[0]);
+        p[0] = obj; p[1] = l; p[2] = t; p[3] = r; p[4] = b;
+        if (mode == 1) {
+            float m = -FLT_MAX;
+            for (int c = 0; c < ncls; ++c) m = fmaxf(m, p[6 + c]);
+            float sum = 0.f;
+            for (int c = 0; c < ncls; ++c) sum += expf(p[6 + c] - m);
+            for (int c = 0; c < ncls; ++c) so[threadIdx.x * ncls + c] = obj * (expf(p[6 + c] - m) / sum);
+        } else {
+            so[threadIdx.x] = obj;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb * C; i += 256) rows[k0 * C + i] = sm[i];
+    const int per = mode == 1 ? ncls : 1;
+    for (int i = threadIdx.x; i < nb * per; i += 256) scores[k0 * per + i] = so[i];
+}
+
+extern "C" int yolo_decode_scores(const float* out, float* rows, float* scores, int B, int C, const yolo_grid_desc* g,
+                                  int mode, void* stream) {
+    if (!out || !rows || !scores || B <= 0 || C < 6 || (mode != 0 && mode != 1)) return YOLO_EINVAL;
+    if (mode == 1 && C <= 6) return YOLO_EINVAL;
+    if (C > 96) return YOLO_EUNSUPPORTED;                      // LDS staging: 256 boxes x (C + ncls) floats
+    GridDev d; int nbox;
+    int rc = make_grid(g, d, &nbox);
+    if (rc) return rc;
+    const long long nboxes = (long long)B * nbox;
+    YOLO_LAUNCH(decode_scores_kernel, dim3((unsigned)((nboxes + 255) / 256)), dim3(256),
+                (size_t)256 * (C + (C - 6 > 1 ? C - 6 : 1)) * sizeof(float), (hipStream_t)stream, out, rows, scores, C,
+                C - 6, mode, nbox, nboxes, d);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}
+
 // ---- NMS ---------------------------------------------------------------------------------------
 // One 1024-thread block per image.
 //   1. exact top-k selection by (score desc, id asc): three histogram passes over the score bits
@@ -265,13 +320,24 @@ __global__ __launch_bounds__(256) void nms_hist_kernel(const float* __restrict__
     const float* sc = scores + (long long)b * ncand;
     const long long i0 = blockIdx.x * per_block, i1 = min(i0 + per_block, ncand);
     const unsigned q1 = pass == 1 ? sl[0] : 0;
+    // a thread counts runs of equal bins privately: scores of neighbouring candidates often share their top bits
+    // (every candidate of a random-weight net lands in two or three bins), and LDS atomics on one address serialise
+    unsigned cur = 0xffffffffu, run = 0;
     for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
         const unsigned u = __float_as_uint(sc[i]);
         if (u >= vbits && !(u & 0x80000000u)) {
-            if (pass == 0) atomicAdd(&h[u >> 21], 1u);
-            else if ((u >> 21) == q1) atomicAdd(&h[(u >> 10) & 2047u], 1u);
+            unsigned bin = 0xffffffffu;
+            if (pass == 0) bin = u >> 21;
+            else if ((u >> 21) == q1) bin = (u >> 10) & 2047u;
+            if (bin != cur) {
+                if (run) atomicAdd(&h[cur], run);
+                cur = bin;
+                run = 0;
+            }
+            if (bin != 0xffffffffu) ++run;
         }
     }
+    if (run) atomicAdd(&h[cur], run);
     __syncthreads();
     unsigned* gh = hist + ((long long)b * 2 + pass) * 2048;
     for (int i = threadIdx.x; i < 2048; i += 256)

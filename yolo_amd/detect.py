@@ -72,6 +72,17 @@ class Detector(object):
         L.check(self._lib.yolo_decode(L.ptr(m), L.ptr(rows), B, self.C, C.byref(self.grid), L.stream_ptr()), 'decode')
         return rows
 
+    def decode_scores(self, outs, mode='class'):
+        """decode() and nms_scores() in one pass over the logits -> (rows, scores); bit-identical to the two calls."""
+        m = self._merged(outs)
+        B = m.shape[0]
+        md = 1 if mode == 'class' else 0
+        rows = torch.empty((B, self.nbox, self.C), dtype=torch.float32, device=m.device)
+        scores = torch.empty((B, self.nbox * ((self.C - 6) if md else 1)), dtype=torch.float32, device=m.device)
+        L.check(self._lib.yolo_decode_scores(L.ptr(m), L.ptr(rows), L.ptr(scores), B, self.C, C.byref(self.grid), md,
+                                             L.stream_ptr()), 'decode_scores')
+        return rows, scores
+
     def predict_device(self, outs):
         m = self._merged(outs)
         B = m.shape[0]

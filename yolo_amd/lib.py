@@ -52,6 +52,7 @@ SIGNATURES = {
     'yolo_composite': (_i, [_vp, _vp, _vp, _vp, _ll, _vp]),
     'yolo_upsample2x_concat': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'yolo_decode': (_i, [_vp, _vp, _i, _i, C.POINTER(GridDesc), _vp]),
+    'yolo_decode_scores': (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(GridDesc), _i, _vp]),
     'yolo_predict_top1': (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(GridDesc), _vp]),
     'yolo_predict_lp': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp]),
     'yolo_predict_lp_nhwc': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp]),
