@@ -44,16 +44,25 @@ template <> __device__ __forceinline__ void store1<bf16_t>(bf16_t* p, float v) {
 // must be zero on first use; the finalize / parameter-gradient kernels zero it again after reading (no memset
 // launch per call).
 // ------------------------------------------------------------------------------------------------
+// channels a block of the REDUCTION covers (the apply pass covers all C): wide layers are cut into 256-channel groups
+// (blockIdx.y), so that the number of blocks does not have to shrink with C to bound the atomics (C = 2048 over the
+// 13x13 maps ran on 64 blocks at 0.65 TB/s)
+constexpr int BN_CG = 256;
+
 static void bn_partition(long long npix, int C, int elem, bool reduces, int* ppb, unsigned* nb) {
-    long long p = 32768 / ((long long)C * elem);               // ~32 KB of one tensor per block ...
+    const int cb = (reduces && C > BN_CG) ? BN_CG : C;          // channels per block
+    // (measured over the training step: 64 KB per block beats 32 / 128 KB by 0.3 / 0.4 ms; twice / four times the atomics
+    // budget costs 0.6 / 1.3 ms, half of it changes nothing)
+    const long long kBytes = 65536, kAtom = 131072, kMaxb = 2048;
+    long long p = kBytes / ((long long)cb * elem);              // ~64 KB of one tensor per block ...
     if (p < 16) p = 16;
-    // ... and a bounded number of blocks: every block of the reduction ends with 2C double atomics, which
-    // dominate the small deep layers (C = 1024 over 5408 pixels) unless the block count shrinks with C
-    long long maxb = 2048;
+    // ... and a bounded number of blocks: every block of the reduction ends with 2*cb double atomics; their total
+    // (2C per pixel range) dominates the small deep layers unless the number of pixel ranges shrinks with C
+    long long maxb = kMaxb;
     if (reduces) {
-        maxb = 65536 / C;
+        maxb = kAtom / C;
         if (maxb < 64) maxb = 64;
-        if (maxb > 2048) maxb = 2048;
+        if (maxb > kMaxb) maxb = kMaxb;
     }
     if ((npix + p - 1) / p > maxb) p = (npix + maxb - 1) / maxb;
     *ppb = (int)p;
@@ -71,11 +80,13 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ y,
     constexpr int U = MODE == 0 ? 8 : 4;
     __shared__ float red[2][256][8];
     const int noct = C >> 3;
-    const int per = noct < 256 ? noct : 256;                    // octets handled per batch
+    const int goct = BN_CG / 8;                                 // octets of a channel group
+    const int per = noct < goct ? noct : goct;                  // octets handled by this block
     const int lanes = 256 / per;                                // pixel lanes per octet in this block
     const long long p0 = (long long)blockIdx.x * pix_per_block;
     const long long p1 = min(p0 + pix_per_block, npix);
-    for (int ob = 0; ob < noct; ob += 256) {                    // octet batches (C > 2048 only)
+    {
+        const int ob = blockIdx.y * goct;                       // first octet of this block's channel group
         const int oct = ob + (threadIdx.x % per);
         const int pl = threadIdx.x / per;
         float s[8], q[8];
@@ -240,7 +251,7 @@ static int bn_fwd_t(const T* y, const float* gamma, const float* beta, const T* 
     int ppb, ppa; unsigned nb, na;
     bn_partition(npix, C, (int)sizeof(T), true, &ppb, &nb);
     bn_partition(npix, C, (int)sizeof(T), false, &ppa, &na);
-    YOLO_LAUNCH((bn_reduce_kernel<T, 0>), dim3(nb), dim3(256), 0, st, y, (const T*)nullptr, (const float*)nullptr,
+    YOLO_LAUNCH((bn_reduce_kernel<T, 0>), dim3(nb, (C + BN_CG - 1) / BN_CG), dim3(256), 0, st, y, (const T*)nullptr, (const float*)nullptr,
                 (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, workspace, C, npix, ppb, slope);
     YOLO_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, mean, invstd, running_mean,
                 running_var, C, 1.0 / (double)npix, eps, momentum);
@@ -273,7 +284,7 @@ static int bn_bwd_t(const T* dz, const T* y, const float* mean, const float* inv
     int ppb, ppa; unsigned nb, na;
     bn_partition(npix, C, (int)sizeof(T), true, &ppb, &nb);
     bn_partition(npix, C, (int)sizeof(T), false, &ppa, &na);
-    YOLO_LAUNCH((bn_reduce_kernel<T, 1>), dim3(nb), dim3(256), 0, st, y, dz, mean, invstd, gamma, beta, workspace, C,
+    YOLO_LAUNCH((bn_reduce_kernel<T, 1>), dim3(nb, (C + BN_CG - 1) / BN_CG), dim3(256), 0, st, y, dz, mean, invstd, gamma, beta, workspace, C,
                 npix, ppb, slope);
     YOLO_LAUNCH(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, dgamma, dbeta, C);
     YOLO_LAUNCH((bn_apply_kernel<T, 1>), dim3(na), dim3(256), 0, st, y, dz, mean, invstd, gamma, beta,
