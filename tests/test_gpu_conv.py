@@ -82,11 +82,11 @@ PIPE_CASES = [
 ]
 
 
-@pytest.mark.parametrize('algo', [2, 3, 4, 5, 6, 7, 8, 11, 12, 19, 20, 21])
+@pytest.mark.parametrize('algo', [2, 3, 4, 5, 6, 7, 8, 11, 12, 19, 20, 21, 22, 23, 24, 25])
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('case', PIPE_CASES)
 def test_conv_pipe(lib, cuda, case, dtype, algo):
-    if (algo in (6, 7) and case[5] != 3) or (algo in (12, 19, 20, 21) and case[5] != 1):
+    if (algo in (6, 7) and case[5] != 3) or (algo in (12, 19, 20, 21, 22, 23, 24, 25) and case[5] != 1):
         pytest.skip('variant not defined for this kernel size')
     x, w, scale, bias, r = _mk(case, 4)
     y = run_conv(lib, cuda, x, w, scale, bias, case[6], 0.1, dtype, residual=r, algo=algo)

@@ -79,7 +79,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // they are interleaved between the MFMAs, and the second half of the waves (which shares SIMDs with
 // the first half) issues them at shifted positions, so a wave stuck in a DMA issue is covered by its
 // SIMD partner's MFMAs.
-template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1, int RD = 0>
+template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1, int RD = 0, int KC = 1>
 __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvArgs a) {
     constexpr int PT = 1;
     constexpr int NW = WAVES_P * WAVES_C;
@@ -89,19 +89,27 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     constexpr int NTAP = KS * KS;
     constexpr int PPC = NTAP / PT;                       // phases per K-chunk
     static_assert(NTAP % PT == 0 && (KS != 1 || PT == 1), "phase shape");
-    constexpr int W_STAGE = PT * BC * 64;                // bytes per weight ring slot
-    constexpr int WL = W_STAGE / (NT * 16);              // LDS-DMAs per thread per phase (weights)
-    static_assert(W_STAGE % (NT * 16) == 0, "weight stage must be whole DMAs");
-    constexpr int X_STAGE = XSLOTS * 64;
-    constexpr int XL = X_STAGE / (NT * 16);              // LDS-DMAs per thread per X tile
-    static_assert(X_STAGE % (NT * 16) == 0, "input stage must be whole DMAs");
+    // KC (1x1 only): K chunks of 32 bf16 channels per phase.  The small-map 1x1 layers spend ~600 cycles per
+    // one-chunk phase on the fixed chain barrier -> LDS reads -> 4 MFMAs -> wait; two chunks per phase halve the
+    // number of barriers for the same bytes in flight.
+    static_assert(KC == 1 || KS == 1, "several K chunks per phase: 1x1 only");
+    constexpr int W_STAGE1 = PT * BC * 64;               // bytes of one chunk's weight slab
+    constexpr int W_STAGE = KC * W_STAGE1;               // bytes per weight ring slot
+    constexpr int WL1 = W_STAGE1 / (NT * 16);
+    constexpr int WL = KC * WL1;                         // LDS-DMAs per thread per phase (weights)
+    static_assert(W_STAGE1 % (NT * 16) == 0, "weight stage must be whole DMAs");
+    constexpr int X_STAGE1 = XSLOTS * 64;
+    constexpr int X_STAGE = KC * X_STAGE1;
+    constexpr int XL1 = X_STAGE1 / (NT * 16);
+    constexpr int XL = KC * XL1;                         // LDS-DMAs per thread per X tile
+    static_assert(X_STAGE1 % (NT * 16) == 0, "input stage must be whole DMAs");
     // 1x1: depth of the X and W rings (loads run R1-1 phases ahead): 4 where that keeps the blocks per CU, else 3
 #ifndef YOLO_RING1
 #define YOLO_RING1 4
 #endif
     constexpr int EPI1_ = WAVES_P * WAVES_C * YOLO_EPI_WAVE_BYTES;
-    constexpr int L13_ = 3 * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) > EPI1_ ? 3 * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) : EPI1_;
-    constexpr int L1N_ = YOLO_RING1 * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) > EPI1_ ? YOLO_RING1 * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) : EPI1_;
+    constexpr int L13_ = 3 * KC * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) > EPI1_ ? 3 * KC * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) : EPI1_;
+    constexpr int L1N_ = YOLO_RING1 * KC * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) > EPI1_ ? YOLO_RING1 * KC * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) : EPI1_;
     // RD != 0 (1x1 only): an explicit ring depth.  The small-map 1x1 layers are bound by the latency of their loads (a
     // 64 x 128 tile has 12 KB per phase: 32 phases of K = 1024 took ~1000 cycles each with 3 phases in flight), so
     // some variants trade co-resident blocks for a deeper ring.
@@ -159,9 +167,9 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     const long long wplane = (long long)a.Cout_pad * 64;
     static_assert((BC * 4) % NT == 0 || NT % (BC * 4) == 0, "tap index must be uniform per DMA");
 
-    unsigned xo[XL];
+    unsigned xo[XL1];
     const int nchunks = a.nchunks;
-    const int nphase = nchunks * PPC;
+    const int nphase = nchunks * PPC / KC;
     const uint32_t wave_lds = lds0 + wave * 1024;        // this wave's 1 KiB lane-linear window per DMA
 
     // weights of global phase gp (clamped: the tail re-loads the last plane into a dead ring slot so
@@ -169,9 +177,10 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     // weight DMA j (of WL) of global phase gp; the tail is clamped: it re-loads the last plane into a
     // dead ring slot so every phase issues the same number of DMAs and the counted waits stay exact
     auto issue_w1 = [&](int gp, int j) {
-        const int g = min(gp, nphase - 1);
-        glds16(wsrc + (long long)g * wplane + (long long)j * NT * 16,
-               wave_lds + W_OFF + (gp % WR) * W_STAGE + j * NT * 16);
+        const int kc = j / WL1, jj = j - kc * WL1;
+        const int g = min(gp, nphase - 1) * KC + kc;
+        glds16(wsrc + (long long)g * wplane + (long long)jj * NT * 16,
+               wave_lds + W_OFF + (gp % WR) * W_STAGE + kc * W_STAGE1 + jj * NT * 16);
     };
     auto issue_w = [&](int gp) {
 #pragma unroll
@@ -179,9 +188,10 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     };
     // input DMA j of chunk c into X buffer `buf`
     auto issue_x = [&](int j, int c, int buf) {
-        const int cc = min(c, nchunks - 1);
-        const char* src = (xo[j] != 0xffffffffu) ? a.x + ((size_t)xo[j] + (size_t)cc * 64) : (const char*)yolo_zero_page;
-        glds16(src, wave_lds + buf * X_STAGE + j * NT * 16);
+        const int kc = j / XL1, jj = j - kc * XL1;
+        const int cc = (KS != 1) ? min(c, nchunks - 1) : min(c, nphase - 1) * KC + kc;      // (1x1: c counts phases)
+        const char* src = (xo[jj] != 0xffffffffu) ? a.x + ((size_t)xo[jj] + (size_t)cc * 64) : (const char*)yolo_zero_page;
+        glds16(src, wave_lds + buf * X_STAGE + kc * X_STAGE1 + jj * NT * 16);
     };
     static_assert(KS == 1 || XL <= PPC, "3x3: at most one input DMA per phase");
     static_assert(BC * 4 >= NT, "one weight DMA covers rows of a single tap plane");
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     // ---- per-thread DMA sources: byte offset of the slot's 16-byte unit for chunk 0 (32-bit: the host
     //      checks the activation tensor is < 4 GiB), or ~0 for a zero-padding slot (DMA'd from the zero page)
 #pragma unroll
-    for (int j = 0; j < XL; ++j) {
+    for (int j = 0; j < XL1; ++j) {
         const int u = tid + j * NT;
         const int slot = u >> 2, part = u & 3;
         bool valid;
@@ -258,7 +268,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     __builtin_amdgcn_s_barrier();
     STAMP(1);
 
-    constexpr int NM = 2 * MI * NI;                     // MFMA "steps" per phase (one 16-byte operand pair each)
+    constexpr int NM = 2 * KC * MI * NI;                // MFMA "steps" per phase (one 16-byte operand pair each)
     auto phase = [&](auto shift_c, int c, int q, int gp) {
         constexpr int SHIFT = decltype(shift_c)::value;
         const int nx = (KS != 1) ? (q < XL ? 1 : 0) : XL;          // input DMAs of this phase
@@ -283,12 +293,13 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
             bx[ni] = slot * 64 + ((h ^ ((slot >> 2) & 3)) << 4);
         }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < 2 * KC; ++ks) {
+            const int kofw = (ks >> 1) * W_STAGE1, kofx = (ks >> 1) * X_STAGE1;     // sub-chunk of this phase (KC > 1)
             uint4 af[MI], bf[NI];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) af[mi] = *(const uint4*)(Wl + mi * 2048 + (aoff0 ^ (ks * 32)));
+            for (int mi = 0; mi < MI; ++mi) af[mi] = *(const uint4*)(Wl + kofw + mi * 2048 + (aoff0 ^ ((ks & 1) * 32)));
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) bf[ni] = *(const uint4*)(Xl + (bx[ni] ^ (ks * 32)));
+            for (int ni = 0; ni < NI; ++ni) bf[ni] = *(const uint4*)(Xl + kofx + (bx[ni] ^ ((ks & 1) * 32)));
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);      // keep the next phase's address math out of this phase (VGPR pressure)
     };
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = 0; c < nchunks / KC; ++c) {
 #pragma unroll
         for (int q = 0; q < PPC; ++q) {
             const int gp = c * PPC + q;
@@ -349,9 +360,10 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1, int RD = 0>
+template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1, int RD = 0, int KC = 1>
 static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     constexpr int BP = WAVES_P * NI * 32, BC = WAVES_C * MI * 32;
+    if (KC > 1 && (a.nchunks % KC || a.nchunks < 2 * KC)) return YOLO_EUNSUPPORTED;
     if (KS != 1) {
         int best = -1, best_hs = 1 << 30;
         for (int d = 1; d <= a.Wo; ++d) {
@@ -376,11 +388,11 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
     conv_args_fastdiv(a);
     if (name) {
-        snprintf(name->buf, name->len, "void conv_pipe_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d>(ConvArgs)",
-                 sizeof(T) == 2 ? "bf16_t" : "float", KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD);
+        snprintf(name->buf, name->len, "void conv_pipe_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %d>(ConvArgs)",
+                 sizeof(T) == 2 ? "bf16_t" : "float", KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC);
         return YOLO_OK;
     }
-    YOLO_LAUNCH((conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD>), dim3((unsigned)grid),
+    YOLO_LAUNCH((conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC>), dim3((unsigned)grid),
                 dim3(WAVES_P * WAVES_C * 64), 0, st, a);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
@@ -446,6 +458,11 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
             case 19: return launch_pipe<T, 1, 1, 4, 2, 2, 64, 1, 7>(a, st, nm);      // 64 px x 256 cout
             case 20: return launch_pipe<T, 1, 2, 2, 2, 1, 64, 1, 8>(a, st, nm);      // 64 px x 128 cout
             case 21: return launch_pipe<T, 1, 2, 2, 2, 2, 128, 1, 6>(a, st, nm);     // 128 px x 128 cout
+            // two K chunks per phase (half the barriers)
+            case 22: return launch_pipe<T, 1, 2, 2, 2, 1, 64, 1, 0, 2>(a, st, nm);   // 64 px x 128 cout
+            case 23: return launch_pipe<T, 1, 2, 2, 2, 2, 128, 1, 0, 2>(a, st, nm);  // 128 px x 128 cout
+            case 24: return launch_pipe<T, 1, 2, 2, 2, 3, 192, 1, 0, 2>(a, st, nm);  // 192 px x 128 cout
+            case 25: return launch_pipe<T, 1, 1, 4, 2, 2, 64, 1, 0, 2>(a, st, nm);   // 64 px x 256 cout
         }
     }
     return YOLO_EUNSUPPORTED;
