@@ -1,16 +1,18 @@
-// Pipelined implicit-GEMM convolution for gfx950: the fast path for 3x3 stride-1 and 1x1 layers
-// whose K-chunks are whole (Cin*sizeof(T) % 64 == 0).  Same math, data layout, packed-weight
-// image and epilogue as conv_igemm.hip (the generic path); what differs is the memory pipeline:
+// Pipelined implicit-GEMM convolution for gfx950: the fast path for 3x3 (stride 1 and 2), 1x1 and the 2x2-window
+// form of the stride-2 data gradient (yolo_conv_dgrad_s2), for layers whose K-chunks are whole
+// (Cin*sizeof(T) % 64 == 0).  Same math, data layout, packed-weight image and epilogue as conv_igemm.hip (the
+// generic path); what differs is the memory pipeline:
 //
 //   * global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR
 //     staging, no ds_write pass).  The LDS image is lane-linear, so the bank-conflict XOR swizzle
 //     is applied to the per-lane SOURCE address (weights: at pack time) and again on the read.
-//   * weights stream through a 3-deep ring, one ring slot per "phase" (PT taps of a 3x3, or one
-//     K-chunk of a 1x1); the zero-padded input halo tile is double-buffered per K-chunk and read
-//     by all 9 taps.  Loads for phase p+2 are issued at the top of phase p; the only wait is a
-//     COUNTED s_waitcnt vmcnt(N) (N = loads issued in this phase) in front of ONE raw s_barrier per
-//     phase, so DMA stays in flight across barriers.  Zero padding / image edges are DMA'd from a
-//     zero page: no predication anywhere in the main loop.
+//   * weights stream through a ring of 3-4 slots (4 wherever the extra slot does not cost a co-resident block; the
+//     1x1 variants may ask for more), one ring slot per "phase" (one tap of a 3x3 / 2x2, or KC K-chunks of a 1x1);
+//     the zero-padded input halo tile is double-buffered per K-chunk and read by all taps.  Loads run ring-depth - 1
+//     phases ahead, interleaved between the MFMAs of a phase; the only wait is a COUNTED s_waitcnt vmcnt(N)
+//     (N = loads of the phases still allowed in flight) in front of ONE raw s_barrier per phase, so DMA stays in
+//     flight across barriers.  Zero padding / image edges are DMA'd from a zero page: no predication anywhere in
+//     the main loop.
 //   * XCD-aware block order: the blocks that share an input tile (different cout tiles) are
 //     consecutive on one XCD so its L2 serves the re-reads.
 #include "common.h"
