@@ -68,7 +68,8 @@ typedef struct yolo_conv_desc {
     const void* x;         /* (N,H,W,Cin) dtype                                               */
     const void* w_packed;  /* yolo_pack_conv_weights image                                    */
     const float* scale;    /* [padded Cout] folded BN scale                                   */
-    const float* bias;     /* [padded Cout] folded BN bias / conv bias                        */
+    const float* bias;     /* [padded Cout] folded BN bias / conv bias; scale and bias both NULL =
+                              identity epilogue: y = conv(x) (+ residual), slope ignored       */
     const void* residual;  /* (N,Ho,Wo,Cout) dtype or NULL; added after the activation        */
     void* y;               /* (N,Ho,Wo,Cout) dtype, or float32 when out_f32                   */
     int N, H, W, Cin, Cout;

@@ -224,3 +224,45 @@ def test_stem_down_rejects(lib, cuda):
     assert lib.yolo_stem_down_fwd(*args(32, 128, L.BF16, 0.1)) == L.EUNSUPPORTED
     assert lib.yolo_stem_down_fwd(*args(32, 64, L.F32, 0.1)) == L.EUNSUPPORTED
     assert lib.yolo_stem_down_fwd(*args(32, 64, L.BF16, 1.5)) == L.EINVAL
+
+
+@pytest.mark.parametrize('case,algo', [((2, 128, 26, 26, 256, 3, 1, True), 0), ((2, 128, 26, 26, 256, 3, 1, True), 4),
+                                       ((3, 256, 13, 13, 88, 1, 1, False), 1), ((2, 64, 40, 40, 128, 3, 1, True), 13),
+                                       ((2, 64, 26, 26, 128, 3, 2, False), 0), ((1, 256, 13, 13, 512, 1, 1, True), 11)])
+@pytest.mark.parametrize('dtype', ['bf16', 'f32'])
+def test_identity_epilogue(lib, cuda, case, algo, dtype):
+    """scale == bias == NULL (the training step's raw convolutions / data gradients): bit-identical to scale 1, bias 0,
+    slope 1 through every epilogue path; exactly one of the two NULL is an argument error."""
+    import ctypes as C
+    import torch
+    from yolo_amd import lib as L
+    from util import to_nhwc, LDT, TDT
+    N, Cin, H, W, Cout, k, stride, with_res = case
+    if algo == 13 and dtype != 'bf16':
+        pytest.skip('the streaming kernel is bf16 only')
+    x, w, _, _, r = _mk(case, 21)
+    st = torch.cuda.current_stream().cuda_stream
+    dt = LDT[dtype]
+    xd = to_nhwc(x, dtype, cuda)
+    wp = torch.empty(lib.yolo_packed_weight_bytes(Cout, Cin, k, dt), dtype=torch.uint8, device=cuda)
+    L.check(lib.yolo_pack_conv_weights(torch.from_numpy(w).to(cuda).data_ptr(), wp.data_ptr(), Cout, Cin, k, dt, st), 'pack')
+    cp = lib.yolo_padded_channels(Cout)
+    ones, zeros = torch.ones(cp, device=cuda), torch.zeros(cp, device=cuda)
+    rd = to_nhwc(r, dtype, cuda) if r is not None else None
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    outs = []
+    for sc, bi in ((ones.data_ptr(), zeros.data_ptr()), (None, None)):
+        y = torch.full((N, Ho, Wo, Cout), float('nan'), dtype=TDT[dtype], device=cuda)
+        d = L.ConvDesc()
+        d.x, d.w_packed, d.scale, d.bias, d.y = xd.data_ptr(), wp.data_ptr(), sc, bi, y.data_ptr()
+        d.residual = rd.data_ptr() if rd is not None else None
+        d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.dtype, d.slope, d.algo = N, H, W, Cin, Cout, k, stride, dt, 1.0, algo
+        assert lib.yolo_conv_fwd(C.byref(d), st) == 0
+        outs.append(y)
+    torch.cuda.synchronize()
+    it = torch.int16 if dtype == 'bf16' else torch.int32
+    assert not torch.isnan(outs[1].float()).any()
+    assert torch.equal(outs[0].view(it), outs[1].view(it))
+    d.scale = ones.data_ptr()
+    assert lib.yolo_conv_fwd(C.byref(d), st) == L.EINVAL

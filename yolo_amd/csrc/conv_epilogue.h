@@ -29,6 +29,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
     static_assert(32 * RS + 2 * 32 * 8 <= YOLO_EPI_WAVE_BYTES, "scratch size");
     const int l31 = lane & 31, h = lane >> 5;
     const float slope = a.slope;
+    // scale == bias == nullptr: identity epilogue (the training step's raw convolutions and data gradients: BN and the
+    // activation are separate passes there) -- skips two loads and three VALU operations per output
+    const bool ident = a.scale == nullptr;
 
     if (a.out_f32 && a.res == nullptr && (a.Cout % 2) == 0 && (a.y_ps % 2) == 0 && (a.y_bs % 2) == 0 &&
         ((size_t)a.y % 8) == 0) {
@@ -39,7 +42,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
         const int col2 = lane % LPR2, rowa = lane / LPR2;
         const int co2 = co_w + col2 * 2;
         const bool ok2 = co2 < a.Cout;
-        const float sc0 = a.scale[co2], sc1 = a.scale[co2 + 1], bi0 = a.bias[co2], bi1 = a.bias[co2 + 1];
+        const float sc0 = ident ? 1.f : a.scale[co2], sc1 = ident ? 1.f : a.scale[co2 + 1];
+        const float bi0 = ident ? 0.f : a.bias[co2], bi1 = ident ? 0.f : a.bias[co2 + 1];
         long long* ytab2 = (long long*)(wsm + 32 * RS);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
@@ -57,8 +61,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                 const long long yo2 = ok2 ? ytab2[row] : -1;
                 const float2 t2 = *(const float2*)(wsm + row * RS + col2 * 8);
                 float2 o2;
-                o2.x = leaky(t2.x * sc0 + bi0, slope);
-                o2.y = leaky(t2.y * sc1 + bi1, slope);
+                o2.x = ident ? t2.x : leaky(t2.x * sc0 + bi0, slope);
+                o2.y = ident ? t2.y : leaky(t2.y * sc1 + bi1, slope);
                 if (yo2 >= 0) *(float2*)(a.y + (yo2 + co2) * 4) = o2;
             }
         }
@@ -75,14 +79,14 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                 for (int g = 0; g < 4; ++g) {
                     const int co = co_w + mi * 32 + 8 * g + 4 * h;
                     if (co >= a.Cout) continue;
-                    const f32x4 sc = *(const f32x4*)(a.scale + co);
-                    const f32x4 bi = *(const f32x4*)(a.bias + co);
+                    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+                    if (!ident) { sc = *(const f32x4*)(a.scale + co); bi = *(const f32x4*)(a.bias + co); }
                     const long long o = yoff[ni] + co;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (co + e >= a.Cout) continue;
-                        float t = acc[mi][ni][4 * g + e] * sc[e] + bi[e];
-                        t = leaky(t, slope);
+                        float t = acc[mi][ni][4 * g + e];
+                        if (!ident) t = leaky(t * sc[e] + bi[e], slope);
                         if (a.out_f32) {
                             ((float*)a.y)[o + e] = t;
                         } else if constexpr (ES == 2) {
@@ -115,8 +119,11 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
     float sc[CPL], bi[CPL];
 #pragma unroll
     for (int q = 0; q < CPL / 4; ++q) {
-        const f32x4 s4 = *(const f32x4*)(a.scale + co + 4 * q);     // arrays are padded to the cout tile
-        const f32x4 b4 = *(const f32x4*)(a.bias + co + 4 * q);
+        f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+        if (!ident) {
+            s4 = *(const f32x4*)(a.scale + co + 4 * q);     // arrays are padded to the cout tile
+            b4 = *(const f32x4*)(a.bias + co + 4 * q);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { sc[4 * q + e] = s4[e]; bi[4 * q + e] = b4[e]; }
     }
@@ -160,10 +167,12 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[4 * q + e] = t4[e];
             }
+            if (!ident) {
 #pragma unroll
-            for (int e = 0; e < CPL; ++e) {
-                const float t = v[e] * sc[e] + bi[e];
-                v[e] = leaky(t, slope);
+                for (int e = 0; e < CPL; ++e) {
+                    const float t = v[e] * sc[e] + bi[e];
+                    v[e] = leaky(t, slope);
+                }
             }
             uint4 ov;
             if constexpr (ES == 2) {

@@ -331,7 +331,7 @@ extern "C" int yolo_conv_kernel_name(const yolo_conv_desc* d, char* buf, int len
 }
 
 static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* nm) {
-    if (!d || !d->x || !d->w_packed || !d->scale || !d->bias || !d->y) return YOLO_EINVAL;
+    if (!d || !d->x || !d->w_packed || !d->y || (!d->scale != !d->bias)) return YOLO_EINVAL;      // (both NULL: identity epilogue)
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return YOLO_EINVAL;
     if (d->ksize != 1 && d->ksize != 3) return YOLO_EUNSUPPORTED;
     if (d->stride != 1 && d->stride != 2) return YOLO_EUNSUPPORTED;
@@ -391,7 +391,7 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
 // epilogue stores depth-to-space.  Even H/W of dx only (2H x 2W); bf16; pipelined variants only -- callers fall back
 // to yolo_dilate2x + yolo_conv_fwd on YOLO_EUNSUPPORTED.
 extern "C" int yolo_conv_dgrad_s2(const yolo_conv_desc* d, void* stream) {
-    if (!d || !d->x || !d->w_packed || !d->scale || !d->bias || !d->y) return YOLO_EINVAL;
+    if (!d || !d->x || !d->w_packed || !d->y || (!d->scale != !d->bias)) return YOLO_EINVAL;      // (both NULL: identity epilogue)
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->algo < 0) return YOLO_EINVAL;
     if (!(d->slope >= 0.f && d->slope <= 1.f)) return YOLO_EINVAL;
     if (d->dtype != YOLO_BF16 || d->out_f32 || d->y_pixel_stride || d->y_batch_stride) return YOLO_EUNSUPPORTED;

@@ -76,10 +76,11 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
     const int ecol = lane & 3, erow0 = lane >> 2;
     const int eco = wave_c * 32 + ecol * 8;
     float sc[8], bi[8];
+    const bool ident = a.scale == nullptr;               // identity epilogue (conv_epilogue.h)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const f32x4 s4 = *(const f32x4*)(a.scale + eco + 4 * q);
-        const f32x4 b4 = *(const f32x4*)(a.bias + eco + 4 * q);
+        f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+        if (!ident) { s4 = *(const f32x4*)(a.scale + eco + 4 * q); b4 = *(const f32x4*)(a.bias + eco + 4 * q); }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { sc[4 * q + e] = s4[e]; bi[4 * q + e] = b4[e]; }
     }
@@ -182,10 +183,12 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[4 * q + e] = t4[e];
                 }
+                if (!ident) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float t = v[e] * sc[e] + bi[e];
-                    v[e] = leaky(t, slope);
+                    for (int e = 0; e < 8; ++e) {
+                        const float t = v[e] * sc[e] + bi[e];
+                        v[e] = leaky(t, slope);
+                    }
                 }
                 if (has_res) {
                     const uint32_t w[4] = {rv[ni][k].x, rv[ni][k].y, rv[ni][k].z, rv[ni][k].w};

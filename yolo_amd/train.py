@@ -87,6 +87,7 @@ class Trainer(object):
         # previous layer's BN backward) and MFMA-bound, while the BN passes they overlap are HBM-bound
         self._side = torch.cuda.Stream(device=self.dev)
         self._overlap = not os.environ.get('YOLO_TRAIN_SERIAL_WGRAD')          # (the knob keeps the serial order for A/B runs)
+        self._identity = not os.environ.get('YOLO_TRAIN_UNIT_EPILOGUE')        # (the knob: scale 1 / bias 0 arrays instead of the identity epilogue)
         self._repack()
 
     # ---- weight images for the forward and data-gradient convolutions (re-packed after every update) ----
@@ -162,7 +163,8 @@ class Trainer(object):
             mean = torch.empty(c.cout, dtype=torch.float32, device=self.dev)
             invstd = torch.empty_like(mean)
             wp, wd, ones, bias, zeros = self._prep[c.name]
-            d = self._conv_desc(xin.val, xin.shape, wp, ones, zeros, yraw.val, Cc, c.cout, c.k, c.stride)
+            ident = (None, None) if self._identity else (ones, zeros)     # raw convolution: identity epilogue
+            d = self._conv_desc(xin.val, xin.shape, wp, ident[0], ident[1], yraw.val, Cc, c.cout, c.k, c.stride)
             self._tune(d)
             P.fwd.append(dict(kind='conv_bn', c=c, x=xin, yraw=yraw, z=z, mean=mean, invstd=invstd, res=residual, desc=d))
             return z
@@ -277,13 +279,14 @@ class Trainer(object):
                 out, resid = torch.empty(xin.shape, dtype=self.tdt, device=self.dev), None
             else:
                 out, resid = xin.grad, xin.grad
-            d = self._conv_desc(dy, dy_shape, s2[0], s2[1], s2[2], out, cin_of_dy, 4 * Cx, 2, 1, residual=resid)
+            sb = (None, None) if self._identity else (s2[1], s2[2])
+            d = self._conv_desc(dy, dy_shape, s2[0], sb[0], sb[1], out, cin_of_dy, 4 * Cx, 2, 1, residual=resid)
             rc = None
             if getattr(self.net, 'tune', None) == 'measure':
                 key = ('s2', dy_shape, cin_of_dy, Cx, resid is not None)
                 if key not in self._dgrad_algo:
                     scratch = torch.zeros(xin.shape, dtype=self.tdt, device=self.dev)
-                    dm = self._conv_desc(dy, dy_shape, s2[0], s2[1], s2[2], scratch, cin_of_dy, 4 * Cx, 2, 1,
+                    dm = self._conv_desc(dy, dy_shape, s2[0], sb[0], sb[1], scratch, cin_of_dy, 4 * Cx, 2, 1,
                                          residual=scratch if resid is not None else None)
                     self._dgrad_algo[key] = self.net._measure_algo(dm, fn=lib.yolo_conv_dgrad_s2, algos=(2, 6, 10, 4))
                 d.algo = self._dgrad_algo[key]
@@ -308,6 +311,8 @@ class Trainer(object):
             resid = None
         else:
             out, resid = xin.grad, xin.grad
+        if self._identity:
+            ones = zeros = None
         d = self._conv_desc(src, sshape, wd, ones, zeros, out, cin_of_dy, Cx, c.k, 1, residual=resid)
         if getattr(self.net, 'tune', None) == 'measure':
             key = (sshape, cin_of_dy, Cx, c.k, resid is not None)
