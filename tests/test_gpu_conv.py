@@ -266,3 +266,16 @@ def test_identity_epilogue(lib, cuda, case, algo, dtype):
     assert torch.equal(outs[0].view(it), outs[1].view(it))
     d.scale = ones.data_ptr()
     assert lib.yolo_conv_fwd(C.byref(d), st) == L.EINVAL
+
+
+@pytest.mark.parametrize('algo', [2, 3, 4, 5, 8, 11, 12])
+@pytest.mark.parametrize('cin', [64, 96, 128])
+def test_conv_pipe_1x1_short_k(lib, cuda, algo, cin):
+    """1x1 variants on K extents below four phases (bf16: 2-3 chunks of 32 channels) take the generic K loop instead of
+    the lean one, and exactly four phases is the lean loop's shortest case (its whole body is the tail)."""
+    case = (2, cin, 13, 13, 128, 1, 1, True)
+    x, w, scale, bias, r = _mk(case, 5)
+    y = run_conv(lib, cuda, x, w, scale, bias, 1, 0.1, 'bf16', residual=r, algo=algo)
+    ref = ref_conv(x, w, scale, bias, 1, 0.1, residual=r, bf16=True)
+    assert not np.isnan(y).any()
+    np.testing.assert_allclose(y, ref, rtol=1.6e-2, atol=2e-2)

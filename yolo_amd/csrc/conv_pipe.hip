@@ -47,6 +47,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst_unifor
                  : "v"(gsrc), "s"(lds_dst_uniform)
                  : "memory");
 }
+// The same without saving / restoring m0 (the lean loops: nothing the compiler emits for gfx950 in these kernels reads
+// m0 -- LDS instructions have not needed it since GFX9 -- and the generic form's save + restore is two of the four
+// scalar instructions of every DMA).
+__device__ __forceinline__ void glds16_m0(const void* gsrc, uint32_t lds_dst_uniform) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -81,7 +87,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // they are interleaved between the MFMAs, and the second half of the waves (which shares SIMDs with
 // the first half) issues them at shifted positions, so a wave stuck in a DMA issue is covered by its
 // SIMD partner's MFMAs.
-template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1, int RD = 0, int KC = 1>
+template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1, int RD = 0, int KC = 1, int LEAN = 0>
 __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvArgs a) {
     constexpr int PT = 1;
     constexpr int NW = WAVES_P * WAVES_C;
@@ -320,12 +326,97 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);      // keep the next phase's address math out of this phase (VGPR pressure)
     };
+    if constexpr (KS == 1 && LEAN) {
+        // ---- lean 1x1 K loop.  With one or two waves per SIMD (the small maps: 340 blocks of a 64 x 128 tile at 13x13)
+        //      a wave issues an instruction every ~4 cycles and nothing fills the gaps, so the ~75 instructions of a
+        //      generic phase -- ring-slot modulo, 64-bit source address multiply-adds, zero-page selects, m0 save / restore
+        //      per DMA -- cost more than its 4 MFMAs (128 cycles).  Here the loop is unrolled by the ring depth (every
+        //      LDS offset is an immediate), DMA sources are pointers advanced by one add per phase, and m0 is written
+        //      once per DMA. ------------------------------------------------------------------------------------------
+        static_assert(PPC == 1, "1x1");
+        const char* wq[WL];                                  // source of weight DMA j for the NEXT phase to issue
+        const char* xq[XL];
+        unsigned xinc[XL1];                                  // 64 * KC for a pixel row, 0 for the zero page
+        {
+            const int g0 = (R1 - 1) * KC;                    // the prologue issued phases 0 .. R1-2
+#pragma unroll
+            for (int j = 0; j < WL; ++j) {
+                const int kc = j / WL1, jj = j - kc * WL1;
+                wq[j] = wsrc + (long long)(g0 + kc) * wplane + (long long)jj * NT * 16;
+            }
+#pragma unroll
+            for (int j = 0; j < XL; ++j) {
+                const int kc = j / XL1, jj = j - kc * XL1;
+                const bool ok = xo[jj] != 0xffffffffu;
+                xq[j] = ok ? a.x + ((size_t)xo[jj] + (size_t)(g0 + kc) * 64) : (const char*)yolo_zero_page;
+                if (kc == 0) xinc[jj] = ok ? 64u * KC : 0u;
+            }
+        }
+        const long long winc = (long long)KC * wplane;
+        auto lean_phase = [&](auto slot_c, int gp) {
+            constexpr int U = decltype(slot_c)::value;       // ring slot read in this phase; (U + R1 - 1) % R1 is written
+            constexpr int UW = (U + R1 - 1) % R1;
+            const char* Wl = smem + W_OFF + U * W_STAGE;
+            const char* Xl = smem + U * X_STAGE;
+            int bx[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bx[ni] = slot00[ni] * 64 + ((h ^ ((slot00[ni] >> 2) & 3)) << 4);
+            constexpr int ND = XL + WL;
+            constexpr int STRIDE = (NM - 1) / ND > 0 ? (NM - 1) / ND : 1;
+#pragma unroll
+            for (int ks = 0; ks < 2 * KC; ++ks) {
+                const int kofw = (ks >> 1) * W_STAGE1, kofx = (ks >> 1) * X_STAGE1;
+                uint4 af[MI], bf[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) af[mi] = *(const uint4*)(Wl + kofw + mi * 2048 + (aoff0 ^ ((ks & 1) * 32)));
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) bf[ni] = *(const uint4*)(Xl + kofx + (bx[ni] ^ ((ks & 1) * 32)));
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        FragP<T>::mma(af[mi], bf[ni], acc[mi][ni]);
+                        const int m = (ks * MI + mi) * NI + ni;
+#pragma unroll
+                        for (int k = 0; k < ND; ++k)
+                            if (m == (1 + k * STRIDE < NM - 1 ? 1 + k * STRIDE : NM - 1)) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (k < XL) {
+                                    const int kc = k / XL1, jj = k - kc * XL1;
+                                    glds16_m0(xq[k], wave_lds + UW * X_STAGE + kc * X_STAGE1 + jj * NT * 16);
+                                } else {
+                                    const int j = k - XL, kc = j / WL1, jj = j - kc * WL1;
+                                    glds16_m0(wq[j], wave_lds + W_OFF + UW * W_STAGE + kc * W_STAGE1 + jj * NT * 16);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                    }
+            }
+            if (gp + R1 < nphase) {                          // (tail: the pointers stay on the last phase -> dead reloads)
+#pragma unroll
+                for (int j = 0; j < WL; ++j) wq[j] += winc;
+#pragma unroll
+                for (int j = 0; j < XL; ++j) xq[j] += xinc[j % XL1];
+            }
+            wait_vmcnt<(R1 - 2) * (WL + XL)>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int gp = 0; gp < nphase; gp += R1) {
+            if constexpr (R1 > 0) { lean_phase(std::integral_constant<int, 0>{}, gp); }
+            if constexpr (R1 > 1) { if (gp + 1 < nphase) lean_phase(std::integral_constant<int, 1 % R1>{}, gp + 1); }
+            if constexpr (R1 > 2) { if (gp + 2 < nphase) lean_phase(std::integral_constant<int, 2 % R1>{}, gp + 2); }
+            if constexpr (R1 > 3) { if (gp + 3 < nphase) lean_phase(std::integral_constant<int, 3 % R1>{}, gp + 3); }
+            static_assert(R1 <= 4, "lean loop: ring depth <= 4");
+        }
+    } else {
     for (int c = 0; c < nchunks / KC; ++c) {
 #pragma unroll
         for (int q = 0; q < PPC; ++q) {
             const int gp = c * PPC + q;
             phase(std::integral_constant<int, 1>{}, c, q, gp);
         }
+    }
     }
     STAMP(2);
     wait_vmcnt<0>();     // the tail's dead DMAs must land before the block's LDS is released
@@ -362,10 +453,11 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1, int RD = 0, int KC = 1>
+template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1, int RD = 0, int KC = 1, int LEAN = 0>
 static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     constexpr int BP = WAVES_P * NI * 32, BC = WAVES_C * MI * 32;
     if (KC > 1 && (a.nchunks % KC || a.nchunks < 2 * KC)) return YOLO_EUNSUPPORTED;
+    if (LEAN && a.nchunks / KC < 4) return YOLO_EUNSUPPORTED;       // the lean loop starts after a full ring of phases
     if (KS != 1) {
         int best = -1, best_hs = 1 << 30;
         for (int d = 1; d <= a.Wo; ++d) {
@@ -390,11 +482,11 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
     conv_args_fastdiv(a);
     if (name) {
-        snprintf(name->buf, name->len, "void conv_pipe_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %d>(ConvArgs)",
-                 sizeof(T) == 2 ? "bf16_t" : "float", KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC);
+        snprintf(name->buf, name->len, "void conv_pipe_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d>(ConvArgs)",
+                 sizeof(T) == 2 ? "bf16_t" : "float", KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC, LEAN);
         return YOLO_OK;
     }
-    YOLO_LAUNCH((conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC>), dim3((unsigned)grid),
+    YOLO_LAUNCH((conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC, LEAN>), dim3((unsigned)grid),
                 dim3(WAVES_P * WAVES_C * 64), 0, st, a);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
@@ -449,22 +541,31 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
         }
     } else {
         switch (algo) {
-            case 2: return launch_pipe<T, 1, 2, 4, 2, 4, 256>(a, st, nm);
-            case 3: return launch_pipe<T, 1, 4, 2, 2, 2, 256>(a, st, nm);
-            case 4: return launch_pipe<T, 1, 2, 2, 2, 2, 128>(a, st, nm);
-            case 5: return launch_pipe<T, 1, 1, 8, 1, 4, 128>(a, st, nm);
-            case 8: return launch_pipe<T, 1, 2, 2, 2, 3, 192>(a, st, nm);
-            case 11: return launch_pipe<T, 1, 2, 2, 2, 1, 64>(a, st, nm);
-            case 12: return launch_pipe<T, 1, 1, 4, 2, 2, 64>(a, st, nm);
-            // deep-ring variants (one block per CU, 5-7 phases of loads in flight)
+            // 1x1: the lean K loop wherever the K extent allows it (>= 4 phases), the generic loop otherwise
+#define YOLO_PIPE1(...)                                                                        \
+    {                                                                                          \
+        ConvArgs b = a;                                                                        \
+        const int rc = launch_pipe<T, 1, __VA_ARGS__, 1, 0, 1, 1>(b, st, nm);                  \
+        if (rc != YOLO_EUNSUPPORTED) { a = b; return rc; }                                     \
+        return launch_pipe<T, 1, __VA_ARGS__>(a, st, nm);                                      \
+    }
+            case 2: YOLO_PIPE1(2, 4, 2, 4, 256)
+            case 3: YOLO_PIPE1(4, 2, 2, 2, 256)
+            case 4: YOLO_PIPE1(2, 2, 2, 2, 128)
+            case 5: YOLO_PIPE1(1, 8, 1, 4, 128)
+            case 8: YOLO_PIPE1(2, 2, 2, 3, 192)
+            case 11: YOLO_PIPE1(2, 2, 2, 1, 64)
+            case 12: YOLO_PIPE1(1, 4, 2, 2, 64)
+#undef YOLO_PIPE1
+            // deep-ring variants (one block per CU, 5-7 phases of loads in flight; generic loop)
             case 19: return launch_pipe<T, 1, 1, 4, 2, 2, 64, 1, 7>(a, st, nm);      // 64 px x 256 cout
             case 20: return launch_pipe<T, 1, 2, 2, 2, 1, 64, 1, 8>(a, st, nm);      // 64 px x 128 cout
             case 21: return launch_pipe<T, 1, 2, 2, 2, 2, 128, 1, 6>(a, st, nm);     // 128 px x 128 cout
-            // two K chunks per phase (half the barriers)
-            case 22: return launch_pipe<T, 1, 2, 2, 2, 1, 64, 1, 0, 2>(a, st, nm);   // 64 px x 128 cout
-            case 23: return launch_pipe<T, 1, 2, 2, 2, 2, 128, 1, 0, 2>(a, st, nm);  // 128 px x 128 cout
-            case 24: return launch_pipe<T, 1, 2, 2, 2, 3, 192, 1, 0, 2>(a, st, nm);  // 192 px x 128 cout
-            case 25: return launch_pipe<T, 1, 1, 4, 2, 2, 64, 1, 0, 2>(a, st, nm);   // 64 px x 256 cout
+            // two K chunks per phase (half the barriers), lean loop
+            case 22: return launch_pipe<T, 1, 2, 2, 2, 1, 64, 1, 0, 2, 1>(a, st, nm);   // 64 px x 128 cout
+            case 23: return launch_pipe<T, 1, 2, 2, 2, 2, 128, 1, 0, 2, 1>(a, st, nm);  // 128 px x 128 cout
+            case 24: return launch_pipe<T, 1, 2, 2, 2, 3, 192, 1, 0, 2, 1>(a, st, nm);  // 192 px x 128 cout
+            case 25: return launch_pipe<T, 1, 1, 4, 2, 2, 64, 1, 0, 2, 1>(a, st, nm);   // 64 px x 256 cout
         }
     }
     return YOLO_EUNSUPPORTED;
