@@ -28,7 +28,16 @@ def _worker(rank, world, port, q):
     # gradient bucket: SUM all-reduce then 1/global_batch rescale (trainer.step(batch_size), car/YOLO.py:396)
     g = torch.full((7,), float(rank + 1))
     P.allreduce_sum_(g)
-    q.put((rank, shard.shape[0], gathered.tolist() if rank == 0 else None, t, g.tolist()))
+    # uneven shards (7 images over 2 ranks: 3 + 4): trainer.step(batch_size) needs the SUM of the local sizes
+    a, b = P.shard_bounds(7, rank, world)
+    gb = P.global_batch_size(b - a)
+    # checkpoint: running statistics averaged over the ranks (gluon Parameter._reduce), weights untouched, live stats untouched
+    params = {'c.weight': torch.full((2,), float(rank)), 'c.running_mean': torch.full((3,), float(rank + 1)),
+              'c.running_var': torch.full((3,), 2.0 * (rank + 1))}
+    ck = P.checkpoint_params(params)
+    q.put((rank, shard.shape[0], gathered.tolist() if rank == 0 else None, t, g.tolist(), gb,
+           ck['c.running_mean'].tolist(), ck['c.running_var'].tolist(), ck['c.weight'].tolist(),
+           params['c.running_mean'].tolist()))
     dist.destroy_process_group()
 
 
@@ -45,6 +54,10 @@ def test_two_rank_sharding_and_reductions():
     assert out[0][2] == expect
     assert out[0][3] == out[1][3] == 2.0
     assert out[0][4] == out[1][4] == [3.0] * 7
+    assert out[0][5] == out[1][5] == 7
+    assert out[0][6] == out[1][6] == [1.5] * 3 and out[0][7] == out[1][7] == [3.0] * 3
+    assert out[0][8] == [0.0] * 2 and out[1][8] == [1.0] * 2
+    assert out[0][9] == [1.0] * 3 and out[1][9] == [2.0] * 3
 
 
 def test_shard_bounds_match_reference_formula():

@@ -114,6 +114,47 @@ def test_adam_update_and_second_step(cuda):
     assert torch.isfinite(l2).all() and tr.t == 2
 
 
+def test_inference_after_training_uses_the_updated_weights(cuda):
+    """train -> validate -> train -> validate on ONE net (the reference's _valid_iou every valid_step,
+    car/YOLO.py:501-534): every inference forward must see the weights and running statistics of the step before it
+    (the folded scale/bias and the packed weight images are re-made), and load_params on a net that has a Trainer
+    must reach the trainer's flat buffer."""
+    from oracle import forward as of
+    spec, size, g, P, x, lab, net, tr = _setup(cuda)
+    xt, lt = torch.from_numpy(x).to(cuda), torch.from_numpy(lab).to(cuda)
+
+    def check(tag):
+        Pn = {k: v.detach().cpu().numpy().copy() for k, v in net.params.items()}
+        ref = of.forward_torch(g, Pn, x)
+        outs = net(xt)
+        torch.cuda.synchronize()
+        for o, r in zip(outs, ref):
+            err = float(np.abs(o.cpu().numpy() - r.numpy()).max())
+            assert err < 1e-3, (tag, err)
+        return [o.clone() for o in outs]
+
+    o0 = check('before training')
+    for _ in range(3):
+        tr.train_step(xt, lt)
+    o1 = check('after 3 steps')
+    assert max(float((a - b).abs().max()) for a, b in zip(o0, o1)) > 1e-3          # the update was visible
+    for _ in range(2):
+        tr.train_step(xt, lt)
+    o2 = check('after 5 steps')
+    assert max(float((a - b).abs().max()) for a, b in zip(o1, o2)) > 1e-4
+    tr.train_step(xt, lt, update=False)                  # no weight update, but the running statistics moved
+    check('after a step without update')
+    # load_params after the Trainer was built: in place, so the trainer trains the loaded weights
+    net.load_params(P)
+    o3 = check('after load_params')
+    assert all(torch.equal(a, b) for a, b in zip(o0, o3))
+    assert all(net.params[n].data_ptr() == v.data_ptr() for n, v in tr.pview.items())
+    l_a = tr.train_step(xt, lt, update=False)
+    spec2, size2, g2, P2, x2, lab2, net2, tr2 = _setup(cuda)
+    l_b = tr2.train_step(xt, lt, update=False)
+    np.testing.assert_allclose(l_a.cpu().numpy(), l_b.cpu().numpy(), rtol=1e-5, atol=1e-8)    # = a fresh trainer's losses
+
+
 def test_training_reduces_loss(cuda):
     spec, size, g, P, x, lab, net, tr = _setup(cuda, B=4, seed_lab=3)
     xt, lt = torch.from_numpy(x).to(cuda), torch.from_numpy(lab).to(cuda)

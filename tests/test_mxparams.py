@@ -97,6 +97,43 @@ MID = {'layers': [1, 2, 1, 1], 'channels': [8, 16, 32, 64, 128], 'all_anchors': 
        'slice_point': [1, 3, 5, 6, 30]}
 
 
+def _handnamed(g, P, shuffle_seed=None, export=False):
+    """A checkpoint dict with gluon's names written out BY HAND from the naming rules (not through
+    mxparams.gluon_param_names): backbone under the net's prefix with running counters; YOLOPyrmaid's blocks outside
+    every scope -- per scale the output conv (top-level conv counter), the detection block (its own scope), and for
+    i > 0 the transition (top-level conv + batchnorm counters)."""
+    items = []
+
+    def add(name, ours):
+        if export:
+            name = ('aux:' if 'running' in name else 'arg:') + name
+        items.append((name, P[ours]))
+
+    n = 0
+    for c in [g.stem] + [x for down, res in g.stages for x in [down] + [y for pair in res for y in pair]]:
+        add('carnet0_conv%d_weight' % n, c.name + '.weight')
+        for k in ('gamma', 'beta', 'running_mean', 'running_var'):
+            add('carnet0_batchnorm%d_%s' % (n, k), c.name + '.' + k)
+        n += 1
+    top_c = top_b = 0
+    for i, (body, tip, outc, _) in enumerate(g.heads):
+        add('conv%d_weight' % top_c, outc.name + '.weight'); add('conv%d_bias' % top_c, outc.name + '.bias'); top_c += 1
+        for jj, c in enumerate(list(body) + [tip]):
+            add('yolodetectionblockv3%d_conv%d_weight' % (i, jj), c.name + '.weight')
+            for k in ('gamma', 'beta', 'running_mean', 'running_var'):
+                add('yolodetectionblockv3%d_batchnorm%d_%s' % (i, jj, k), c.name + '.' + k)
+        if i > 0:
+            t = g.transitions[i - 1]
+            add('conv%d_weight' % top_c, t.name + '.weight'); top_c += 1
+            for k in ('gamma', 'beta', 'running_mean', 'running_var'):
+                add('batchnorm%d_%s' % (top_b, k), t.name + '.' + k)
+            top_b += 1
+    if shuffle_seed is not None:
+        np.random.default_rng(shuffle_seed).shuffle(items)
+    from collections import OrderedDict
+    return OrderedDict(items)
+
+
 @pytest.mark.parametrize('spec', [MICRO, MID])
 def test_gluon_file_round_trip(tmp_path, spec):
     g = NetGraph(spec)
@@ -109,29 +146,83 @@ def test_gluon_file_round_trip(tmp_path, spec):
         np.testing.assert_array_equal(back[k], P[k])
 
 
-def test_exported_symbol_order_and_shape_check(tmp_path):
+@pytest.mark.parametrize('spec', [MICRO, MID])
+def test_names_written_match_gluon_naming_rules(spec):
+    """to_gluon's names == the names derived by hand from gluon's scoping rules, in collect_params() order for the
+    backbone, and as a set overall."""
+    g = NetGraph(spec)
+    P = _random_params(g, 3)
+    ours, hand = mp.to_gluon(g, P), _handnamed(g, P)
+    assert set(ours) == set(hand)
+    for k in hand:
+        np.testing.assert_array_equal(ours[k], hand[k])
+    nb = 5 * (1 + sum(1 + 2 * n for n in spec['layers']))
+    assert list(ours)[:nb] == list(hand)[:nb]
+    # registration order after the backbone: transitions, then the blocks, then the outputs (basic_yolo.py:32-37)
+    rest = list(ours)[nb:]
+    assert rest[0] == 'conv2_weight' and rest[1].startswith('batchnorm0_')
+    assert rest[-2:] == ['conv%d_weight' % (3 if len(g.heads) == 3 else 1), 'conv%d_bias' % (3 if len(g.heads) == 3 else 1)]
+
+
+@pytest.mark.parametrize('export', [False, True])
+def test_real_files_are_in_hash_order_match_by_name(tmp_path, export):
+    """The reference is Python-2 code and saves through a plain dict: the order inside a real file is arbitrary.  Many
+    layers share a shape (repeated residual blocks, the per-conv gamma/beta), so a positional mapping would permute
+    them silently; matching by name must not care."""
+    g = NetGraph(MID)
+    P = _random_params(g, 4)
+    for seed in (0, 1, 2):
+        p = str(tmp_path / ('s%d.params' % seed))
+        mp.write_params(p, _handnamed(g, P, shuffle_seed=seed, export=export))
+        back = mp.from_gluon(g, mp.read_params(p))
+        assert sorted(back) == sorted(P)
+        for k in P:
+            np.testing.assert_array_equal(back[k], P[k], err_msg=k)
+
+
+def test_name_matching_ignores_counter_offsets_and_prefix(tmp_path):
+    """A net that was not the first block of its process has shifted counters (carnet3_, conv7_ ...): only the structure
+    (scope, kind, counter ORDER) is used."""
+    g = NetGraph(MICRO)
+    P = _random_params(g, 5)
+    import re
+    shifted = {}
+    for n, a in _handnamed(g, P).items():
+        n = n.replace('carnet0_', 'carnet3_')
+        n = re.sub(r'^(conv|batchnorm)(\d+)_', lambda m: '%s%d_' % (m.group(1), int(m.group(2)) + 7), n)
+        n = re.sub(r'yolodetectionblockv3(\d+)_', lambda m: 'yolodetectionblockv3%d_' % (int(m.group(1)) + 11), n)
+        shifted[n] = a
+    back = mp.from_gluon(g, shifted)
+    for k in P:
+        np.testing.assert_array_equal(back[k], P[k], err_msg=k)
+
+
+def test_wrong_structure_is_rejected():
+    g = NetGraph(MICRO)
+    P = _random_params(g, 6)
+    d = _handnamed(g, P)
+    missing = dict(d); del missing['carnet0_batchnorm3_gamma']
+    with pytest.raises(mp.ParamsFormatError):
+        mp.from_gluon(g, missing)
+    other = _handnamed(NetGraph(MID), _random_params(NetGraph(MID), 6))
+    with pytest.raises(mp.ParamsFormatError):
+        mp.from_gluon(g, other)
+
+
+def test_positional_fallback_for_files_without_gluon_names(tmp_path):
+    """Name-less containers ('0', '1', ...) or foreign names: registration order, every shape checked."""
     g = NetGraph(MICRO)
     P = _random_params(g, 1)
     exp = {}
-    for c in mp.gluon_conv_order(g, 'forward'):          # net.export: arg:/aux: names, forward order
-        exp['arg:%s_weight' % c.name] = P[c.name + '.weight']
-        if c.bn:
-            exp['arg:%s_gamma' % c.name] = P[c.name + '.gamma']
-            exp['arg:%s_beta' % c.name] = P[c.name + '.beta']
-        else:
-            exp['arg:%s_bias' % c.name] = P[c.name + '.bias']
-    for c in mp.gluon_conv_order(g, 'forward'):
-        if c.bn:
-            exp['aux:%s_running_mean' % c.name] = P[c.name + '.running_mean']
-            exp['aux:%s_running_var' % c.name] = P[c.name + '.running_var']
-    p = str(tmp_path / 'sym-0000.params')
-    mp.write_params(p, exp)
-    back = mp.from_gluon(g, mp.read_params(p))
+    for c in mp.gluon_conv_order(g, 'registration'):
+        for k in (('weight', 'gamma', 'beta', 'running_mean', 'running_var') if c.bn else ('weight', 'bias')):
+            exp['%s_%s' % (c.name, k)] = P[c.name + '.' + k]
+    back = mp.from_gluon(g, exp)
     for k in P:
         np.testing.assert_array_equal(back[k], P[k])
     # a file in the other order fails the shape check instead of loading silently wrong
     with pytest.raises(mp.ParamsFormatError):
-        mp.from_gluon(g, mp.read_params(p), order='registration')
+        mp.from_gluon(g, exp, order='forward')
 
 
 def test_gluon_order_with_lp_branch():

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(1024) void predict_top1_kernel(const float* __restr
             const int oi = __shfl_xor(bi, off, 64);
             argmax_combine(bv, bi, ov, oi);
         }
-        if (lane == 0) { si[0] = bi; sv[0] = bv; }
+        if (lane == 0) { si[0] = bi == 0x7fffffff ? 0 : bi; sv[0] = bv; }   // all-NaN scores: index 0, as mxnet's argmax
     }
     __syncthreads();
     const int k = si[0];
@@ -685,6 +685,7 @@ __global__ __launch_bounds__(256) void predict_lp_kernel(const float* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w) argmax_combine(bv, bi, sv[w], si[w]);
+        if (bi == 0x7fffffff) bi = 0;          // all-NaN scores: index 0, as mxnet's argmax
         si[0] = bi;
         best_idx[0] = bi;
     }
@@ -739,6 +740,7 @@ __global__ __launch_bounds__(256) void predict_lp_nhwc_kernel(const float* __res
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w) argmax_combine(bv, bi, sv[w], si[w]);
+        if (bi == 0x7fffffff) bi = 0;          // all-NaN scores: index 0, as mxnet's argmax
         si[0] = bi;
         best_idx[b] = bi;
     }

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ l
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w)
             if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
-        const int k = bi;
+        const int k = bi == 0x7fffffff ? 0 : bi;          // NaN label / all-NaN IoU: box 0, as mxnet's argmax
         const int px = k / g.A, anc = k - px * g.A;
         int layer = 0;
         for (int q = 1; q < g.nscale; ++q)

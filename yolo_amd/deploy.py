@@ -5,7 +5,8 @@ half precision / through TensorRT) and the `/YOLO/box` row the video node publis
 On MI355X the "engine" is a `CarNet` with BatchNorm folded into per-channel scale/bias and the weights packed for
 the MFMA kernels (`CarNet.prepare`), running bf16 activations: there is no separate runtime to build.  The exported
 symbol JSON is MXNet-specific and is not needed -- the spec rebuilds the graph -- so only the `export-NNNN.params`
-half of `net.export` (yolo_gluon.py:245-272: `arg:` / `aux:` prefixed names, forward order) is read and written.
+half of `net.export` (yolo_gluon.py:245-272: the gluon parameter names prefixed with `arg:` / `aux:`) is read and
+written; parameters are matched by name (yolo_amd/mxparams.py).
 """
 import math
 import os
@@ -31,24 +32,12 @@ class Executor(object):
         return self.outputs
 
 
-def export_params(net, export_folder, epoch=0):
-    """The parameter half of yolo_gluon.export: <folder>/export-%04d.params with arg:/aux: names in forward order."""
+def export_params(net, export_folder, epoch=0, prefix='carnet0_'):
+    """The parameter half of yolo_gluon.export: <folder>/export-%04d.params, what HybridBlock.export writes --
+    collect_params() with every name prefixed by `arg:` (or `aux:` for the running statistics)."""
     os.makedirs(export_folder, exist_ok=True)
-    P = net.collect_params()
-    get = lambda k: np.asarray(P[k].detach().cpu().numpy() if hasattr(P[k], 'detach') else P[k], np.float32)
-    arg, aux = {}, {}
-    for i, c in enumerate(mxparams.gluon_conv_order(net.graph, 'forward')):
-        arg['arg:conv%d_weight' % i] = get(c.name + '.weight')
-        if c.bn:
-            arg['arg:batchnorm%d_gamma' % i] = get(c.name + '.gamma')
-            arg['arg:batchnorm%d_beta' % i] = get(c.name + '.beta')
-            aux['aux:batchnorm%d_running_mean' % i] = get(c.name + '.running_mean')
-            aux['aux:batchnorm%d_running_var' % i] = get(c.name + '.running_var')
-        else:
-            arg['arg:conv%d_bias' % i] = get(c.name + '.bias')
-    arg.update(aux)
     path = os.path.join(export_folder, 'export-%04d.params' % epoch)
-    mxparams.write_params(path, arg)
+    mxparams.write_params(path, mxparams.to_gluon(net.graph, net.collect_params(), prefix, export=True))
     return path
 
 
@@ -59,7 +48,7 @@ def init_executor(export_folder, spec, size, device='cuda:0', step=0, dtype='bf1
     from .net import CarNet, CarLPNet
     cls = CarLPNet if 'LP_slice_point' in spec else CarNet
     net = cls(spec, dtype=dtype, device=device, tune=tune)
-    net.load_gluon_params(os.path.join(export_folder, 'export-%04d.params' % step), order='forward')
+    net.load_gluon_params(os.path.join(export_folder, 'export-%04d.params' % step))
     net.prepare()
     net(torch.zeros((1, 3, int(size[0]), int(size[1])), dtype=torch.float32, device=device))    # bind: build the plan
     return Executor(net)

@@ -21,8 +21,29 @@ Gluon parameter order (`collect_params()` is depth-first in child REGISTRATION o
 `stages`, then `transitions`, `yolo_blocks`, `yolo_outputs`): stem, every stage (down-sampling conv, then its residual
 blocks), the transitions, the detection blocks deep -> shallow (body convs, then tip), the outputs deep -> shallow.
 Each `_conv2d` contributes weight, gamma, beta, running_mean, running_var; each YOLOOutput weight, bias.
-An exported symbol file (`arg:` / `aux:` prefixed names) lists arguments in forward (topological) order instead.
+`HybridBlock.export` (yolo_gluon.py:257) iterates the same `collect_params()` and only prefixes every name with
+`arg:` / `aux:`, so an exported file is in registration order too.  The reference is Python-2 code (`exec "..."`), and
+both writers go through a plain dict, so the order INSIDE a real file is hash order: parameters are therefore matched
+by NAME (`gluon_param_names` below restates gluon's naming rules); position is only the fallback for files without
+gluon names.
+
+Gluon names (Block.__init__ -> _BlockScope.create, restated): a block created inside `with parent.name_scope()` is
+called `<parent prefix><class name lower-cased><per-scope counter>_`; outside any scope the counter is the process-
+wide NameManager's.  gluoncv's `_conv2d` and `DarknetBasicBlockV3` open NO scope of their own (their Conv2D /
+BatchNorm take the counters of whatever scope is current), `YOLODetectionBlockV3` does.  BasicYOLONet builds the
+backbone inside `with self.name_scope()` (basic_yolo.py:18-27) and calls YOLOPyrmaid OUTSIDE it (:32-37), and
+YOLOOutput (basic_yolo.py:91-98) opens no scope, so a CarNet checkpoint holds
+
+    carnet0_conv{0..51}_weight, carnet0_batchnorm{0..51}_{gamma,beta,running_mean,running_var}        backbone
+    yolodetectionblockv3{k}_conv{0..5}_weight, ..._batchnorm{0..5}_*    detection block k (deep -> shallow; 5 = tip)
+    conv{j}_weight, conv{j}_bias                    YOLOOutput k and, with batchnorm{t}_*, transition t, j in creation
+                                                    order (output 0, output 1, transition 0, output 2, transition 1)
+
+CarLPNet (car_and_LP/YOLO.py:47-60) adds yolodetectionblockv3{3..7}_* and one more biased top-level conv.  The
+reader does not rely on the literal prefixes or counter values -- only on the structure (scope, layer kind, counter
+order) -- and checks every shape.
 """
+import re
 import struct
 from collections import OrderedDict
 
@@ -158,6 +179,9 @@ def gluon_conv_order(graph, order='registration'):
 
 _SUFFIX = ('weight', 'gamma', 'beta', 'running_mean', 'running_var', 'bias')
 _AUX = ('running_mean', 'running_var')
+_NAME_RE = re.compile(r'^(?:(?:arg|aux):)?(.*?)(conv|batchnorm)(\d+)_(weight|bias|gamma|beta|running_mean|running_var|'
+                      r'moving_mean|moving_var)$')
+_BLOCK_RE = re.compile(r'^(.*)yolodetectionblockv3(\d+)_$')
 
 
 def _suffix(name):
@@ -167,14 +191,146 @@ def _suffix(name):
     return None
 
 
+def gluon_param_names(graph, prefix='carnet0_'):
+    """OrderedDict `<our name>.<param>` -> gluon parameter name, in collect_params() (registration) order, for a net
+    built as the first blocks of its process (fresh NameManager counters) -- see the module docstring."""
+    out = OrderedDict()
+
+    def unit(c, scope, ci, bi):
+        out[c.name + '.weight'] = '%sconv%d_weight' % (scope, ci)
+        if c.bn:
+            for s in ('gamma', 'beta', 'running_mean', 'running_var'):
+                out['%s.%s' % (c.name, s)] = '%sbatchnorm%d_%s' % (scope, bi, s)
+        else:
+            out[c.name + '.bias'] = '%sconv%d_bias' % (scope, ci)
+
+    n = 0
+    backbone = [graph.stem]
+    for down, res in graph.stages:
+        backbone.append(down)
+        for c1, c2 in res:
+            backbone += [c1, c2]
+    for c in backbone:
+        unit(c, prefix, n, n)
+        n += 1
+    # YOLOPyrmaid, outside every scope: per scale the output conv, the detection block, (i > 0) the transition
+    top_conv, top_bn = {}, {}
+    ci = bi = 0
+    for i, (body, tip, outc, _) in enumerate(graph.heads):
+        top_conv[outc.name] = ci; ci += 1
+        if i > 0:
+            t = graph.transitions[i - 1]
+            top_conv[t.name], top_bn[t.name] = ci, bi
+            ci += 1; bi += 1
+    lp_blocks = list(getattr(graph, 'lp_blocks', []))
+    lp_out = getattr(graph, 'lp_out', None)
+    if lp_out is not None:
+        top_conv[lp_out.name] = ci; ci += 1
+    for t in graph.transitions:                                   # registration: transitions, yolo_blocks, yolo_outputs
+        unit(t, '', top_conv[t.name], top_bn[t.name])
+    for k, (body, tip, outc, _) in enumerate(graph.heads):
+        for j, c in enumerate(list(body) + [tip]):
+            unit(c, 'yolodetectionblockv3%d_' % k, j, j)
+    for body, tip, outc, _ in graph.heads:
+        unit(outc, '', top_conv[outc.name], None)
+    for k, (body, tip) in enumerate(lp_blocks):                   # CarLPNet.LP_branch, registered last
+        for j, c in enumerate(list(body) + [tip]):
+            unit(c, 'yolodetectionblockv3%d_' % (len(graph.heads) + k), j, j)
+    if lp_out is not None:
+        unit(lp_out, '', top_conv[lp_out.name], None)
+    return out
+
+
+def _from_gluon_by_name(graph, loaded):
+    """Structural name matching; returns None when the file's names are not gluon names."""
+    scopes = {}
+    for n, a in loaded.items():
+        m = _NAME_RE.match(n)
+        if m is None:
+            return None
+        scope, kind, idx, suffix = m.group(1), m.group(2), int(m.group(3)), m.group(4).replace('moving', 'running')
+        layers = scopes.setdefault(scope, {'conv': {}, 'batchnorm': {}})[kind]
+        ent = layers.setdefault(idx, {})
+        if suffix in ent:
+            raise ParamsFormatError('parameter %r appears twice' % n)
+        ent[suffix] = np.asarray(a)
+
+    def units(scope):
+        """[(conv counter, {param: array})] of one scope: the k-th bias-less conv owns the k-th BatchNorm."""
+        convs = sorted(scopes[scope]['conv'].items())
+        bns = sorted(scopes[scope]['batchnorm'].items())
+        plain = [(i, c) for i, c in convs if 'bias' not in c]
+        if len(plain) != len(bns):
+            raise ParamsFormatError('scope %r: %d convolutions without bias but %d BatchNorms' % (scope, len(plain), len(bns)))
+        for (i, c), (_, b) in zip(plain, bns):
+            c.update(b)
+        return convs
+
+    block_scopes, other = [], []
+    for sc in scopes:
+        m = _BLOCK_RE.match(sc)
+        if m:
+            block_scopes.append(((m.group(1), int(m.group(2))), sc))
+        else:
+            other.append(sc)
+    block_scopes.sort()
+    plain, biased = [], []
+    # non-block scopes, the one with the most layers (the net's own: the backbone) first
+    for sc in sorted(other, key=lambda sc_: (-len(scopes[sc_]['conv']), sc_)):
+        for i, u in units(sc):
+            (biased if 'bias' in u else plain).append(u)
+    backbone = [graph.stem]
+    for down, res in graph.stages:
+        backbone.append(down)
+        for c1, c2 in res:
+            backbone += [c1, c2]
+    lp_blocks = list(getattr(graph, 'lp_blocks', []))
+    lp_out = getattr(graph, 'lp_out', None)
+    want_plain = backbone + list(graph.transitions)
+    want_biased = [h[2] for h in graph.heads] + ([lp_out] if lp_out is not None else [])
+    want_blocks = [list(body) + [tip] for body, tip, _, _ in graph.heads] + [list(body) + [tip] for body, tip in lp_blocks]
+    if len(plain) != len(want_plain) or len(biased) != len(want_biased) or len(block_scopes) != len(want_blocks):
+        raise ParamsFormatError('file has %d conv+BN layers / %d biased convs / %d detection blocks outside the blocks; '
+                                'the spec needs %d / %d / %d' % (len(plain), len(biased), len(block_scopes),
+                                                                 len(want_plain), len(want_biased), len(want_blocks)))
+    out = {}
+
+    def put(c, u, where):
+        need = ('weight', 'gamma', 'beta', 'running_mean', 'running_var') if c.bn else ('weight', 'bias')
+        if sorted(u) != sorted(need):
+            raise ParamsFormatError('%s (%s): file has %s, expected %s' % (c.name, where, sorted(u), sorted(need)))
+        for k in need:
+            shape = (c.cout, c.cin, c.k, c.k) if k == 'weight' else (c.cout,)
+            if tuple(u[k].shape) != shape:
+                raise ParamsFormatError('%s.%s (%s): expected shape %s, file has %s' % (c.name, k, where, shape, tuple(u[k].shape)))
+            out['%s.%s' % (c.name, k)] = np.asarray(u[k], np.float32)
+
+    for c, u in zip(want_plain, plain):
+        put(c, u, 'conv+BN outside the detection blocks')
+    for c, u in zip(want_biased, biased):
+        put(c, u, 'biased output conv')
+    for convs, (_, sc) in zip(want_blocks, block_scopes):
+        us = units(sc)
+        if len(us) != len(convs):
+            raise ParamsFormatError('scope %r has %d layers, a detection block has %d' % (sc, len(us), len(convs)))
+        for c, (_, u) in zip(convs, us):
+            put(c, u, sc)
+    return out
+
+
 def from_gluon(graph, loaded, order='auto'):
-    """Map an OrderedDict read from a gluon `.params` file onto this package's names.  Parameters are matched by
-    ORDER within their kind (the i-th conv weight of the file is the i-th conv in gluon order, and likewise the
-    i-th gamma/beta/running_mean/running_var/bias) and every shape is checked, so the result does not depend on
-    gluon's name counters."""
-    names = list(loaded.keys())
+    """Map an OrderedDict read from a gluon `.params` file onto this package's names.
+
+    order='auto': by NAME when the file carries gluon parameter names (module docstring) -- the position inside the
+    file is then irrelevant (real files are in Python-2 dict order); files without such names (e.g. '0', '1', ...) fall
+    back to position in registration order.  order='registration' / 'forward' force the positional mapping: the i-th
+    array of a kind is the i-th conv's in that order.  Every shape is checked."""
     if order == 'auto':
-        order = 'forward' if any(n.startswith(('arg:', 'aux:')) for n in names) else 'registration'
+        byname = _from_gluon_by_name(graph, loaded)
+        if byname is not None:
+            return byname
+        order = 'registration'
+    names = list(loaded.keys())
     convs = gluon_conv_order(graph, order)
     by_kind = {s: [] for s in _SUFFIX}
     for n in names:
@@ -208,20 +364,14 @@ def from_gluon(graph, loaded, order='auto'):
     return out
 
 
-def to_gluon(graph, params, prefix='carnet0_'):
-    """This package's parameters as an OrderedDict in collect_params() order with gluon-style names
-    (<prefix>conv<i>_weight, <prefix>batchnorm<i>_gamma, ...; loading is by order, see from_gluon)."""
+def to_gluon(graph, params, prefix='carnet0_', export=False):
+    """This package's parameters as an OrderedDict with gluon names (gluon_param_names) in collect_params() order.
+    export=True: the `arg:` / `aux:` prefixes HybridBlock.export adds (running statistics are auxiliary states)."""
     out = OrderedDict()
-    ci = bi = 0
-    for c in gluon_conv_order(graph, 'registration'):
-        get = lambda k: np.asarray(params[c.name + '.' + k].detach().cpu().numpy() if hasattr(params[c.name + '.' + k], 'detach')
-                                   else params[c.name + '.' + k], np.float32)
-        out['%sconv%d_weight' % (prefix, ci)] = get('weight')
-        if c.bn:
-            for s in ('gamma', 'beta', 'running_mean', 'running_var'):
-                out['%sbatchnorm%d_%s' % (prefix, bi, s)] = get(s)
-            bi += 1
-        else:
-            out['%sconv%d_bias' % (prefix, ci)] = get('bias')
-        ci += 1
+    for ours, theirs in gluon_param_names(graph, prefix).items():
+        v = params[ours]
+        a = np.asarray(v.detach().cpu().numpy() if hasattr(v, 'detach') else v, np.float32)
+        if export:
+            theirs = ('aux:' if ours.endswith(_AUX) else 'arg:') + theirs
+        out[theirs] = a
     return out

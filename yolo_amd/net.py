@@ -60,6 +60,10 @@ class CarNet(object):
         self.params = {}
         self._prepared = {}
         self._plans = {}
+        # parameter version: bumped by everything that changes a parameter or a running statistic (initialize,
+        # load_params, every Trainer.train_step); forward() re-folds / re-packs when the prepared images are older
+        self._version = 0
+        self._prepared_version = -1
         self._lib = L.load()
 
     # ---- parameters (gluon collect_params().save/load seam, car/YOLO.py:549, yolo_gluon.py:190) --
@@ -69,16 +73,25 @@ class CarNet(object):
         for c in self.graph.convs():
             a = xavier_bound(c.cin, c.cout, c.k)
             w = (torch.rand((c.cout, c.cin, c.k, c.k), generator=gen) * 2 - 1) * a
-            self.params[c.name + '.weight'] = w.to(self.device)
+            self._set_param(c.name + '.weight', w.to(self.device))
             if c.bn:
-                self.params[c.name + '.gamma'] = torch.ones(c.cout, device=self.device)
-                self.params[c.name + '.beta'] = torch.zeros(c.cout, device=self.device)
-                self.params[c.name + '.running_mean'] = torch.zeros(c.cout, device=self.device)
-                self.params[c.name + '.running_var'] = torch.ones(c.cout, device=self.device)
+                self._set_param(c.name + '.gamma', torch.ones(c.cout, device=self.device))
+                self._set_param(c.name + '.beta', torch.zeros(c.cout, device=self.device))
+                self._set_param(c.name + '.running_mean', torch.zeros(c.cout, device=self.device))
+                self._set_param(c.name + '.running_var', torch.ones(c.cout, device=self.device))
             else:
-                self.params[c.name + '.bias'] = torch.zeros(c.cout, device=self.device)
-        self._prepared = {}
+                self._set_param(c.name + '.bias', torch.zeros(c.cout, device=self.device))
+        self._version += 1
         return self
+
+    def _set_param(self, name, t):
+        """Store a parameter.  An existing tensor of the same shape is overwritten IN PLACE: a Trainer's flat
+        weight buffer and the launch plans hold views of / pointers into it."""
+        old = self.params.get(name)
+        if old is not None and old.shape == t.shape:
+            old.copy_(t)
+        else:
+            self.params[name] = t
 
     def load_params(self, params):
         """params: dict name -> ndarray / tensor, gluon-style names (see ConvSpec.param_names)."""
@@ -88,15 +101,17 @@ class CarNet(object):
                     raise KeyError('missing parameter %s' % n)
                 v = params[n]
                 t = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v
-                self.params[n] = t.detach().to(self.device, torch.float32).contiguous()
-        self._prepared = {}
+                self._set_param(n, t.detach().to(self.device, torch.float32).contiguous())
+        self._version += 1
         return self
 
     def collect_params(self):
         return self.params
 
     def save_state(self, path):
-        np.savez(path, **{k: v.detach().cpu().numpy() for k, v in self.params.items()})
+        from . import parallel
+        # (under torch.distributed every rank must call this: the running statistics are averaged over the ranks)
+        np.savez(path, **{k: v.detach().cpu().numpy() for k, v in parallel.checkpoint_params(self.params).items()})
 
     def load_state(self, path):
         with np.load(path) as z:
@@ -110,8 +125,8 @@ class CarNet(object):
         return self.load_params(mxparams.from_gluon(self.graph, mxparams.read_params(path), order))
 
     def save_gluon_params(self, path, prefix='carnet0_'):
-        from . import mxparams
-        mxparams.write_params(path, mxparams.to_gluon(self.graph, self.params, prefix))
+        from . import mxparams, parallel
+        mxparams.write_params(path, mxparams.to_gluon(self.graph, parallel.checkpoint_params(self.params), prefix))
 
     # ---- one-off preparation: BN folding + weight packing (all on device, HIP kernels) ------------
     def prepare(self):
@@ -121,11 +136,14 @@ class CarNet(object):
             nbytes = lib.yolo_packed_weight_bytes(c.cout, c.cin, c.k, dt)
             if nbytes < 0:
                 raise L.YoloError('unsupported conv %s' % c.name)
-            wp = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            L.check(lib.yolo_pack_conv_weights(L.ptr(w), L.ptr(wp), c.cout, c.cin, c.k, dt, st), 'pack ' + c.name)
             cp = lib.yolo_padded_channels(c.cout)
-            scale = torch.empty(cp, dtype=torch.float32, device=self.device)
-            bias = torch.empty(cp, dtype=torch.float32, device=self.device)
+            if c.name in self._prepared:
+                wp, scale, bias = self._prepared[c.name]      # refreshed in place: the launch plans point at them
+            else:
+                wp = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+                scale = torch.empty(cp, dtype=torch.float32, device=self.device)
+                bias = torch.empty(cp, dtype=torch.float32, device=self.device)
+            L.check(lib.yolo_pack_conv_weights(L.ptr(w), L.ptr(wp), c.cout, c.cin, c.k, dt, st), 'pack ' + c.name)
             if c.bn:
                 p = lambda s: L.ptr(self.params[c.name + s])
                 L.check(lib.yolo_fold_bn(p('.gamma'), p('.beta'), p('.running_mean'), p('.running_var'),
@@ -134,8 +152,12 @@ class CarNet(object):
                 L.check(lib.yolo_fold_bn(None, L.ptr(self.params[c.name + '.bias']), None, None, BN_EPS,
                                          L.ptr(scale), L.ptr(bias), c.cout, st), 'bias ' + c.name)
             self._prepared[c.name] = (wp, scale, bias)
-        self._plans = {}
+        self._prepared_version = self._version
         return self
+
+    def _ensure_prepared(self):
+        if not self._prepared or self._prepared_version != self._version:
+            self.prepare()
 
     # ---- plan construction --------------------------------------------------------------------------
     def _conv_op(self, plan, c, x, xshape, residual=None, out=None, out_f32=False, y_bs=0, y_ps=0, cin=None):
@@ -284,8 +306,7 @@ class CarNet(object):
     def forward(self, x, training=False):
         if training:
             raise NotImplementedError('training-mode forward is not built yet')
-        if not self._prepared:
-            self.prepare()
+        self._ensure_prepared()
         if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or not x.is_cuda:
             raise ValueError('expected a (B,3,H,W) float32 CUDA tensor')
         x = x.contiguous()
@@ -329,8 +350,7 @@ class CarNet(object):
     def plan_kernels(self, B, H, W):
         """[(op name, kernel instantiation name, algorithmic FLOPs)] for the launch list of one input
         shape (FLOPs = 2*Cin*k^2*Cout*Ho*Wo*B per conv; 0 for non-conv ops)."""
-        if not self._prepared:
-            self.prepare()
+        self._ensure_prepared()
         plan = self._plans.get((B, H, W))
         if plan is None:
             plan = self._plans[(B, H, W)] = self._build_plan(B, H, W)

@@ -49,6 +49,32 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
+def global_batch_size(local_batch, device=None):
+    """Sum of the ranks' local batch sizes: the `batch_size` of trainer.step(batch_size) (car/YOLO.py:396).  Ranks may
+    hold uneven shards (shard_bounds), so this is a SUM all-reduce, not local * world."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return int(local_batch)
+    t = torch.tensor([int(local_batch)], dtype=torch.int64, device=device if dist.get_backend() == 'nccl' else None)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def checkpoint_params(params):
+    """The parameter dict a checkpoint holds: `.running_mean` / `.running_var` averaged over the ranks (copies; the
+    live statistics stay local to a GPU: no SyncBN) -- what gluon's Parameter._reduce() does with the per-device
+    copies when collect_params().save() writes a file (car/YOLO.py:549).  Collective: every rank must call it."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return params
+    world = dist.get_world_size()
+    out = dict(params)
+    for n in sorted(params):
+        if n.endswith(('.running_mean', '.running_var')):
+            t = params[n].detach().clone()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            out[n] = t / world
+    return out
+
+
 def allreduce_sum_(flat):
     """In-place SUM all-reduce of a flat gradient bucket (no-op for a single rank)."""
     if dist.is_initialized() and dist.get_world_size() > 1:

@@ -74,11 +74,15 @@ class Trainer(object):
             self.pview[n] = net.params[n]
             self.gview[n] = self.gflat[of:of + s].view(shp)
         self.buckets = parallel.GradBuckets(self.gflat, names, offs, sizes, nbuckets=4)
-        net._prepared = {}
+        # the parameters moved into the flat buffer: the net's launch plans hold pointers to the old tensors (stem
+        # weights), and its folded / packed images are re-made on the next inference forward (net._version)
+        net._plans = {}
+        net._version += 1
         self._prep = {}
         self._prep_s2 = {}          # conv name -> (sub-pixel dgrad weight image, ones, zeros); see _dgrad
         self._plans = {}
         self._dgrad_algo = {}
+        self._gb_cache = {}
         cmax = max(c.cout for c in g.convs())
         self.ws = torch.zeros(3 * cmax, dtype=torch.float64, device=self.dev)
         wsb = max(self.lib.yolo_conv_wgrad_workspace_bytes(max(c.cin, 8), c.cout, c.k, self.ldt) for c in g.convs())
@@ -89,6 +93,7 @@ class Trainer(object):
         self._overlap = not os.environ.get('YOLO_TRAIN_SERIAL_WGRAD')          # (the knob keeps the serial order for A/B runs)
         self._identity = not os.environ.get('YOLO_TRAIN_UNIT_EPILOGUE')        # (the knob: scale 1 / bias 0 arrays instead of the identity epilogue)
         self._repack()
+        self._packed_version = net._version
 
     # ---- weight images for the forward and data-gradient convolutions (re-packed after every update) ----
     def _repack(self):
@@ -433,6 +438,11 @@ class Trainer(object):
         P = self._plans.get(B)
         if P is None:
             P = self._plans[B] = self._build(B, H, W)
+        if self.net._version != self._packed_version:
+            # net.load_params / initialize since the last step (they write into the flat buffer's views in place)
+            if any(self.net.params[n].data_ptr() != v.data_ptr() for n, v in self.pview.items()):
+                raise L.YoloError('a parameter tensor of the net was replaced after the Trainer was built')
+            self._repack()
         self._forward(P, images)
         nobj, ncls = labels.shape[1], labels.shape[2] - 6
         C_ = self.net.graph.per_anchor
@@ -468,12 +478,21 @@ class Trainer(object):
         self._backward(P, exchange=update)
         if update:
             self.buckets.wait()                                    # KVStore sum-reduce of trainer.step (RCCL), bucketed
-            gb = global_batch if global_batch is not None else B * (torch.distributed.get_world_size()
-                                                                     if torch.distributed.is_initialized() else 1)
+            if global_batch is None:
+                # trainer.step(batch_size): the SUM of the ranks' shard sizes (uneven shards allowed); the shards of a
+                # run are static, so the all-reduce + host read happens once per local batch size
+                if B not in self._gb_cache:
+                    self._gb_cache[B] = parallel.global_batch_size(B, self.dev)
+                global_batch = self._gb_cache[B]
+            gb = global_batch
             self.t += 1
             L.check(lib.yolo_adam_step(L.ptr(self.wflat), L.ptr(self.gflat), L.ptr(self.mflat), L.ptr(self.vflat),
                                        self.wflat.numel(), self.t, self.lr, self.b1, self.b2, self.eps, 1.0 / gb, st), 'adam')
             self._repack()
+        # the running statistics moved in every step (and the weights when update): an inference forward of the same net
+        # (the reference's _valid_iou every valid_step, car/YOLO.py:501-534) must re-fold and re-pack
+        self.net._version += 1
+        self._packed_version = self.net._version
         return losses
 
     def grads(self):
