@@ -154,6 +154,10 @@ int yolo_predict_lp_nhwc(const float* out, float* pred, int* best_idx, int B, in
 /* get_iou(predict, target, mode=2), yolo_gluon.py:127-168: boxes (n,4) ltrb vs one target
  * [c,y,x,h,w] (5 floats, device) -> iou (n). */
 int yolo_iou_ltrb_vs_yxhw(const float* boxes, const float* target, float* iou, int n, void* stream);
+/* get_iou(predict, target, mode=1) -- the reference's DEFAULT mode (yolo_gluon.py:127): target [c,l,t,r,b]; keeps the
+ * reference's target_area = target[3] * target[4] (yolo_gluon.py:166; = r * b in this mode), so a caller that omits
+ * `mode` gets the reference's numbers, quirk included. */
+int yolo_iou_ltrb_vs_cltrb(const float* boxes, const float* target, float* iou, int n, void* stream);
 
 /* Greedy per-class NMS over decoded rows (not in the reference -- SURVEY.md S1; semantics =
  * SURVEY App. A.8).  mode 0: score = sigmoid(obj), class-agnostic; mode 1: candidates are

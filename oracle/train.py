@@ -320,3 +320,32 @@ def train_step_reference_lp(g, P, x, labels, lp_labels, spec, size, scale=DEFAUL
     grads = {k: t.grad.numpy() for k, t in Pt.items() if t.requires_grad and t.grad is not None}
     return [l.detach().numpy() for l in losses], grads, merged.detach().numpy(), lp[0].detach().numpy()
 
+
+
+# ---- one-hop backward references from SAVED forward values (tests/test_gpu_configs.py) ---------------------------------
+# A randomly initialised net in train mode is chaotic (a 1e-5 forward difference flips LeakyReLU' signs), so comparing a
+# whole backward pass end to end needs loose bars.  These helpers restate the backward of ONE layer of _train_batch's
+# autograd graph (car/YOLO.py:381-392; gluoncv _conv2d = Convolution -> BatchNorm(train) -> LeakyReLU(0.1), SURVEY
+# App. A.1/A.3) given the values the layer under test itself saved: errors cannot accumulate across layers and every
+# gradient of the step can be held to a tight bar.
+def bn_act_backward(yraw, gamma, beta, dz, eps=1e-5, slope=0.1):
+    """Backward of train-mode BatchNorm (biased batch variance) + LeakyReLU at the saved raw convolution output `yraw`
+    (B,C,H,W).  Returns (z, dy, dgamma, dbeta); a residual branch adds to z and receives dz unchanged."""
+    y = torch.as_tensor(yraw).detach().clone().requires_grad_(True)
+    g = torch.as_tensor(gamma).detach().clone().requires_grad_(True)
+    b = torch.as_tensor(beta).detach().clone().requires_grad_(True)
+    mean = y.mean(dim=(0, 2, 3))
+    var = y.var(dim=(0, 2, 3), unbiased=False)
+    a = (y - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + eps) * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+    z = torch.nn.functional.leaky_relu(a, slope)
+    z.backward(torch.as_tensor(dz))
+    return z.detach(), y.grad, g.grad, b.grad
+
+
+def conv_backward(x, w, dy, stride):
+    """Data and weight gradient of Convolution(no bias, pad = k // 2) at the saved input `x` for the given dy."""
+    x, w, dy = torch.as_tensor(x), torch.as_tensor(w), torch.as_tensor(dy)
+    pad = w.shape[2] // 2
+    dx = torch.nn.grad.conv2d_input(x.shape, w, dy, stride=stride, padding=pad)
+    dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride=stride, padding=pad)
+    return dx, dw

@@ -115,3 +115,38 @@ def test_bucket_ranges_cover_the_buffer():
         r = P.bucket_ranges(offs, sizes, nb, total=112)
         assert r[0][0] == 0 and r[-1][1] == 112 and all(a[1] == b[0] for a, b in zip(r, r[1:]))
         assert all(a in offs + [112] for a, _ in r) and len(r) <= max(1, nb) + 1
+
+
+# ---- bench.py's own launcher: `python bench.py --gpus N` must start N ranks (round-1 verdict: it ran one) -------------
+def _run_bench(args, env_extra):
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + args, env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_launcher_starts_n_ranks_gloo():
+    """--gpus 2 with no WORLD_SIZE in the environment: bench.py re-executes itself under torch.distributed.run with two
+    ranks; both rendezvous (gloo here, RCCL on the GPU box), barrier and reduce, and the line reports the world that ran."""
+    import json
+    r = _run_bench(['--gpus', '2', '--launch-check'], {'YOLO_BENCH_BACKEND': 'gloo'})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d == {'launch_check': True, 'n_gpus': 2, 'world': 2, 'max': 2.0, 'ranks': [0, 1], 'backend': 'gloo'}
+
+
+def test_bench_refuses_fewer_gpus_than_asked():
+    """On a box with fewer GPUs than --gpus the run fails loudly instead of printing an N-GPU line from one rank."""
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip('needs a box with fewer than 2 GPUs')
+    r = _run_bench(['--gpus', '2', '--steps', '1', '--warmup', '0'], {})
+    assert r.returncode != 0 and not any(l.startswith('{') for l in r.stdout.splitlines())
+    assert 'GPU' in r.stderr
+
+
+def test_bench_rejects_world_size_mismatch():
+    r = _run_bench(['--gpus', '4', '--launch-check'], {'YOLO_BENCH_BACKEND': 'gloo', 'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert r.returncode != 0 and 'WORLD_SIZE 1 != --gpus 4' in r.stderr

@@ -169,25 +169,37 @@ extern "C" int yolo_predict_top1(const float* out, float* pred, int* best_idx, i
     return YOLO_OK;
 }
 
-// ---- get_iou(predict, target, mode=2), yolo_gluon.py:127-168 ---------------------------------
+// ---- get_iou(predict, target, mode), yolo_gluon.py:127-168 ------------------------------------
+// MODE 2: target = [c, y, x, h, w] (the hot path: car/YOLO.py:403,525).  MODE 1 (the reference's default): target =
+// [c, l, t, r, b] -- including its target_area = target[3] * target[4] (yolo_gluon.py:166), i.e. r2 * b2 in this mode.
+template <int MODE>
 __global__ void iou_kernel(const float* __restrict__ boxes, const float* __restrict__ target,
                            float* __restrict__ iou, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float ty = target[1], tx = target[2], th = target[3], tw = target[4];
-    const float l2 = tx - tw / 2.f, t2 = ty - th / 2.f, r2 = tx + tw / 2.f, b2 = ty + th / 2.f;
+    const float t1 = target[1], t2_ = target[2], t3 = target[3], t4 = target[4];
+    float l2, t2, r2, b2;
+    if (MODE == 1) { l2 = t1; t2 = t2_; r2 = t3; b2 = t4; }
+    else { l2 = t2_ - t4 / 2.f; t2 = t1 - t3 / 2.f; r2 = t2_ + t4 / 2.f; b2 = t1 + t3 / 2.f; }
     const float4 p = ((const float4*)boxes)[i];     // l,t,r,b
     const float iw = fmaxf(fminf(r2, p.z) - fmaxf(l2, p.x), 0.f);
     const float ih = fmaxf(fminf(b2, p.w) - fmaxf(t2, p.y), 0.f);
     const float inter = iw * ih;
     const float pa = (p.z - p.x) * (p.w - p.y);
-    const float ta = th * tw;
+    const float ta = t3 * t4;
     iou[i] = inter / (pa + ta - inter);
 }
 
 extern "C" int yolo_iou_ltrb_vs_yxhw(const float* boxes, const float* target, float* iou, int n, void* stream) {
     if (!boxes || !target || !iou || n <= 0) return YOLO_EINVAL;
-    YOLO_LAUNCH(iou_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, boxes, target, iou, n);
+    YOLO_LAUNCH(iou_kernel<2>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, boxes, target, iou, n);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}
+
+extern "C" int yolo_iou_ltrb_vs_cltrb(const float* boxes, const float* target, float* iou, int n, void* stream) {
+    if (!boxes || !target || !iou || n <= 0) return YOLO_EINVAL;
+    YOLO_LAUNCH(iou_kernel<1>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, boxes, target, iou, n);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }

@@ -125,14 +125,18 @@ class Detector(object):
         return kept, ks, cnt
 
 
-def get_iou(predict, target, mode=2):
-    """yolo_gluon.get_iou (mode 2: target = [c, y, x, h, w]); predict (...,4) ltrb CUDA float32."""
-    if mode != 2:
-        raise NotImplementedError('only mode=2 is on the hot path (car/YOLO.py:403,525)')
+def get_iou(predict, target, mode=1):
+    """yolo_gluon.get_iou (yolo_gluon.py:127-168): predict (...,4) ltrb CUDA float32 vs ONE target (5,).
+    mode 1 (the reference's default): target = [c, l, t, r, b], with the reference's target_area = target[3] *
+    target[4] (:166) kept; mode 2 (what the hot path passes, car/YOLO.py:403,525): target = [c, y, x, h, w]."""
+    if mode not in (1, 2):
+        raise ValueError('mode should be int 1 or 2')              # (the reference only prints this, then fails on l2)
     p = predict.contiguous().view(-1, 4)
     t = target.to(p.device, torch.float32).contiguous()
     out = torch.empty((p.shape[0],), dtype=torch.float32, device=p.device)
-    L.check(L.load().yolo_iou_ltrb_vs_yxhw(L.ptr(p), L.ptr(t), L.ptr(out), p.shape[0], L.stream_ptr()), 'iou')
+    lib = L.load()
+    fn = lib.yolo_iou_ltrb_vs_cltrb if mode == 1 else lib.yolo_iou_ltrb_vs_yxhw
+    L.check(fn(L.ptr(p), L.ptr(t), L.ptr(out), p.shape[0], L.stream_ptr()), 'iou')
     return out.view(tuple(predict.shape[:-1]) + (1,))
 
 

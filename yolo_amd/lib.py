@@ -57,6 +57,7 @@ SIGNATURES = {
     'yolo_predict_lp': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp]),
     'yolo_predict_lp_nhwc': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp]),
     'yolo_iou_ltrb_vs_yxhw': (_i, [_vp, _vp, _vp, _i, _vp]),
+    'yolo_iou_ltrb_vs_cltrb': (_i, [_vp, _vp, _vp, _i, _vp]),
     'yolo_nms_workspace_bytes': (_ll, [_i, _i, _i, _i, _i]),
     'yolo_nms_scores': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'yolo_nms_select_workspace_bytes': (_ll, [_i]),

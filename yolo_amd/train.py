@@ -360,7 +360,10 @@ class Trainer(object):
                 torch.cuda.current_stream().wait_event(done)
                 self.buckets.done(names)
 
-    def _backward(self, P, exchange=True):
+    def _backward(self, P, exchange=True, capture=None):
+        """capture: optional dict that receives, per conv name, the gradient w.r.t. the layer output as the layer saw it
+        (`dz`, a copy: the buffer is re-used as the residual branch's gradient) and w.r.t. the raw convolution output
+        (`dy`) -- parity tests re-derive every gradient of the step from them (tests/test_gpu_configs.py)."""
         lib, st = self.lib, L.stream_ptr()
         g = self.net.graph
         self.gflat.zero_()
@@ -405,6 +408,8 @@ class Trainer(object):
                                               L.ptr(p[c.name + '.gamma']), L.ptr(p[c.name + '.beta']), L.ptr(dy),
                                               L.ptr(self.gview[c.name + '.gamma']), L.ptr(self.gview[c.name + '.beta']),
                                               L.ptr(self.ws), npix, c.cout, LEAKY_SLOPE, self.ldt, st), 'bn bwd ' + c.name)
+                if capture is not None:
+                    capture[c.name] = dict(dz=dz.clone(), dy=dy)
                 if op['res'] is not None:
                     self._accum(op['res'], dz)          # the residual branch receives dz unchanged
                 N, Hh, Ww, Cx = xin.shape
@@ -427,7 +432,7 @@ class Trainer(object):
             torch.cuda.current_stream().wait_stream(self._side)
 
     # ---- one training step -----------------------------------------------------------------------------------
-    def train_step(self, images, labels, global_batch=None, update=True, lp_labels=None):
+    def train_step(self, images, labels, global_batch=None, update=True, lp_labels=None, capture=None):
         """images (B,3,H,W) float32 CUDA; labels (B,nobj,6+ncls) float32 CUDA [cls,y,x,h,w,rot,dist...],
         cls < 0 = no object.  Returns losses (5,B) [score, box_yx, box_hw, rotate, class] (device)."""
         lib, st = self.lib, L.stream_ptr()
@@ -475,7 +480,7 @@ class Trainer(object):
                                              LPC, nlp, l5, self.lp_pos_w, self.lp_neg_w, st), 'lp loss')
             losses = torch.cat([losses, lp_losses], dim=0)
             self._last = (P, rec, lrec)
-        self._backward(P, exchange=update)
+        self._backward(P, exchange=update, capture=capture)
         if update:
             self.buckets.wait()                                    # KVStore sum-reduce of trainer.step (RCCL), bucketed
             if global_batch is None:
