@@ -96,6 +96,16 @@ int yolo_stem_conv_fwd(const float* x_nchw, const float* w_oihw, const float* sc
                        void* y, int N, int H, int W, int Cin, int Cout, int dtype, float slope,
                        void* stream);
 
+/* One DarknetBasicBlockV3 (basic_yolo.py:26; gluoncv darknet.py: x + conv3x3(C)(conv1x1(C/2)(x)), each conv with
+ * folded BN + LeakyReLU, no activation after the add) as ONE inference kernel for the first stages: x, y (N,H,W,C)
+ * bf16 NHWC; w1_packed / w2_packed = yolo_pack_conv_weights images of the (C/2,C,1,1) and (C,C/2,3,3) convs; scale /
+ * bias = yolo_fold_bn of each layer.  The C/2-channel map between the two convs stays in LDS and x is read once.  Same
+ * rounding points as yolo_conv_fwd run twice (mid rounded to bf16 once; residual added in fp32 before the output's
+ * one rounding).  YOLO_BF16 and C in {64, 128} only (YOLO_EUNSUPPORTED otherwise: run the two layers separately). */
+int yolo_res_block_fwd(const void* x, const void* w1_packed, const float* scale1, const float* bias1,
+                       const void* w2_packed, const float* scale2, const float* bias2, void* y, int N, int H, int W,
+                       int C, int dtype, float slope, void* stream);
+
 /* The first TWO layers fused for inference: the stem above and the first stage's down-sampling _conv2d (basic_yolo.py:24,
  * Conv3x3 s2 p1, C1 -> C2) + folded BN + LeakyReLU -> y (N,(H-1)/2+1,(W-1)/2+1,C2) bf16 NHWC; the full-resolution
  * C1-channel map between them stays in LDS.  w1_oihw (C1,3,3,3) float32; w2_packed = yolo_pack_conv_weights image of

@@ -328,18 +328,34 @@ def train_step_reference_lp(g, P, x, labels, lp_labels, spec, size, scale=DEFAUL
 # autograd graph (car/YOLO.py:381-392; gluoncv _conv2d = Convolution -> BatchNorm(train) -> LeakyReLU(0.1), SURVEY
 # App. A.1/A.3) given the values the layer under test itself saved: errors cannot accumulate across layers and every
 # gradient of the step can be held to a tight bar.
-def bn_act_backward(yraw, gamma, beta, dz, eps=1e-5, slope=0.1):
+def bn_act_backward(yraw, gamma, beta, dz, eps=1e-5, slope=0.1, flip=None):
     """Backward of train-mode BatchNorm (biased batch variance) + LeakyReLU at the saved raw convolution output `yraw`
-    (B,C,H,W).  Returns (z, dy, dgamma, dbeta); a residual branch adds to z and receives dz unchanged."""
-    y = torch.as_tensor(yraw).detach().clone().requires_grad_(True)
-    g = torch.as_tensor(gamma).detach().clone().requires_grad_(True)
-    b = torch.as_tensor(beta).detach().clone().requires_grad_(True)
-    mean = y.mean(dim=(0, 2, 3))
-    var = y.var(dim=(0, 2, 3), unbiased=False)
-    a = (y - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + eps) * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
-    z = torch.nn.functional.leaky_relu(a, slope)
-    z.backward(torch.as_tensor(dz))
-    return z.detach(), y.grad, g.grad, b.grad
+    (B,C,H,W), evaluated in float64.  Returns (z, dy, dgamma, dbeta, a) with a = the BatchNorm output (the LeakyReLU
+    input); a residual branch adds to z and receives dz unchanged.
+
+    flip: optional bool mask of elements whose LeakyReLU derivative is taken on the OTHER side of the kink.  An element
+    whose `a` is within rounding of zero lands on either side depending on the operation order of the implementation
+    under test; the caller passes the (few, checked to be near-kink) elements where that happened so that dy, dgamma
+    and dbeta are compared for the same branch decisions."""
+    y = torch.as_tensor(yraw).double()
+    g = torch.as_tensor(gamma).double().view(1, -1, 1, 1)
+    b = torch.as_tensor(beta).double().view(1, -1, 1, 1)
+    dz = torch.as_tensor(dz).double()
+    mean = y.mean(dim=(0, 2, 3), keepdim=True)
+    var = y.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+    invstd = 1.0 / torch.sqrt(var + eps)
+    xhat = (y - mean) * invstd
+    a = xhat * g + b
+    z = torch.where(a > 0, a, a * slope)
+    d = torch.where(a > 0, torch.ones_like(a), torch.full_like(a, slope))
+    if flip is not None:
+        d = torch.where(torch.as_tensor(flip), (1.0 + slope) - d, d)
+    da = dz * d
+    dbeta = da.sum(dim=(0, 2, 3))
+    dgamma = (da * xhat).sum(dim=(0, 2, 3))
+    n = y.shape[0] * y.shape[2] * y.shape[3]
+    dy = g * invstd * (da - dbeta.view(1, -1, 1, 1) / n - xhat * dgamma.view(1, -1, 1, 1) / n)
+    return z, dy, dgamma, dbeta, a
 
 
 def conv_backward(x, w, dy, stride):

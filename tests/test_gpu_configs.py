@@ -35,22 +35,24 @@ def _rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-def _rel_but_flips(a, b, tol, frac=2e-5):
-    """Max error relative to the scale, after setting aside the few elements whose LeakyReLU' sign differs: an
-    element whose BatchNorm output is within fp32 rounding of zero lands on either side of the kink depending on the
-    operation order, and its gradient then differs tenfold -- legitimate fp32 behaviour, not an error.  At most `frac`
-    of the elements may be set aside."""
-    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
-    err = (a - b).abs() / (b.abs().max() + 1e-30)
+def _kink_flips(dy, dy_ref, a_ref, tol, frac=2e-5):
+    """Elements where the implementation took the other LeakyReLU branch than the float64 reference: their dy is off by
+    the kink's factor.  Legitimate only for elements whose BatchNorm output is within rounding of zero -- checked -- and
+    only for a handful of them."""
+    err = (dy.double() - dy_ref).abs() / (dy_ref.abs().max() + 1e-30)
     bad = err > tol
-    assert float(bad.double().mean()) <= frac, 'too many elements off: %d of %d' % (int(bad.sum()), bad.numel())
-    return float(err[~bad].max())
+    if bool(bad.any()):
+        assert float(bad.double().mean()) <= frac, 'too many elements off: %d of %d' % (int(bad.sum()), bad.numel())
+        assert float(a_ref[bad].abs().max()) <= 2e-5 * float(a_ref.abs().max()), 'an element far from the kink is off'
+    return bad
 
 
-def _one_hop_check(tr, P, cap, params, tol, tol_w, rb):
+def _one_hop_check(tr, P, cap, params, tol, tol_w, rb, exact_kink=True):
     """Every forward value and every gradient of the step against its one-hop reference.  rb: the rounding the HIP path
-    applies when it stores an activation (identity for fp32, bf16 round for bf16)."""
+    applies when it stores an activation (identity for fp32, bf16 round for bf16).  exact_kink: resolve LeakyReLU
+    branch decisions at the kink element by element (fp32); in bf16 the stored rounding hides them below the bar."""
     grads = tr.grads()
+    nflip = [0]
     consumers = {}
     for op in P.fwd:
         for k in ('x', 'res', 'up', 'route'):
@@ -102,14 +104,20 @@ def _one_hop_check(tr, P, cap, params, tol, tol_w, rb):
             # forward, one hop: the raw convolution of the saved input, BN + LeakyReLU (+ residual) of the saved raw output
             note('conv fwd', c.name, _rel(yraw, rb(F.conv2d(x, rb(w), None, stride=c.stride, padding=c.k // 2))), tol)
             dz = _nchw(cap[c.name]['dz'])
-            zref, dy_ref, dg_ref, db_ref = ot.bn_act_backward(yraw, params[c.name + '.gamma'].cpu(), params[c.name + '.beta'].cpu(), dz)
+            gam, bet = params[c.name + '.gamma'].cpu(), params[c.name + '.beta'].cpu()
+            zref, dy_ref, dg_ref, db_ref, aref = ot.bn_act_backward(yraw, gam, bet, dz)
             if op['res'] is not None:
-                zref = zref + _nchw(op['res'].val)
-            note('bn fwd', c.name, _rel(_nchw(z.val), rb(zref)), tol)
-            np.testing.assert_allclose(op['mean'].cpu().numpy(), yraw.mean(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-5)
-            # backward, one hop
+                zref = zref + _nchw(op['res'].val).double()
+            note('bn fwd', c.name, _rel(_nchw(z.val), rb(zref.float())), tol)
+            np.testing.assert_allclose(op['mean'].cpu().numpy(), yraw.double().mean(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-5)
+            # backward, one hop (for the branch decisions the implementation took at the kink of LeakyReLU)
             dy = _nchw(cap[c.name]['dy'])
-            note('bn bwd dy', c.name, _rel_but_flips(dy, rb(dy_ref), tol), tol)
+            if exact_kink:
+                flips = _kink_flips(dy, dy_ref, aref, tol)
+                if bool(flips.any()):
+                    nflip[0] += int(flips.sum())
+                    _, dy_ref, dg_ref, db_ref, _ = ot.bn_act_backward(yraw, gam, bet, dz, flip=flips)
+            note('bn bwd dy', c.name, _rel(dy, rb(dy_ref.float())), tol)
             note('dgamma', c.name, _rel(grads[c.name + '.gamma'].cpu(), dg_ref), tol_w)
             note('dbeta', c.name, _rel(grads[c.name + '.beta'].cpu(), db_ref), tol_w)
             dw_ref = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride=c.stride, padding=c.k // 2)
@@ -126,6 +134,7 @@ def _one_hop_check(tr, P, cap, params, tol, tol_w, rb):
             note('dbias', c.name, _rel(grads[c.name + '.bias'].cpu(), dyp.sum(dim=(0, 1, 2)).cpu()), tol_w)
         else:
             note('dgrad (d/dcat)', 'upcat', _rel(_nchw(op['cat'].grad), rb(grad_ref(op['cat']))), tol)
+    worst['kink flips'] = (nflip[0], '')
     return worst
 
 

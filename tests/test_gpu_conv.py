@@ -3,7 +3,9 @@ restatement of Convolution + folded BatchNorm + LeakyReLU (+ residual)."""
 import numpy as np
 import pytest
 
-from util import run_conv, ref_conv
+import torch
+from util import run_conv, ref_conv, to_nhwc, from_nhwc
+from yolo_amd import lib as L
 
 pytestmark = pytest.mark.gpu
 
@@ -279,3 +281,60 @@ def test_conv_pipe_1x1_short_k(lib, cuda, algo, cin):
     ref = ref_conv(x, w, scale, bias, 1, 0.1, residual=r, bf16=True)
     assert not np.isnan(y).any()
     np.testing.assert_allclose(y, ref, rtol=1.6e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize('case', [(2, 37, 70, 64), (1, 20, 130, 128), (3, 5, 62, 64), (1, 40, 8, 128), (2, 52, 104, 128),
+                                  (1, 33, 63, 64), (1, 64, 208, 64)])
+def test_res_block_fused(lib, cuda, case):
+    """yolo_res_block_fwd (one DarknetBasicBlockV3 of the first stages as one kernel) against the torch reference on the
+    bf16-rounded operands with the HIP path's rounding points, and against the two separate HIP layers: several strips
+    (balanced, ragged), several row slices, image edges on every side."""
+    import ctypes as C
+    N, H, W, Cc = case
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((N, Cc, H, W)).astype(np.float32)
+    w1 = (rng.standard_normal((Cc // 2, Cc, 1, 1)) / np.sqrt(Cc)).astype(np.float32)
+    w2 = (rng.standard_normal((Cc, Cc // 2, 3, 3)) / np.sqrt(Cc // 2 * 9)).astype(np.float32)
+    s1, b1 = rng.uniform(.5, 1.5, Cc // 2).astype(np.float32), (.3 * rng.standard_normal(Cc // 2)).astype(np.float32)
+    s2, b2 = rng.uniform(.5, 1.5, Cc).astype(np.float32), (.3 * rng.standard_normal(Cc)).astype(np.float32)
+    mid = ref_conv(x, w1, s1, b1, 1, 0.1, bf16=True)
+    ref = ref_conv(mid, w2, s2, b2, 1, 0.1, residual=x, bf16=True)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def pack(w):
+        co, ci, k, _ = w.shape
+        wp = torch.empty(lib.yolo_packed_weight_bytes(co, ci, k, L.BF16), dtype=torch.uint8, device=cuda)
+        L.check(lib.yolo_pack_conv_weights(torch.from_numpy(w).to(cuda).data_ptr(), wp.data_ptr(), co, ci, k, L.BF16, st), 'pack')
+        return wp
+
+    def padded(v):
+        t = torch.zeros(lib.yolo_padded_channels(len(v)), device=cuda)
+        t[:len(v)] = torch.from_numpy(v).to(cuda)
+        return t
+
+    wp1, wp2 = pack(w1), pack(w2)
+    ts1, tb1, ts2, tb2 = padded(s1), padded(b1), padded(s2), padded(b2)
+    xd = to_nhwc(x, 'bf16', cuda)
+    y = torch.full((N, H, W, Cc), float('nan'), dtype=torch.bfloat16, device=cuda)
+    rc = lib.yolo_res_block_fwd(xd.data_ptr(), wp1.data_ptr(), ts1.data_ptr(), tb1.data_ptr(), wp2.data_ptr(), ts2.data_ptr(),
+                                tb2.data_ptr(), y.data_ptr(), N, H, W, Cc, L.BF16, 0.1, st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = from_nhwc(y)
+    assert np.isfinite(got).all()
+    # one bf16 ulp of the output (the mid map may differ from the reference's by one rounding, too)
+    np.testing.assert_allclose(got, ref, rtol=2e-2, atol=3e-2)
+    assert np.abs(got - ref).mean() < 2e-3
+    # the two separate layers through yolo_conv_fwd: same operands and rounding points -> equal up to fp32 summation order
+    mid_h = run_conv(lib, cuda, x, w1, s1, b1, 1, 0.1, 'bf16')
+    sep = run_conv(lib, cuda, mid_h, w2, s2, b2, 1, 0.1, 'bf16', residual=x)
+    assert np.mean(got != sep) < 2e-3 and np.abs(got - sep).max() < 0.07
+
+
+def test_res_block_rejects(lib, cuda):
+    buf = torch.zeros(1 << 16, device=cuda)
+    p = buf.data_ptr()
+    assert lib.yolo_res_block_fwd(p, p, p, p, p, p, p, p, 1, 8, 8, 256, L.BF16, 0.1, None) == L.EUNSUPPORTED
+    assert lib.yolo_res_block_fwd(p, p, p, p, p, p, p, p, 1, 8, 8, 64, L.F32, 0.1, None) == L.EUNSUPPORTED
+    assert lib.yolo_res_block_fwd(p, None, p, p, p, p, p, p, 1, 8, 8, 64, L.BF16, 0.1, None) == L.EINVAL
+    assert lib.yolo_res_block_fwd(p, p, p, p, p, p, p, p, 1, 8, 8, 64, L.BF16, 1.5, None) == L.EINVAL

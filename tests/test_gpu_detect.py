@@ -67,16 +67,16 @@ def test_iou(cuda):
     steps = od.init_steps(SPEC['layers'], SPEC['all_anchors'])
     ltrb = od.get_default_ltrb((416, 416), steps, SPEC['all_anchors'])
     target = np.asarray([3, 0.41, 0.52, 0.33, 0.27], np.float32)
-    got = get_iou(torch.from_numpy(ltrb).to(cuda), torch.from_numpy(target)).cpu().numpy()
+    got = get_iou(torch.from_numpy(ltrb).to(cuda), torch.from_numpy(target), mode=2).cpu().numpy()
     ref = od.get_iou(ltrb, target, mode=2)
     np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-7)
     assert int(np.argmax(got.reshape(-1))) == int(np.argmax(ref.reshape(-1)))
     # IoU(self) == 1, disjoint == 0
     box = np.asarray([[0.1, 0.2, 0.4, 0.6]], np.float32)
     t_self = np.asarray([0, 0.4, 0.25, 0.4, 0.3], np.float32)
-    assert abs(float(get_iou(torch.from_numpy(box).to(cuda), torch.from_numpy(t_self))[0, 0]) - 1.0) < 1e-6
+    assert abs(float(get_iou(torch.from_numpy(box).to(cuda), torch.from_numpy(t_self), mode=2)[0, 0]) - 1.0) < 1e-6
     t_far = np.asarray([0, 0.9, 0.9, 0.05, 0.05], np.float32)
-    assert float(get_iou(torch.from_numpy(box).to(cuda), torch.from_numpy(t_far))[0, 0]) == 0.0
+    assert float(get_iou(torch.from_numpy(box).to(cuda), torch.from_numpy(t_far), mode=2)[0, 0]) == 0.0
 
 
 @pytest.mark.parametrize('mode', ['obj', 'class'])

@@ -48,7 +48,7 @@ def test_detect_vs_golden(cuda):
     assert k[0, :int(c[0])].cpu().tolist() == z['kept_cls'].tolist()
     np.testing.assert_allclose(s[0, :int(c[0])].cpu().numpy(), z['score_cls'], rtol=2e-5)
     ltrb = od.get_default_ltrb(size, steps, spec['all_anchors'])
-    iou = get_iou(torch.from_numpy(ltrb).to(cuda), torch.from_numpy(z['target'])).cpu().numpy().reshape(-1)
+    iou = get_iou(torch.from_numpy(ltrb).to(cuda), torch.from_numpy(z['target']), mode=2).cpu().numpy().reshape(-1)
     assert int(np.argmax(iou)) == int(z['iou_argmax'][0])
     np.testing.assert_allclose(iou[z['sel']], z['iou_sel'], rtol=1e-6, atol=1e-7)
 

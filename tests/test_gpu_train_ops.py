@@ -68,7 +68,10 @@ def test_dgrad(lib, cuda, case):
     np.testing.assert_allclose(from_nhwc(out), 2 * dx_ref, rtol=1e-3, atol=2e-3 * np.abs(dx_ref).max())
 
 
-@pytest.mark.parametrize('shape', [(2, 8, 12, 128), (3, 13, 13, 64), (1, 4, 6, 32), (4, 32, 48, 16), (2, 5, 7, 2048 + 64)])
+@pytest.mark.parametrize('shape', [(2, 8, 12, 128), (3, 13, 13, 64), (1, 4, 6, 32), (4, 32, 48, 16), (2, 5, 7, 2048 + 64),
+                                   # D53 shapes: the widest map (one 256-channel group, many pixel ranges) and the widest
+                                   # layer over the smallest map (eight channel groups)
+                                   (2, 208, 208, 64), (8, 13, 13, 2048), (8, 52, 52, 256)])
 @pytest.mark.parametrize('with_res', [False, True])
 def test_bn_train_fwd_bwd(lib, cuda, shape, with_res):
     N, H, W, Cc = shape
@@ -132,7 +135,14 @@ def test_upcat_bwd(lib, cuda):
                                   (3, 128, 13, 13, 96, 3, 1), (2, 72, 17, 19, 200, 3, 1), (2, 128, 11, 26, 64, 3, 1),
                                   (1, 80, 9, 38, 72, 3, 1), (1, 96, 7, 32, 64, 3, 1), (1, 128, 5, 40, 64, 3, 1),
                                   (2, 128, 6, 16, 64, 3, 1), (1, 72, 3, 64, 64, 3, 1), (1, 72, 4, 100, 64, 3, 1),
-                                  (70, 128, 13, 13, 128, 3, 1)])
+                                  (70, 128, 13, 13, 128, 3, 1),
+                                  # the D53 layer shapes of BASELINE configs[2] themselves (416x416; batch 8): the strip kernel
+                                  # at 416^2 / 208^2, the split-pixel-range atomics of the per-tap kernel, the row groups at
+                                  # 52^2 / 26^2 / 13^2, the widest 1x1 and 3x3 layers
+                                  (8, 8, 416, 416, 32, 3, 1), (8, 32, 416, 416, 64, 3, 2), (8, 64, 208, 208, 32, 1, 1),
+                                  (8, 32, 208, 208, 64, 3, 1), (8, 64, 208, 208, 128, 3, 2), (8, 128, 52, 52, 256, 3, 1),
+                                  (8, 256, 52, 52, 128, 1, 1), (8, 256, 26, 26, 512, 3, 1), (8, 512, 13, 13, 1024, 3, 1),
+                                  (8, 1024, 13, 13, 2048, 3, 1), (8, 2048, 13, 13, 1024, 1, 1), (8, 512, 26, 26, 1024, 3, 2)])
 def test_wgrad_bf16_transposing_reads(lib, cuda, case):
     """bf16 weight gradient (MFMA 32x32x16 fed by ds_read_b64_tr_b16): exact fp32 accumulation of the
     bf16-rounded operands, so it must match torch on the rounded inputs to fp32 noise."""

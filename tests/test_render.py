@@ -10,11 +10,28 @@ CLASSES = [[15.0 * i, 0.0] for i in range(24)]
 
 
 def test_label_dist_and_label_row():
-    from oracle import train as ot
+    """get_label_dist (car/render_car.py:410-438) against answers worked out by hand.  On the equator (elevation 0, all
+    24 classes at elevation 0, 15 degrees apart) the great-circle angle to class k is the azimuth difference, so for
+    azimuth 0 the distribution is exp(-(min(k, 24 - k) * pi / 12)^2 / 0.1), normalised."""
+    c, d = render.get_label_dist(0.0, 0.0, CLASSES)
+    k = np.arange(24)
+    g = np.exp(-(np.minimum(k, 24 - k) * math.pi / 12) ** 2 / 0.1)
+    assert c == 0 and d.dtype == np.float32 and d.shape == (24,)
+    np.testing.assert_allclose(d, g / g.sum(), rtol=2e-5, atol=1e-9)
+    # the three largest entries as plain numbers: 1, e^-0.68539, e^-2.74156 over their sum 2.1410
+    np.testing.assert_allclose(d[[0, 1, 23, 2]], np.array([1.0, 0.503894, 0.503894, 0.064470]) / 2.140962, rtol=1e-4)
+    # azimuth 90 degrees = class 6: the same distribution rotated by six classes
+    c6, d6 = render.get_label_dist(0.0, math.pi / 2, CLASSES)
+    assert c6 == 6
+    np.testing.assert_allclose(d6, np.roll(d, 6), rtol=1e-4, atol=1e-9)
+    # at the pole every class direction is 90 degrees away: uniform, and the arg-min is the first class
+    cp, dp = render.get_label_dist(math.pi / 2, 1.234, CLASSES)
+    np.testing.assert_allclose(dp, np.full(24, 1 / 24.0), rtol=1e-5)
+    # half way between two classes: they share the top probability
+    ch, dh = render.get_label_dist(0.0, math.radians(7.5), CLASSES)
+    assert ch in (0, 1) and abs(float(dh[0]) - float(dh[1])) < 1e-6 and float(dh[0]) > float(dh[2])
     for ele, azi in ((0.0, 0.3), (0.1, 3.0), (0.0, 6.2)):
         c, d = render.get_label_dist(ele, azi, CLASSES)
-        c2, d2 = ot.get_label_dist(ele, azi, CLASSES)
-        assert c == c2 and np.array_equal(d, d2)
         assert abs(float(d.sum()) - 1.0) < 1e-6 and int(np.argmax(d)) == c
     c, d = render.get_label_dist(0.0, math.radians(44.0), CLASSES)
     assert c == 3                                                       # nearest of 0, 15, 30, 45, ...

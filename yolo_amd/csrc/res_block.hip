@@ -1,0 +1,297 @@
+// One DarknetBasicBlockV3 of the first two stages as ONE inference kernel (basic_yolo.py:26; gluoncv darknet.py:
+// x + conv3x3(2c)(conv1x1(c)(x)), each conv with folded BN + LeakyReLU, no activation after the add), bf16 NHWC,
+// for C = 2c in {64, 128}.
+//
+// Run as two kernels these blocks are HBM-bound three times over: the 1x1 reads x and writes the half-width map, the
+// 3x3 reads that map and x again (the residual) and writes the output -- 2.5x the bytes of "read x, write out", at the
+// largest maps of the network (15 % of the 608x608 pass).  Here the half-width map never leaves LDS and x is read once:
+//   * a block (4 waves) owns a column strip (<= 62 output pixels) of one image and walks down its output rows, as
+//     conv_stream_kernel / stem_down_kernel do; BOTH layers' weights stay in registers for the block's lifetime
+//     (C = 64: 4 + 18 A-fragments per wave; C = 128: 8 + 36);
+//   * input rows live in a 3-row rolling LDS ring (row oy: the residual of the output row; row oy + 1: the operand of the
+//     1x1 for the mid row the 3x3 needs next); the loads of the NEXT D - 1 rows are in flight in registers meanwhile (a
+//     row-step is a dependent chain load -> LDS -> 1x1 -> LDS -> 3x3 -> store of ~1.5k cycles, shorter than one HBM round
+//     trip under load: with one row in flight the kernel ran at the memory latency, 2.7 us per row-step);
+//   * the 1x1's output (mid) lives in a 3-row rolling LDS ring in the layout the 3x3 reads its B fragments from; it is
+//     COMPUTED there one row per step.  Mid pixels outside the image are written as zeros: they are the 3x3's zero
+//     padding, not conv1x1(padding);
+//   * the 3x3 epilogue (conv_stream's: transpose through a per-wave LDS scratch, 16-byte row stores) takes its residual
+//     from the input ring instead of reading x a second time.
+// Same packed weight images, operand rounding points (mid is rounded to bf16 once; the residual is added in fp32 before
+// the output's one rounding) and K order ((kh, kw, channel)) as conv_stream_kernel.
+#include "common.h"
+#include <stdio.h>
+
+namespace {
+constexpr int MW = 64;                   // mid / input row width in pixels (= 2 MFMA column groups); strip width <= MW - 2
+constexpr int SW_MAX = MW - 2;
+constexpr int SCR = 32 * 144;            // per-wave epilogue scratch: 32 pixel rows x (32 f32 + pad)
+
+struct ResArgs {
+    const char* x;
+    const char* wp1;
+    const float* scale1;
+    const float* bias1;
+    const char* wp2;
+    const float* scale2;
+    const float* bias2;
+    char* y;
+    int N, H, W, Cpad1, Cpad2;
+    int nstrips, strip_w, rows_per_slice;
+    float slope;
+};
+}  // namespace
+
+template <int C, int D>
+__global__ __launch_bounds__(256) void res_block_kernel(ResArgs a) {
+    constexpr int CM = C / 2;
+    constexpr int WAVES_C = C / 32, WAVES_P = 4 / WAVES_C, NI = 2 / WAVES_P;   // 3x3: wave = (cout slice, pixel group)
+    constexpr int MT1 = CM / 32;                                              // 1x1: cout slices of the mid row
+    constexpr int K1 = C / 16, K2 = CM / 16;                                  // k-steps of 16 channels
+    constexpr int PX = C * 2 + 16, PM = CM * 2 + 16;                          // pixel pitch in the rings (+16: conflict-free reads)
+    constexpr int XROW = MW * PX, MROW = (MW + 2) * PM;
+    constexpr int XU = MW * (C * 2 / 16) / 256;                               // 16-byte input loads per thread per row
+    static_assert(MW * (C * 2 / 16) % 256 == 0, "input row = whole passes of the block");
+    __shared__ __attribute__((aligned(16))) char smem[3 * XROW + 3 * MROW + 4 * SCR];
+    char* xl = smem;
+    char* ml = smem + 3 * XROW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wave_c = wave % WAVES_C, wave_p = wave / WAVES_C;
+    char* scr = smem + 3 * XROW + 3 * MROW + wave * SCR;
+
+    const int strip = blockIdx.x % a.nstrips;
+    const int n = blockIdx.x / a.nstrips;
+    const int ox0 = strip * a.strip_w;
+    const int ox_end = min(ox0 + a.strip_w, a.W);
+    const int oy0 = blockIdx.y * a.rows_per_slice;
+    const int oy1 = min(oy0 + a.rows_per_slice, a.H);
+    if (oy0 >= oy1) return;
+    const int H = a.H, W = a.W;
+    const int mx0 = ox0 - 1;                  // image column of ring pixel 0
+
+    // ---- hygiene: ring pixels that are never written are only read by lanes whose results are discarded ----------
+    for (int i = tid; i < (3 * XROW + 3 * MROW) / 16; i += 256) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
+
+    // ---- weights: A-fragments from the packed images (conv_stream's addressing) ----------------------------------
+    const int swz = (l31 >> 2) & 3;
+    uint4 A2[9 * K2];
+    {
+        const int row = wave_c * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 9 * K2; ++ks) {
+            const int tap = ks / K2, kc = ks % K2;
+            const int chunk = kc >> 1, unit = ((kc & 1) * 2 + h) ^ swz;
+            A2[ks] = *(const uint4*)(a.wp2 + ((long long)(chunk * 9 + tap) * a.Cpad2 + row) * 64 + unit * 16);
+        }
+    }
+    // 1x1: wave w produces mid tile (cout slice w % MT1, pixel group w / MT1); with MT1 == 1 only waves 0, 1 have one
+    const int m1 = wave % MT1, p1 = wave / MT1;
+    const bool has1 = p1 < 2;
+    uint4 A1[K1];
+    {
+        const int row = m1 * 32 + l31;
+#pragma unroll
+        for (int kc = 0; kc < K1; ++kc) {
+            const int chunk = kc >> 1, unit = ((kc & 1) * 2 + h) ^ swz;
+            A1[kc] = *(const uint4*)(a.wp1 + ((long long)chunk * a.Cpad1 + row) * 64 + unit * 16);
+        }
+    }
+    // folded BN of the 1x1 for the 16 mid channels a lane holds after its MFMAs (rows 8g + 4h + e of the slice)
+    float sc1[16], bi1[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 s4 = *(const f32x4*)(a.scale1 + m1 * 32 + 8 * g + 4 * h), b4 = *(const f32x4*)(a.bias1 + m1 * 32 + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc1[4 * g + e] = s4[e]; bi1[4 * g + e] = b4[e]; }
+    }
+    // 3x3 epilogue constants (after the transpose a lane owns 8 couts of a pixel row)
+    const int ecol = lane & 3, erow0 = lane >> 2;
+    const int eco = wave_c * 32 + ecol * 8;
+    float sc2[8], bi2[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const f32x4 s4 = *(const f32x4*)(a.scale2 + eco + 4 * q), b4 = *(const f32x4*)(a.bias2 + eco + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc2[4 * q + e] = s4[e]; bi2[4 * q + e] = b4[e]; }
+    }
+    const float slope = a.slope;
+
+    // ---- input rows: registers -> ring slot (row mod 3) ------------------------------------------------------------
+    uint4 xr[D][XU];                                        // register sets: rows oy+2 .. oy+D in flight (static indices only)
+    auto load_x = [&](uint4 (&r)[XU], int iy) {
+#pragma unroll
+        for (int j = 0; j < XU; ++j) {
+            const int u = tid + j * 256;
+            const int px = u / (C * 2 / 16), part = u % (C * 2 / 16);
+            const int ix = mx0 + px;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                v = *(const uint4*)(a.x + (((long long)n * H + iy) * W + ix) * (C * 2) + part * 16);
+            r[j] = v;
+        }
+    };
+    auto store_x = [&](const uint4 (&r)[XU], int slot) {
+#pragma unroll
+        for (int j = 0; j < XU; ++j) {
+            const int u = tid + j * 256;
+            const int px = u / (C * 2 / 16), part = u % (C * 2 / 16);
+            *(uint4*)(xl + slot * XROW + px * PX + part * 16) = r[j];
+        }
+    };
+    auto slot3 = [](int row) { return (row + 3) % 3; };       // rows >= -1
+    // ---- mid row my from the input ring: this wave's tile, BN + LeakyReLU, one rounding, zeros outside the image ---
+    auto mid_row = [&](int my) {
+        if (!has1) return;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const char* xp = xl + slot3(my) * XROW + (p1 * 32 + l31) * PX + h * 16;
+#pragma unroll
+        for (int kc = 0; kc < K1; ++kc) {
+            const uint4 bf = *(const uint4*)(xp + kc * 32);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A1[kc]), __builtin_bit_cast(bf16x8, bf), acc, 0, 0, 0);
+        }
+        const int px = p1 * 32 + l31;
+        const int mx = mx0 + px;
+        const bool inside = my >= 0 && my < H && mx >= 0 && mx < W;
+        char* dst = ml + slot3(my) * MROW + px * PM + m1 * 64;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = leaky(acc[4 * g + e] * sc1[4 * g + e] + bi1[4 * g + e], slope);
+            *(uint2*)(dst + (8 * g + 4 * h) * 2) = inside ? make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])) : make_uint2(0u, 0u);
+        }
+    };
+
+    __syncthreads();                                        // the zero fill
+    // ---- prologue: input rows oy0-1, oy0, oy0+1; mid rows oy0-1, oy0 --------------------------------------------------
+    load_x(xr[0], oy0 - 1);
+    load_x(xr[1 % D], oy0);
+    store_x(xr[0], slot3(oy0 - 1));
+    store_x(xr[1 % D], slot3(oy0));
+    load_x(xr[D - 1], oy0 + 1);
+    // rows oy0+2 .. oy0+D go into sets 0 .. D-2 (set of row r = (r - oy0 - 2) % D); step oy stores set (oy - oy0) % D and
+    // re-loads the set the previous step stored
+#pragma unroll
+    for (int k = 0; k < D - 1; ++k)
+        if (oy0 + 2 + k <= oy1) load_x(xr[k], oy0 + 2 + k);
+    __syncthreads();
+    mid_row(oy0 - 1);
+    mid_row(oy0);
+    store_x(xr[D - 1], slot3(oy0 + 1));
+    __syncthreads();
+
+    for (int oyb = oy0; oyb < oy1; oyb += D) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        const int oy = oyb + u;
+        if (oy >= oy1) break;
+        const bool more = oy + 1 < oy1;
+        if (oy + D + 1 <= oy1) load_x(xr[(u + D - 1) % D], oy + D + 1);     // D - 1 rows ahead of the row stored below
+        mid_row(oy + 1);
+        __syncthreads();
+
+        // ---- 3x3 over mid rows oy-1 .. oy+1: 9 taps x K2 k-steps, NI pixel groups per wave ----------------------------
+        f32x16 acc[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const char* rowp = ml + slot3(oy - 1 + kh) * MROW + (wave_p * NI * 32 + l31) * PM + h * 16;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int kc = 0; kc < K2; ++kc)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const uint4 bf = *(const uint4*)(rowp + (ni * 32 + kw) * PM + kc * 32);
+                        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A2[(kh * 3 + kw) * K2 + kc]),
+                                                                          __builtin_bit_cast(bf16x8, bf), acc[ni], 0, 0, 0);
+                    }
+        }
+        // ---- epilogue: folded BN, LeakyReLU, + x (from the input ring, fp32), one rounding, 16-byte row stores ---------
+        const char* xres = xl + slot3(oy) * XROW + eco * 2;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[ni][4 * g], acc[ni][4 * g + 1], acc[ni][4 * g + 2], acc[ni][4 * g + 3]};
+                *(f32x4*)(scr + l31 * 144 + (8 * g + 4 * h) * 4) = v;
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int px = (wave_p * NI + ni) * 32 + erow0 + 16 * k;          // output pixel of the strip
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f32x4 t4 = *(const f32x4*)(scr + (erow0 + 16 * k) * 144 + (ecol * 8 + 4 * q) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * q + e] = t4[e];
+                }
+                const uint4 rv = *(const uint4*)(xres + (px + 1) * PX);           // ring pixel px + 1 = image column ox0 + px
+                const uint32_t w[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = leaky(v[e] * sc2[e] + bi2[e], slope);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[2 * q] += bf16_bits_to_f32(w[q] & 0xffffu);
+                    v[2 * q + 1] += bf16_bits_to_f32(w[q] >> 16);
+                }
+                const int ox = ox0 + px;
+                if (ox < ox_end)
+                    *(uint4*)(a.y + ((((long long)n * H + oy) * W + ox) * C + eco) * 2) =
+                        make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+            }
+        }
+        if (more) store_x(xr[u], slot3(oy + 2));
+        __syncthreads();
+    }
+    }
+}
+
+template <int C, int D>
+static int launch_res_block(ResArgs& a, hipStream_t st) {
+    a.nstrips = (a.W + SW_MAX - 1) / SW_MAX;
+    a.strip_w = (a.W + a.nstrips - 1) / a.nstrips;               // balanced strips (<= 62)
+    const long long bx = (long long)a.N * a.nstrips;
+    if (bx > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
+    // row slices: a slice costs ~3.5 row-steps of prologue (ring fill, two extra mid rows, weights) and the launch runs in
+    // rounds of `slots` resident blocks (2 per CU for C = 64, 1 for C = 128): pick the slice count with the least
+    // rounds x (rows per slice + prologue)
+    const long long slots = (C == 64 ? 2 : 1) * 256;
+    long long best_s = 1;
+    double best_cost = 1e30;
+    for (long long sl = 1; sl <= (a.H >= 16 ? a.H / 8 : 1); ++sl) {
+        const long long rows = (a.H + sl - 1) / sl, nsl = (a.H + rows - 1) / rows;
+        const double cost = (double)((bx * nsl + slots - 1) / slots) * (double)(rows + 3.5);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best_s = nsl; }
+    }
+    a.rows_per_slice = (int)((a.H + best_s - 1) / best_s);
+    const long long slices = (a.H + a.rows_per_slice - 1) / a.rows_per_slice;
+    YOLO_LAUNCH((res_block_kernel<C, D>), dim3((unsigned)bx, (unsigned)slices), dim3(256), 0, st, a);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}
+
+// Fused residual block (inference): y = x + lrelu(bn2(conv3x3(lrelu(bn1(conv1x1(x)))))); x, y (N,H,W,C) bf16 NHWC;
+// w1_packed / w2_packed: yolo_pack_conv_weights images of the (C/2, C, 1, 1) and (C, C/2, 3, 3) convs; scale / bias:
+// yolo_fold_bn of each layer.  bf16, C in {64, 128} only (YOLO_EUNSUPPORTED otherwise: run the two layers separately).
+extern "C" int yolo_res_block_fwd(const void* x, const void* w1_packed, const float* scale1, const float* bias1,
+                                  const void* w2_packed, const float* scale2, const float* bias2, void* y, int N, int H,
+                                  int W, int C, int dtype, float slope, void* stream) {
+    if (!x || !w1_packed || !scale1 || !bias1 || !w2_packed || !scale2 || !bias2 || !y || N <= 0 || H <= 0 || W <= 0)
+        return YOLO_EINVAL;
+    if (!(slope >= 0.f && slope <= 1.f)) return YOLO_EINVAL;
+    if (dtype != YOLO_BF16 || (C != 64 && C != 128)) return YOLO_EUNSUPPORTED;
+    ResArgs a;
+    a.x = (const char*)x; a.wp1 = (const char*)w1_packed; a.scale1 = scale1; a.bias1 = bias1;
+    a.wp2 = (const char*)w2_packed; a.scale2 = scale2; a.bias2 = bias2; a.y = (char*)y;
+    a.N = N; a.H = H; a.W = W; a.slope = slope;
+    a.Cpad1 = round_up(C / 2, YOLO_COUT_PAD); a.Cpad2 = round_up(C, YOLO_COUT_PAD);
+    return C == 64 ? launch_res_block<64, 3>(a, (hipStream_t)stream) : launch_res_block<128, 3>(a, (hipStream_t)stream);
+}

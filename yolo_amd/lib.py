@@ -49,6 +49,7 @@ SIGNATURES = {
     'yolo_conv_kernel_name': (_i, [C.POINTER(ConvDesc), C.c_char_p, _i]),
     'yolo_stem_conv_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'yolo_stem_down_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'yolo_res_block_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'yolo_composite': (_i, [_vp, _vp, _vp, _vp, _ll, _vp]),
     'yolo_upsample2x_concat': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'yolo_decode': (_i, [_vp, _vp, _i, _i, C.POINTER(GridDesc), _vp]),

@@ -29,13 +29,14 @@ class _Plan(object):
         self.lp = None       # CarLPNet: (B, h, w, LP channels) float32
         self.offsets = None
         self.act = {}        # name -> (tensor, (N,H,W,C)) for parity taps
+        self.side = set()    # indices of ops that run on the side stream
 
 
 class CarNet(object):
     ALGOS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25)     # yolo_conv_desc.algo ids tried by tune='measure'
 
     def __init__(self, spec, num_sync_bn_devices=-1, dtype='bf16', device='cuda:0', tune='auto', tune_cache=None,
-                 fuse_stem=True):
+                 fuse_stem=True, side_stream=True, fuse_res=True):
         # num_sync_bn_devices is accepted for signature parity; the reference always passes -1
         # (no SyncBN, car/YOLO.py:94-96).
         if dtype not in _TORCH_DT:
@@ -51,6 +52,15 @@ class CarNet(object):
         # fuse_stem: run the stem and the first down-sampling conv as one kernel where yolo_stem_down_fwd takes the
         # shape (32 -> 64, bf16); the stem's own output is then not materialised (no 'stem' parity tap)
         self.fuse_stem = bool(fuse_stem)
+        # side_stream: a detection block's tip + output convolutions run on a second HIP stream, concurrently with the
+        # transition -> up-sample/concat -> first 1x1 chain of the next scale (both only read the block's route): the
+        # small kernels of that chain fill the CUs the 13x13 / 26x26 tip kernels leave idle
+        self.side_stream = bool(side_stream)
+        self._side = None
+        # fuse_res: run a residual block of the first stages (C = 64 / 128, bf16) as one kernel (yolo_res_block_fwd): the
+        # half-width map between its two convolutions stays in LDS and x is read once.  With tune='measure' the fused
+        # kernel is timed against the two separate layers and used where it wins.
+        self.fuse_res = bool(fuse_res)
         self._algo_cache = {}
         # optional JSON file remembering measured choices (so a profiled run launches only the chosen kernels)
         self._tune_cache = tune_cache
@@ -163,10 +173,70 @@ class CarNet(object):
     def _conv_op(self, plan, c, x, xshape, residual=None, out=None, out_f32=False, y_bs=0, y_ps=0, cin=None):
         N, H, W, _ = xshape
         ho, wo = c.out_hw(H, W)
-        wp, scale, bias = self._prepared[c.name]
         if out is None:
             out = torch.empty((N, ho, wo, c.cout), dtype=_TORCH_DT[self.dtype], device=self.device)
             plan.buffers.append(out)
+        d = self._conv_desc(c, x, xshape, out, residual, out_f32, y_bs, y_ps, cin)
+        if self.tune == 'measure':
+            d.algo = self._measure_algo(d)
+        plan.ops.append(('conv', d, c.name))
+        if not isinstance(out, int):
+            plan.act[c.name] = (out, (N, ho, wo, c.cout))
+        return out, (N, ho, wo, c.cout)
+
+    def _res_block_payload(self, c1, c2, x, out, shp):
+        wp1, s1, b1 = self._prepared[c1.name]
+        wp2, s2, b2 = self._prepared[c2.name]
+        return (L.ptr(x), L.ptr(wp1), L.ptr(s1), L.ptr(b1), L.ptr(wp2), L.ptr(s2), L.ptr(b2), L.ptr(out), shp[0], shp[1], shp[2], shp[3])
+
+    def _use_res_block(self, c1, c2, x, shp):
+        """Whether the residual block (c1: 1x1 C -> C/2, c2: 3x3 C/2 -> C, + x) runs as the fused kernel."""
+        C_ = shp[3]
+        if not (self.fuse_res and self.dtype == 'bf16' and C_ in (64, 128) and c1.bn and c2.bn
+                and (c1.k, c1.stride, c1.cin, c1.cout) == (1, 1, C_, C_ // 2) and (c2.k, c2.stride, c2.cin, c2.cout) == (3, 1, C_ // 2, C_)):
+            return False
+        if self.tune != 'measure':
+            return True
+        key = ('res', shp[0], shp[1], shp[2], C_)
+        if key in self._algo_cache:
+            return bool(self._algo_cache[key])
+        lib, st, dt = self._lib, L.stream_ptr(), _LIB_DT[self.dtype]
+        tdt = _TORCH_DT[self.dtype]
+        mid = torch.empty(shp[:3] + (C_ // 2,), dtype=tdt, device=self.device)
+        out = torch.empty(shp, dtype=tdt, device=self.device)
+        d1 = self._conv_desc(c1, x, shp, mid)
+        d2 = self._conv_desc(c2, mid, shp[:3] + (C_ // 2,), out, residual=x)
+        d1.algo, d2.algo = self._measure_algo(d1), self._measure_algo(d2)
+        pay = self._res_block_payload(c1, c2, x, out, shp)
+
+        def timed(fn, n=20):
+            fn(); fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / n
+
+        def separate():
+            L.check(lib.yolo_conv_fwd(C.byref(d1), st), 'conv')
+            L.check(lib.yolo_conv_fwd(C.byref(d2), st), 'conv')
+
+        fused_ok = lib.yolo_res_block_fwd(*pay, dt, LEAKY_SLOPE, st) == 0
+        use = fused_ok and timed(lambda: lib.yolo_res_block_fwd(*pay, dt, LEAKY_SLOPE, st)) < timed(separate)
+        self._algo_cache[key] = int(use)
+        self._save_tune_cache()
+        return use
+
+    def _save_tune_cache(self):
+        if self._tune_cache:
+            with open(self._tune_cache, 'w') as f:
+                json.dump({json.dumps(list(k)): v for k, v in self._algo_cache.items()}, f)
+
+    def _conv_desc(self, c, x, xshape, out, residual=None, out_f32=False, y_bs=0, y_ps=0, cin=None):
+        N, H, W, _ = xshape
+        wp, scale, bias = self._prepared[c.name]
         d = L.ConvDesc()
         d.x, d.w_packed, d.scale, d.bias = L.ptr(x), L.ptr(wp), L.ptr(scale), L.ptr(bias)
         d.residual = L.ptr(residual)
@@ -176,12 +246,7 @@ class CarNet(object):
         d.out_f32 = 1 if out_f32 else 0
         d.slope = LEAKY_SLOPE if c.bn else 1.0
         d.y_batch_stride, d.y_pixel_stride = y_bs, y_ps
-        if self.tune == 'measure':
-            d.algo = self._measure_algo(d)
-        plan.ops.append(('conv', d, c.name))
-        if not isinstance(out, int):
-            plan.act[c.name] = (out, (N, ho, wo, c.cout))
-        return out, (N, ho, wo, c.cout)
+        return d
 
     def _measure_algo(self, d, iters=5, fn=None, algos=None):
         """Fastest conv variant for this layer shape (cached).  Outputs are overwritten while timing,
@@ -218,9 +283,7 @@ class CarNet(object):
                 best, best_t = algo, t
         d.algo = 0
         self._algo_cache[key] = best
-        if self._tune_cache:
-            with open(self._tune_cache, 'w') as f:
-                json.dump({json.dumps(list(k)): v for k, v in self._algo_cache.items()}, f)
+        self._save_tune_cache()
         return best
 
     def _build_plan(self, B, H, W):
@@ -261,6 +324,13 @@ class CarNet(object):
             if down is not fused_down:
                 x, shp = self._conv_op(plan, down, x, shp)
             for c1, c2 in res:
+                if self._use_res_block(c1, c2, x, shp):
+                    out = torch.empty(shp, dtype=tdt, device=self.device)
+                    plan.buffers.append(out)
+                    plan.ops.append(('res_block', self._res_block_payload(c1, c2, x, out, shp), c2.name))
+                    plan.act[c2.name] = (out, shp)
+                    x = out
+                    continue
                 mid, mshp = self._conv_op(plan, c1, x, shp)
                 x, shp = self._conv_op(plan, c2, mid, mshp, residual=x)
             if i >= nst - g.num_pyramid:
@@ -287,12 +357,15 @@ class CarNet(object):
             for c in body:
                 x, shp = self._conv_op(plan, c, x, shp)
             route, rshp = x, shp
+            first_side = len(plan.ops)
             t, tshp = self._conv_op(plan, tip, route, rshp)
             k = len(g.heads) - 1 - i                        # position of this scale in fine->coarse order
             yptr = plan.merged.data_ptr() + offs[k] * AC * 4
             self._conv_op(plan, outc, t, tshp, out=yptr, out_f32=True, y_bs=tot * AC, y_ps=AC)
             if i >= len(g.heads) - 1:
                 break
+            if self.side_stream:
+                plan.side.update(range(first_side, len(plan.ops)))
             x, shp = self._conv_op(plan, g.transitions[i], route, rshp)
             r, rs = routes[::-1][i + 1]
             cat = torch.empty((rs[0], rs[1], rs[2], shp[3] + rs[3]), dtype=tdt, device=self.device)
@@ -322,10 +395,13 @@ class CarNet(object):
         lib, st, dt = self._lib, L.stream_ptr(), _LIB_DT[self.dtype]
         if plan.x_nhwc is not None:
             L.check(lib.yolo_nchw_to_nhwc(x.data_ptr(), L.ptr(plan.x_nhwc), B, 3, H, W, 8, dt, st), 'nchw_to_nhwc')
-        for kind, payload, name in plan.ops:
-            rc = self._launch(kind, payload, x, st, dt)
-            if rc:
-                raise L.YoloError('%s (%s) failed with status %d' % (kind, name, rc))
+        if plan.side:
+            self._run_two_streams(plan, x, dt)
+        else:
+            for kind, payload, name in plan.ops:
+                rc = self._launch(kind, payload, x, st, dt)
+                if rc:
+                    raise L.YoloError('%s (%s) failed with status %d' % (kind, name, rc))
         self._last_plan = plan
         A = self.graph.heads[0][3]
         outs = [plan.merged[:, o:o + n].view(B, n, A, self.graph.per_anchor) for o, n in plan.offsets]
@@ -334,6 +410,30 @@ class CarNet(object):
         return outs
 
     __call__ = forward
+
+    def _run_two_streams(self, plan, x, dt):
+        """The launch list with the ops of plan.side on the side stream.  A run of side ops starts after everything
+        launched so far on the main stream (it reads the route the main stream has just produced) and the main stream
+        joins the side stream once, at the end (only the caller reads the head logits)."""
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side, on_side, used = self._side, False, False
+        for i, (kind, payload, name) in enumerate(plan.ops):
+            want = i in plan.side
+            if want and not on_side:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                used = True
+            on_side = want
+            rc = self._launch(kind, payload, x, (side if want else main).cuda_stream, dt)
+            if rc:
+                raise L.YoloError('%s (%s) failed with status %d' % (kind, name, rc))
+        if used:
+            done = torch.cuda.Event()
+            done.record(side)
+            main.wait_event(done)
 
     def _launch(self, kind, payload, x, st, dt):
         lib = self._lib
@@ -345,6 +445,8 @@ class CarNet(object):
         if kind == 'stem_down':
             w1, s1, b1, wp2, s2, b2, y, B, H, W, c1, c2 = payload
             return lib.yolo_stem_down_fwd(x.data_ptr(), w1, s1, b1, wp2, s2, b2, y, B, H, W, c1, c2, dt, LEAKY_SLOPE, st)
+        if kind == 'res_block':
+            return lib.yolo_res_block_fwd(*payload, dt, LEAKY_SLOPE, st)
         return lib.yolo_upsample2x_concat(*payload, dt, st)
 
     def plan_kernels(self, B, H, W):
@@ -367,6 +469,10 @@ class CarNet(object):
                 c = by_name[name]
                 ho, wo = c.out_hw(H_, W_)
                 out.append((name, 'stem_down_kernel', 2 * 3 * 9 * payload[10] * B_ * H_ * W_ + 2 * c.cin * 9 * c.cout * ho * wo * B_))
+                continue
+            if kind == 'res_block':
+                N_, H_, W_, C_ = payload[8:12]
+                out.append((name, 'res_block_kernel<%d>' % C_, 2 * N_ * H_ * W_ * (C_ * (C_ // 2) + 9 * (C_ // 2) * C_)))
                 continue
             if kind != 'conv':
                 out.append((name, kind, 0))
