@@ -179,14 +179,15 @@ def test_d53_train_step_bf16_one_hop(cuda):
     """The bench configuration's arithmetic (bf16 activations and activation gradients, MFMA bf16 convolutions,
     transposing-read weight gradients, sub-pixel stride-2 data gradients) at the D53 layer shapes: one hop from the
     reference on the bf16-rounded saved operands.  An activation is stored with ONE bf16 rounding (2^-9 relative);
-    the weight gradients accumulate in fp32."""
+    the weight gradients accumulate in fp32.  Bar for a stored activation: 2.5 bf16 ulps of the largest element (the HIP
+    fp32 value and the float64 reference can round to neighbouring bf16 values: one ulp = 2^-7 relative)."""
     spec, g, P, x, lab, net, tr = _d53(cuda, 'bf16', 4, tune='measure')
     cap = {}
     losses = tr.train_step(torch.from_numpy(x).to(cuda), torch.from_numpy(lab).to(cuda), update=False, capture=cap)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(losses).all())
     rb = lambda t: t.to(torch.bfloat16).float()
-    worst = _one_hop_check(tr, tr._last[0], cap, net.params, 1.2e-2, 2e-3, rb)
+    worst = _one_hop_check(tr, tr._last[0], cap, net.params, 2e-2, 2e-3, rb)
     print('one-hop worst (bf16):', worst)
     rl, _, _ = ot.train_step_reference(g, P, x, lab, spec, SIZE, sim_bf16=True)
     np.testing.assert_allclose(losses.cpu().numpy(), np.stack(rl), rtol=5e-2, atol=5e-3)
@@ -224,7 +225,8 @@ def test_d53_train_bs64_bf16_replicated_batch(cuda):
         cos[n] = float(a @ b / (a.norm() * b.norm() + 1e-30))
         ratio[n] = float(a.norm() / (b.norm() + 1e-30))
     near = [n for n in cos if '.out.' in n]
-    assert min(cos[n] for n in near) > 0.97 and all(0.9 < ratio[n] < 1.1 for n in near), min((cos[n], n) for n in near)
+    bad = {n: (round(cos[n], 4), round(ratio[n], 4)) for n in near if not (cos[n] > 0.97 and 0.85 < ratio[n] < 1.18)}
+    assert not bad, bad
     assert np.median(list(cos.values())) > 0.5 and min(cos.values()) > 0.2, (np.median(list(cos.values())), min(cos.values()))
     assert 0.7 < np.median(list(ratio.values())) < 1.3
     first = float(tr.train_step(x, lab).sum())

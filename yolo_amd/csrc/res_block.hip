@@ -17,6 +17,11 @@
 //     padding, not conv1x1(padding);
 //   * the 3x3 epilogue (conv_stream's: transpose through a per-wave LDS scratch, 16-byte row stores) takes its residual
 //     from the input ring instead of reading x a second time.
+// Measured (tools/rb_probe.py with ablation builds, 32 x 208 x 208 x 64: 144 us against 164 us for the two layers; HBM floor
+// 56 us): the parts add up instead of overlapping -- 3x3 MFMAs 36 us, output stores 40, mid row 26, input loads 13,
+// skeleton (barriers, ring fill, weights, transposes) 36 -- two waves per SIMD do not cover each other's latencies, and
+// deeper register prefetch (D) changes nothing.  The C = 128 instantiation (one wave per SIMD, 36 A-fragments in
+// AGPRs) runs its MFMA phase 6x below the matrix rate and loses to the two separate layers: the tuner does not pick it.
 // Same packed weight images, operand rounding points (mid is rounded to bf16 once; the residual is added in fp32 before
 // the output's one rounding) and K order ((kh, kw, channel)) as conv_stream_kernel.
 #include "common.h"
