@@ -81,6 +81,13 @@ typedef struct yolo_conv_desc {
     long long y_pixel_stride; /* elements between pixels in y; 0 = dense Cout                 */
     int algo;              /* 0 = library heuristic; 1 = generic kernel; >= 2 = a specific pipelined
                               tile variant (csrc/conv_pipe.hip), YOLO_EUNSUPPORTED if not eligible    */
+    long long x_pixel_stride; /* elements between pixels in x; 0 = dense Cin.  > Cin: x is a channel slice of a wider
+                              NHWC buffer (the route half of a concat buffer, car/utils.py:93); images stay
+                              H*W*x_pixel_stride apart                                        */
+    int upsample2x;        /* 1: every output pixel is stored to the 2x2 patch (2oy..2oy+1, 2ox..2ox+1) of a
+                              (N,2Ho,2Wo,*) map -- gluoncv _upsample(x, stride=2) (car/utils.py:92) fused into the
+                              producing convolution; strides then refer to that map (y_batch_stride 0 =
+                              4*Ho*Wo*y_pixel_stride); no residual, no out_f32                */
 } yolo_conv_desc;
 
 int yolo_conv_fwd(const yolo_conv_desc* d, void* stream);

@@ -338,3 +338,65 @@ def test_res_block_rejects(lib, cuda):
     assert lib.yolo_res_block_fwd(p, p, p, p, p, p, p, p, 1, 8, 8, 64, L.F32, 0.1, None) == L.EUNSUPPORTED
     assert lib.yolo_res_block_fwd(p, None, p, p, p, p, p, p, 1, 8, 8, 64, L.BF16, 0.1, None) == L.EINVAL
     assert lib.yolo_res_block_fwd(p, p, p, p, p, p, p, p, 1, 8, 8, 64, L.BF16, 1.5, None) == L.EINVAL
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', [(2, 64, 13, 13, 32, 1), (1, 128, 10, 14, 64, 1), (3, 32, 6, 5, 64, 3), (2, 512, 13, 13, 256, 1)])
+def test_conv_strided_input_and_upsampled_output(lib, cuda, dtype, case):
+    """yolo_conv_desc.x_pixel_stride (x = channel slice of a wider NHWC buffer) and .upsample2x (every output pixel stored
+    to its 2x2 patch of a (N,2Ho,2Wo,*) buffer, into a channel slice): concat(upsample(conv(x)), route) of
+    car/utils.py:91-93 without a copy.  Against the dense path on the same operands, every tile variant that takes the shape."""
+    import ctypes as C
+    N, Cin, H, W, Cout, k = case
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    sc, bi = rng.uniform(.5, 1.5, Cout).astype(np.float32), (.2 * rng.standard_normal(Cout)).astype(np.float32)
+    dense = run_conv(lib, cuda, x, w, sc, bi, 1, 0.1, dtype)                     # (N,Cout,H,W) through the plain path
+    st = torch.cuda.current_stream().cuda_stream
+    tdt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    dt = L.F32 if dtype == 'f32' else L.BF16
+    # x lives in channels [40, 40+Cin) of a wider buffer; y goes to channels [8, 8+Cout) of a (N,2H,2W,Cout+24) buffer
+    XC, x0, YC, y0 = Cin + 56, 40, Cout + 24, 8
+    xbuf = torch.full((N, H, W, XC), float('nan'), dtype=tdt, device=cuda)
+    xbuf[..., x0:x0 + Cin] = to_nhwc(x, dtype, cuda)
+    wp = torch.empty(lib.yolo_packed_weight_bytes(Cout, Cin, k, dt), dtype=torch.uint8, device=cuda)
+    L.check(lib.yolo_pack_conv_weights(torch.from_numpy(w).to(cuda).data_ptr(), wp.data_ptr(), Cout, Cin, k, dt, st), 'pack')
+    cp = lib.yolo_padded_channels(Cout)
+    scd = torch.zeros(cp, device=cuda); scd[:Cout] = torch.from_numpy(sc).to(cuda)
+    bid = torch.zeros(cp, device=cuda); bid[:Cout] = torch.from_numpy(bi).to(cuda)
+    ran = 0
+    for algo in (0, 1, 2, 4, 8, 11, 22):
+        ybuf = torch.full((N, 2 * H, 2 * W, YC), -7.0, dtype=tdt, device=cuda)
+        d = L.ConvDesc()
+        d.x, d.w_packed, d.scale, d.bias = xbuf[..., x0:].data_ptr(), wp.data_ptr(), scd.data_ptr(), bid.data_ptr()
+        d.y = ybuf[..., y0:].data_ptr()
+        d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.dtype, d.slope, d.algo = N, H, W, Cin, Cout, k, 1, dt, 0.1, algo
+        d.x_pixel_stride, d.upsample2x, d.y_pixel_stride, d.y_batch_stride = XC, 1, YC, 4 * H * W * YC
+        rc = lib.yolo_conv_fwd(C.byref(d), st)
+        if algo and rc == L.EUNSUPPORTED:
+            continue
+        assert rc == 0, (algo, rc)
+        ran += 1
+        torch.cuda.synchronize()
+        got = ybuf.float().cpu().numpy()
+        assert (got[..., :y0] == -7.0).all() and (got[..., y0 + Cout:] == -7.0).all(), algo     # neighbours untouched
+        up = np.repeat(np.repeat(dense, 2, axis=2), 2, axis=3)                                  # nearest 2x, NCHW
+        np.testing.assert_array_equal(got[..., y0:y0 + Cout].transpose(0, 3, 1, 2), up, err_msg='algo %d' % algo)
+    assert ran >= 2
+    # strided output WITH a dense residual (a stage's last block writing its route half of the concat buffer)
+    if Cout % 8 == 0:
+        res = rng.standard_normal((N, Cout, H, W)).astype(np.float32)
+        ref = run_conv(lib, cuda, x, w, sc, bi, 1, 0.1, dtype, residual=res)
+        rd = to_nhwc(res, dtype, cuda)
+        ybuf = torch.full((N, H, W, YC), -7.0, dtype=tdt, device=cuda)
+        d = L.ConvDesc()
+        d.x, d.w_packed, d.scale, d.bias = xbuf[..., x0:].data_ptr(), wp.data_ptr(), scd.data_ptr(), bid.data_ptr()
+        d.residual, d.y = rd.data_ptr(), ybuf[..., y0:].data_ptr()
+        d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.dtype, d.slope, d.algo = N, H, W, Cin, Cout, k, 1, dt, 0.1, 0
+        d.x_pixel_stride, d.y_pixel_stride, d.y_batch_stride = XC, YC, H * W * YC
+        assert lib.yolo_conv_fwd(C.byref(d), st) == 0
+        torch.cuda.synchronize()
+        got = ybuf.float().cpu().numpy()
+        assert (got[..., :y0] == -7.0).all() and (got[..., y0 + Cout:] == -7.0).all()
+        np.testing.assert_array_equal(got[..., y0:y0 + Cout].transpose(0, 3, 1, 2), ref)

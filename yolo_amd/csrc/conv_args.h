@@ -32,9 +32,12 @@ struct ConvArgs {
     int TWt, nstrips, tiles_per_strip, PW, total_i;
     int nchunks, tiles_c;
     int out_f32;
+    int x_ps;       // elements between input pixels (>= Cin: x may be a channel slice of a wider NHWC buffer)
+    int up2;        // 1: every output pixel is stored to its 2x2 patch of the (N,2Ho,2Wo) map (nearest 2x up-sampling)
     int d2s;        // 1: Cout = 4 sub-pixel phases x Cout/4 channels, stored depth-to-space into (N,2Ho,2Wo,Cout/4)
     float slope;
     long long y_bs, y_ps;
+    long long r_bs, r_ps;   // residual strides (elements); differ from y's when y is a channel slice of a wider buffer
     FastDiv d_PW, d_H1, d_TWt, d_Ho, d_HoWo, d_tc, d_tps;   // divisors PW, H+1, TWt, Ho, Ho*Wo, tiles_c, tiles_per_strip
 };
 

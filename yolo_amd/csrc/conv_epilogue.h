@@ -13,12 +13,13 @@
 #pragma once
 #include "conv_args.h"
 
-// bytes of LDS scratch one wave needs (max over MI in {1,2}): 32 rows x (64*4+16) + 2 x 32 x 8
-#define YOLO_EPI_WAVE_BYTES 9216
+// bytes of LDS scratch one wave needs (max over MI in {1,2}): 32 rows x (64*4+16) + 2 x 32 x 8 (output offsets) + 2 x 32 x 8
+// (residual offsets, when the residual's strides differ from the output's)
+#define YOLO_EPI_WAVE_BYTES 9728
 
 template <typename T, int MI, int NI>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long long (&yoff)[NI], char* wsm,
-                                              const ConvArgs& a, int co_w, int lane) {
+                                              const ConvArgs& a, int co_w, int lane, const long long* roff = nullptr) {
     constexpr int WN = MI * 32;                 // couts of the wave tile
     constexpr int RS = WN * 4 + 16;             // fp32 row stride in the scratch (bytes)
     constexpr int ES = (int)sizeof(T);
@@ -26,7 +27,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
     constexpr int LPR = WN / CPL;               // lanes per pixel row
     constexpr int RPP = 64 / LPR;               // rows per pass
     constexpr int NPASS = 32 / RPP;
-    static_assert(32 * RS + 2 * 32 * 8 <= YOLO_EPI_WAVE_BYTES, "scratch size");
+    static_assert(32 * RS + 4 * 32 * 8 <= YOLO_EPI_WAVE_BYTES, "scratch size");
     const int l31 = lane & 31, h = lane >> 5;
     const float slope = a.slope;
     // scale == bias == nullptr: identity epilogue (the training step's raw convolutions and data gradients: BN and the
@@ -82,6 +83,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
                     if (!ident) { sc = *(const f32x4*)(a.scale + co); bi = *(const f32x4*)(a.bias + co); }
                     const long long o = yoff[ni] + co;
+                    const long long ro = (a.res && roff) ? roff[ni] + co : o;       // (dense residual, strided y)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (co + e >= a.Cout) continue;
@@ -90,11 +92,22 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                         if (a.out_f32) {
                             ((float*)a.y)[o + e] = t;
                         } else if constexpr (ES == 2) {
-                            if (a.res) t += bf16_bits_to_f32(((const uint16_t*)a.res)[o + e]);
-                            ((uint16_t*)a.y)[o + e] = (uint16_t)f32_to_bf16_bits(t);
+                            if (a.res) t += bf16_bits_to_f32(((const uint16_t*)a.res)[ro + e]);
+                            const uint16_t b16 = (uint16_t)f32_to_bf16_bits(t);
+                            ((uint16_t*)a.y)[o + e] = b16;
+                            if (a.up2) {
+                                ((uint16_t*)a.y)[o + e + a.y_ps] = b16;
+                                ((uint16_t*)a.y)[o + e + 2LL * a.Wo * a.y_ps] = b16;
+                                ((uint16_t*)a.y)[o + e + (2LL * a.Wo + 1) * a.y_ps] = b16;
+                            }
                         } else {
-                            if (a.res) t += ((const float*)a.res)[o + e];
+                            if (a.res) t += ((const float*)a.res)[ro + e];
                             ((float*)a.y)[o + e] = t;
+                            if (a.up2) {
+                                ((float*)a.y)[o + e + a.y_ps] = t;
+                                ((float*)a.y)[o + e + 2LL * a.Wo * a.y_ps] = t;
+                                ((float*)a.y)[o + e + (2LL * a.Wo + 1) * a.y_ps] = t;
+                            }
                         }
                     }
                 }
@@ -132,18 +145,23 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
     // round trip per 32-pixel slab doubling the epilogue time.  (Prefetching all slabs at once spills on the
     // 8-wave variants.)  Output offsets go through a small LDS table: the transpose changes which pixel a lane owns.
     long long* ytab = (long long*)(wsm + 32 * RS);
+    long long* rtab = ytab + 64;
     const bool has_res = a.res != nullptr;
+    // the residual is a dense (N,Ho,Wo,Cout) tensor; when y is a channel slice of a wider buffer its offsets differ
+    const bool res_sep = has_res && roff != nullptr && (a.r_ps != a.y_ps || a.r_bs != a.y_bs);
     long long yo[2][NPASS];
     uint4 rv[2][NPASS];
     auto prefetch = [&](int ni) {
         if (h == 0) ytab[(ni & 1) * 32 + l31] = yoff[ni];
+        if (res_sep && h == 1) rtab[(ni & 1) * 32 + l31] = roff[ni];
 #pragma unroll
         for (int k = 0; k < NPASS; ++k) yo[ni & 1][k] = co_ok ? ytab[(ni & 1) * 32 + row0 + k * RPP] : -1;
         if (has_res) {
 #pragma unroll
             for (int k = 0; k < NPASS; ++k) {
                 rv[ni & 1][k] = make_uint4(0, 0, 0, 0);
-                if (yo[ni & 1][k] >= 0) rv[ni & 1][k] = *(const uint4*)(a.res + (yo[ni & 1][k] + cofs) * ES);
+                const long long ro = res_sep ? rtab[(ni & 1) * 32 + row0 + k * RPP] : yo[ni & 1][k];
+                if (yo[ni & 1][k] >= 0) rv[ni & 1][k] = *(const uint4*)(a.res + (ro + cofs) * ES);
             }
         }
     };
@@ -194,7 +212,15 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                 ov = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
                                 __float_as_uint(v[3]));
             }
-            if (yo[ni & 1][k] >= 0) *(uint4*)(a.y + (yo[ni & 1][k] + cofs) * ES) = ov;
+            if (yo[ni & 1][k] >= 0) {
+                char* dst = a.y + (yo[ni & 1][k] + cofs) * ES;
+                *(uint4*)dst = ov;
+                if (a.up2) {                            // the other three pixels of the 2x2 patch (row pitch 2*Wo pixels)
+                    *(uint4*)(dst + a.y_ps * ES) = ov;
+                    *(uint4*)(dst + 2LL * a.Wo * a.y_ps * ES) = ov;
+                    *(uint4*)(dst + (2LL * a.Wo + 1) * a.y_ps * ES) = ov;
+                }
+            }
         }
     }
 }

@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int i0 = (tile_p - strip * a.tiles_per_strip) * BP;
     const int co0 = tile_c * BC;
     const int H = a.H, W = a.W, Ho = a.Ho, Wo = a.Wo, TWt = a.TWt, PW = a.PW;
-    const int row_bytes = a.Cin * (int)sizeof(T);
+    const int row_bytes = a.Cin * (int)sizeof(T);           // channel extent of a pixel
+    const int row_pitch = a.x_ps * (int)sizeof(T);          // pitch of an input pixel
 
     // ---- geometry of the staged input tile ----------------------------------------------
     int Rin_lo = 0, HS = XSLOTS, x0 = 0;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             const int yy = Rr - n * (H + 1) - 1;
             const int xx = x0 + cc;
             valid = valid && yy >= 0 && n < a.N && xx >= 0 && xx < W;
-            xoff[j] = valid ? ((long long)(n * H + yy) * W + xx) * row_bytes : -1;
+            xoff[j] = valid ? ((long long)(n * H + yy) * W + xx) * row_pitch : -1;
             xlp[j] = (part ^ ((slot >> 2) & 3)) * 16;
         } else {
             const int plane = u / (XSLOTS * 4);
@@ -113,14 +114,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             const int slot = rem >> 2, part = rem & 3;
             const int i = i0 + slot;
             const bool valid = (i < a.total_i) && (u < X_UNITS);
-            xoff[j] = valid ? (long long)i * row_bytes : -1;
+            xoff[j] = valid ? (long long)i * row_pitch : -1;
             xlp[j] = plane * 64 + (part ^ ((slot >> 2) & 3)) * 16;
         }
     }
 
     // ---- per-lane MFMA operand addresses --------------------------------------------------
     int addrX[NI][NTAP];
-    long long yoff[NI];
+    long long yoff[NI], roff[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int i = i0 + (wave_p * NI + ni) * 32 + l31;
@@ -139,13 +140,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 addrX[ni][t] = slot * 64 + ((h ^ ((slot >> 2) & 3)) << 4);
             }
             pix = oy * Wo + strip * TWt + tx;
+            if (a.up2) pix = oy * 4 * Wo + 2 * (strip * TWt + tx);
         } else {
             const int slot = ii - i0;
             addrX[ni][0] = slot * 64 + ((h ^ ((slot >> 2) & 3)) << 4);
             n = ii / (Ho * Wo);
             pix = ii - n * (Ho * Wo);
+            if (a.up2) {
+                const int oy = pix / Wo;
+                pix = oy * 4 * Wo + 2 * (pix - oy * Wo);
+            }
         }
         yoff[ni] = ok ? (long long)n * a.y_bs + (long long)pix * a.y_ps : -1;
+        roff[ni] = (long long)n * a.r_bs + (long long)pix * a.r_ps;
     }
     const int aoff0 = (wave_c * MI * 32 + l31) * 64 + ((h ^ ((l31 >> 2) & 3)) << 4);
 
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
     // ---- epilogue (conv_epilogue.h): every wave transposes its slab through its own LDS scratch ------
     __syncthreads();                     // all waves are done reading the staged tiles
-    conv_epilogue<T, MI, NI>(acc, yoff, smem + wave * YOLO_EPI_WAVE_BYTES, a, co0 + wave_c * MI * 32, lane);
+    conv_epilogue<T, MI, NI>(acc, yoff, smem + wave * YOLO_EPI_WAVE_BYTES, a, co0 + wave_c * MI * 32, lane, roff);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -356,10 +363,16 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     a.nchunks = (d->Cin * es + 63) / 64;
     a.out_f32 = d->out_f32;
     a.d2s = 0;
+    a.up2 = d->upsample2x ? 1 : 0;
+    if (d->x_pixel_stride < 0 || (d->x_pixel_stride && d->x_pixel_stride < d->Cin) || d->x_pixel_stride > 0x7fffffffLL) return YOLO_EINVAL;
+    a.x_ps = d->x_pixel_stride ? (int)d->x_pixel_stride : d->Cin;
+    if ((a.x_ps * es) % 16) return YOLO_EUNSUPPORTED;                 // 16-byte aligned pixel rows
     a.slope = d->slope;
     a.y_ps = d->y_pixel_stride ? d->y_pixel_stride : d->Cout;
-    a.y_bs = d->y_batch_stride ? d->y_batch_stride : (long long)a.Ho * a.Wo * a.y_ps;
-    if (a.res && (d->y_pixel_stride || d->y_batch_stride || d->out_f32)) return YOLO_EUNSUPPORTED;
+    a.y_bs = d->y_batch_stride ? d->y_batch_stride : (long long)a.Ho * a.Wo * a.y_ps * (a.up2 ? 4 : 1);
+    a.r_ps = d->Cout; a.r_bs = (long long)a.Ho * a.Wo * d->Cout;          // the residual is dense
+    if (a.res && d->out_f32) return YOLO_EUNSUPPORTED;
+    if (a.up2 && (a.res || d->out_f32)) return YOLO_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (d->algo < 0) return YOLO_EINVAL;
     if (d->algo == 13 || d->algo == 14) return conv_stream_dispatch(a, d->ksize, d->stride, d->dtype, d->algo, st, nm);
@@ -403,9 +416,11 @@ extern "C" int yolo_conv_dgrad_s2(const yolo_conv_desc* d, void* stream) {
     a.Ho = d->H; a.Wo = d->W;
     a.Cout_pad = round_up(d->Cout, YOLO_COUT_PAD);
     a.nchunks = (d->Cin * 2 + 63) / 64;
-    a.out_f32 = 0; a.d2s = 1; a.slope = d->slope;
+    a.out_f32 = 0; a.d2s = 1; a.up2 = 0; a.x_ps = d->Cin; a.slope = d->slope;
+    if (d->x_pixel_stride || d->upsample2x) return YOLO_EUNSUPPORTED;
     a.y_ps = d->Cout / 4;
     a.y_bs = (long long)a.Ho * a.Wo * d->Cout;
+    a.r_ps = a.y_ps; a.r_bs = a.y_bs;                    // (accumulation into dx: same depth-to-space addressing)
     hipStream_t st = (hipStream_t)stream;
     if (d->algo) return conv_pipe_dispatch(a, 2, 1, d->dtype, d->algo, st, nullptr);
     // rounds x tile cost as in conv_auto_algo, then the first variant whose halo fits

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     const int i0 = (tile_p - strip * a.tiles_per_strip) * BP;
     const int co0 = tile_c * BC;
     const int H = a.H, W = a.W, Ho = a.Ho, Wo = a.Wo, TWt = a.TWt, PW = a.PW;
-    const int row_bytes = a.Cin * (int)sizeof(T);
+    const int row_bytes = a.x_ps * (int)sizeof(T);          // pitch of an input pixel
 
     int Rin_lo = 0, HS = XSLOTS, x0 = 0;
     if constexpr (KS != 1) {
@@ -424,6 +424,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     // ---- epilogue (conv_epilogue.h): every wave transposes its slab through its own LDS scratch ------
     __builtin_amdgcn_s_barrier();        // all waves are done reading the pipeline's LDS
     long long yoff[NI];                  // output element offset of each lane's pixels (-1: none)
+    long long roff[NI];                  // residual element offset (dense tensor; differs when y is strided)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int i = i0 + (wave_p * NI + ni) * 32 + l31;
@@ -434,15 +435,20 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
             n = fdiv(r, a.d_Ho);
             pix = (r - n * Ho) * Wo + strip * TWt + tx;
             // sub-pixel output: pixel (oy, ox) owns the 2x2 patch at (2 oy, 2 ox) of the (2Ho, 2Wo) map (y_ps = Cout / 4)
-            if (a.d2s) pix = (r - n * Ho) * 4 * Wo + 2 * (strip * TWt + tx);
+            if (a.d2s || a.up2) pix = (r - n * Ho) * 4 * Wo + 2 * (strip * TWt + tx);
         } else {
             n = fdiv(min(i, a.total_i - 1), a.d_HoWo);
             pix = min(i, a.total_i - 1) - n * (Ho * Wo);
+            if (a.up2) {                                  // (1x1: TWt == Wo)
+                const int oy = fdiv(pix, a.d_TWt);
+                pix = oy * 4 * Wo + 2 * (pix - oy * Wo);
+            }
         }
         yoff[ni] = (i < a.total_i) ? (long long)n * a.y_bs + (long long)pix * a.y_ps : -1;
+        roff[ni] = (long long)n * a.r_bs + (long long)pix * a.r_ps;
     }
     STAMP(3);
-    conv_epilogue<T, MI, NI>(acc, yoff, smem + wave * YOLO_EPI_WAVE_BYTES, a, co0 + wave_c * MI * 32, lane);
+    conv_epilogue<T, MI, NI>(acc, yoff, smem + wave * YOLO_EPI_WAVE_BYTES, a, co0 + wave_c * MI * 32, lane, roff);
     STAMP(4);
 #ifdef YOLO_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -576,7 +582,7 @@ int conv_pipe_dispatch(ConvArgs& a, int ks, int stride, int dtype, int algo, hip
     if (a.d2s && ks != 2) return YOLO_EUNSUPPORTED;
     if ((a.Cin * elem_size(dtype)) % 64) return YOLO_EUNSUPPORTED;
     if (ks == 1 && a.nchunks < 2) return YOLO_EUNSUPPORTED;     // a 1x1 needs >= 2 phases; a 3x3 has 9 per chunk
-    if ((long long)a.N * a.H * a.W * a.Cin * elem_size(dtype) >= 0xffffff00LL) return YOLO_EUNSUPPORTED;
+    if ((long long)a.N * a.H * a.W * a.x_ps * elem_size(dtype) >= 0xffffff00LL) return YOLO_EUNSUPPORTED;
     if (dtype == YOLO_BF16) return pipe_dispatch_t<bf16_t>(a, ks, stride, algo, st, nm);
     return pipe_dispatch_t<float>(a, ks, stride, algo, st, nm);
 }

@@ -242,7 +242,7 @@ static int launch_stream(const ConvArgs& c, hipStream_t st, const NameOut* nm) {
 
 // algo 13 (NI = 1) / 14 (NI = 2: twice the strip width per step)
 int conv_stream_dispatch(const ConvArgs& c, int ks, int stride, int dtype, int algo, hipStream_t st, const NameOut* nm) {
-    if (dtype != YOLO_BF16 || c.out_f32) return YOLO_EUNSUPPORTED;
+    if (dtype != YOLO_BF16 || c.out_f32 || c.up2 || c.x_ps != c.Cin) return YOLO_EUNSUPPORTED;
     if (c.y_ps != c.Cout || c.y_bs != (long long)c.Ho * c.Wo * c.Cout) return YOLO_EUNSUPPORTED;
     const int ni = algo == 14 ? 2 : 1;
 #define STREAM_CASE(KS_, S_, CIN_, COUT_)                                                        \

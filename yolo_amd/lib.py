@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
                 ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int),
                 ('ksize', C.c_int), ('stride', C.c_int), ('dtype', C.c_int), ('out_f32', C.c_int),
                 ('slope', C.c_float), ('y_batch_stride', C.c_longlong), ('y_pixel_stride', C.c_longlong),
-                ('algo', C.c_int)]
+                ('algo', C.c_int), ('x_pixel_stride', C.c_longlong), ('upsample2x', C.c_int)]
 
 
 class GridDesc(C.Structure):

@@ -36,7 +36,7 @@ class CarNet(object):
     ALGOS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25)     # yolo_conv_desc.algo ids tried by tune='measure'
 
     def __init__(self, spec, num_sync_bn_devices=-1, dtype='bf16', device='cuda:0', tune='auto', tune_cache=None,
-                 fuse_stem=True, side_stream=True, fuse_res=True):
+                 fuse_stem=True, side_stream=True, fuse_res=True, fuse_concat=True):
         # num_sync_bn_devices is accepted for signature parity; the reference always passes -1
         # (no SyncBN, car/YOLO.py:94-96).
         if dtype not in _TORCH_DT:
@@ -61,6 +61,11 @@ class CarNet(object):
         # half-width map between its two convolutions stays in LDS and x is read once.  With tune='measure' the fused
         # kernel is timed against the two separate layers and used where it wins.
         self.fuse_res = bool(fuse_res)
+        # fuse_concat: `concat(upsample(transition(x)), route)` (car/utils.py:91-93) without a copy kernel: the stage that
+        # produces a route writes it straight into its half of the concat buffer (strided output), the transition conv
+        # stores every output pixel to its 2x2 patch of the other half (yolo_conv_desc.upsample2x), and the route's other
+        # reader -- the next stage's down-sampling conv -- reads it with an input pixel stride
+        self.fuse_concat = bool(fuse_concat)
         self._algo_cache = {}
         # optional JSON file remembering measured choices (so a profiled run launches only the chosen kernels)
         self._tune_cache = tune_cache
@@ -170,30 +175,35 @@ class CarNet(object):
             self.prepare()
 
     # ---- plan construction --------------------------------------------------------------------------
-    def _conv_op(self, plan, c, x, xshape, residual=None, out=None, out_f32=False, y_bs=0, y_ps=0, cin=None):
+    def _conv_op(self, plan, c, x, xshape, residual=None, out=None, out_f32=False, y_bs=0, y_ps=0, cin=None, x_ps=0, up2=False):
         N, H, W, _ = xshape
         ho, wo = c.out_hw(H, W)
         if out is None:
             out = torch.empty((N, ho, wo, c.cout), dtype=_TORCH_DT[self.dtype], device=self.device)
             plan.buffers.append(out)
-        d = self._conv_desc(c, x, xshape, out, residual, out_f32, y_bs, y_ps, cin)
+        d = self._conv_desc(c, x, xshape, out, residual, out_f32, y_bs, y_ps, cin, x_ps, up2)
         if self.tune == 'measure':
             d.algo = self._measure_algo(d)
         plan.ops.append(('conv', d, c.name))
+        oshape = (N, 2 * ho, 2 * wo, c.cout) if up2 else (N, ho, wo, c.cout)
         if not isinstance(out, int):
-            plan.act[c.name] = (out, (N, ho, wo, c.cout))
-        return out, (N, ho, wo, c.cout)
+            plan.act[c.name] = (out, oshape)
+        return out, oshape
 
     def _res_block_payload(self, c1, c2, x, out, shp):
         wp1, s1, b1 = self._prepared[c1.name]
         wp2, s2, b2 = self._prepared[c2.name]
         return (L.ptr(x), L.ptr(wp1), L.ptr(s1), L.ptr(b1), L.ptr(wp2), L.ptr(s2), L.ptr(b2), L.ptr(out), shp[0], shp[1], shp[2], shp[3])
 
+    def _res_block_eligible(self, c1, c2):
+        C_ = c1.cin
+        return (self.fuse_res and self.dtype == 'bf16' and C_ in (64, 128) and c1.bn and c2.bn
+                and (c1.k, c1.stride, c1.cin, c1.cout) == (1, 1, C_, C_ // 2) and (c2.k, c2.stride, c2.cin, c2.cout) == (3, 1, C_ // 2, C_))
+
     def _use_res_block(self, c1, c2, x, shp):
         """Whether the residual block (c1: 1x1 C -> C/2, c2: 3x3 C/2 -> C, + x) runs as the fused kernel."""
         C_ = shp[3]
-        if not (self.fuse_res and self.dtype == 'bf16' and C_ in (64, 128) and c1.bn and c2.bn
-                and (c1.k, c1.stride, c1.cin, c1.cout) == (1, 1, C_, C_ // 2) and (c2.k, c2.stride, c2.cin, c2.cout) == (3, 1, C_ // 2, C_)):
+        if not self._res_block_eligible(c1, c2):
             return False
         if self.tune != 'measure':
             return True
@@ -234,9 +244,18 @@ class CarNet(object):
             with open(self._tune_cache, 'w') as f:
                 json.dump({json.dumps(list(k)): v for k, v in self._algo_cache.items()}, f)
 
-    def _conv_desc(self, c, x, xshape, out, residual=None, out_f32=False, y_bs=0, y_ps=0, cin=None):
+    def _conv_desc(self, c, x, xshape, out, residual=None, out_f32=False, y_bs=0, y_ps=0, cin=None, x_ps=0, up2=False):
         N, H, W, _ = xshape
         wp, scale, bias = self._prepared[c.name]
+        if isinstance(x, torch.Tensor) and x.dim() == 4 and not x.is_contiguous():
+            # a channel slice of a wider NHWC buffer (the route half of a concat buffer)
+            if x.stride(3) != 1 or x.stride(1) != W * x.stride(2) or x.stride(0) != H * W * x.stride(2):
+                raise L.YoloError('unsupported input view for %s' % c.name)
+            x_ps = x.stride(2)
+        if isinstance(out, torch.Tensor) and out.dim() == 4 and not out.is_contiguous():
+            if out.stride(3) != 1 or out.stride(1) != out.shape[2] * out.stride(2):
+                raise L.YoloError('unsupported output view for %s' % c.name)
+            y_ps, y_bs = out.stride(2), out.stride(0)
         d = L.ConvDesc()
         d.x, d.w_packed, d.scale, d.bias = L.ptr(x), L.ptr(wp), L.ptr(scale), L.ptr(bias)
         d.residual = L.ptr(residual)
@@ -246,6 +265,7 @@ class CarNet(object):
         d.out_f32 = 1 if out_f32 else 0
         d.slope = LEAKY_SLOPE if c.bn else 1.0
         d.y_batch_stride, d.y_pixel_stride = y_bs, y_ps
+        d.x_pixel_stride, d.upsample2x = x_ps, 1 if up2 else 0
         return d
 
     def _measure_algo(self, d, iters=5, fn=None, algos=None):
@@ -253,6 +273,8 @@ class CarNet(object):
         which is harmless: the plan has not run yet.  fn / algos: another entry point taking the same descriptor
         (yolo_conv_dgrad_s2, with d.ksize = 2 as the cache key's mark) and its variant ids; 1 = none ran."""
         key = (d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.out_f32, bool(d.residual), d.dtype)
+        if d.x_pixel_stride or d.upsample2x or (d.y_pixel_stride and not d.out_f32):
+            key = key + (int(d.x_pixel_stride), int(d.upsample2x), int(d.y_pixel_stride))
         if key in self._algo_cache:
             return self._algo_cache[key]
         lib, st = self._lib, L.stream_ptr()
@@ -320,10 +342,26 @@ class CarNet(object):
             x, shp = self._conv_op(plan, g.stem, plan.x_nhwc, (B, H, W, 8), cin=8)
         routes = []
         nst = len(g.stages)
+        cats = {}                                            # stage index -> (concat buffer, channels of the up-sampled half)
         for i, (down, res) in enumerate(g.stages):
+            last_of_stage = res[-1][1] if res else down
+            cat_view = None
+            t_idx = nst - 2 - i                              # the transition whose output is concatenated with this stage's
+            if (self.fuse_concat and nst - g.num_pyramid <= i <= nst - 2 and 0 <= t_idx < len(g.transitions)
+                    and last_of_stage is not fused_down and not (res and self._res_block_eligible(res[-1][0], res[-1][1]))):
+                ho, wo = down.out_hw(shp[1], shp[2])
+                up_ch = g.transitions[t_idx].cout
+                cat = torch.empty((B, ho, wo, up_ch + last_of_stage.cout), dtype=tdt, device=self.device)
+                plan.buffers.append(cat)
+                cats[i] = (cat, up_ch)
+                cat_view = cat[..., up_ch:]
             if down is not fused_down:
-                x, shp = self._conv_op(plan, down, x, shp)
-            for c1, c2 in res:
+                x, shp = self._conv_op(plan, down, x, shp, out=cat_view if not res else None)
+            for j, (c1, c2) in enumerate(res):
+                if cat_view is not None and j == len(res) - 1:
+                    mid, mshp = self._conv_op(plan, c1, x, shp)
+                    x, shp = self._conv_op(plan, c2, mid, mshp, residual=x, out=cat_view)
+                    continue
                 if self._use_res_block(c1, c2, x, shp):
                     out = torch.empty(shp, dtype=tdt, device=self.device)
                     plan.buffers.append(out)
@@ -334,7 +372,7 @@ class CarNet(object):
                 mid, mshp = self._conv_op(plan, c1, x, shp)
                 x, shp = self._conv_op(plan, c2, mid, mshp, residual=x)
             if i >= nst - g.num_pyramid:
-                routes.append((x, shp))
+                routes.append((x, shp, cats.get(i)))
         # merged head buffer (B, sum HW, A*C) float32, scales fine->coarse (car/utils.py:95, car/YOLO.py:841)
         hw = [r[1][1] * r[1][2] for r in routes]            # fine -> coarse
         per = [h[3] * g.per_anchor for h in g.heads][::-1]
@@ -366,8 +404,15 @@ class CarNet(object):
                 break
             if self.side_stream:
                 plan.side.update(range(first_side, len(plan.ops)))
+            r, rs, rcat = routes[::-1][i + 1]
+            if rcat is not None:
+                # the route already sits in its half of the concat buffer: the transition conv writes the other half,
+                # every pixel to its 2x2 patch (nearest 2x up-sampling)
+                cat, up_ch = rcat
+                self._conv_op(plan, g.transitions[i], route, rshp, out=cat[..., :up_ch], up2=True)
+                x, shp = cat, tuple(cat.shape)
+                continue
             x, shp = self._conv_op(plan, g.transitions[i], route, rshp)
-            r, rs = routes[::-1][i + 1]
             cat = torch.empty((rs[0], rs[1], rs[2], shp[3] + rs[3]), dtype=tdt, device=self.device)
             plan.buffers.append(cat)
             plan.ops.append(('upcat', (L.ptr(x), L.ptr(r), L.ptr(cat), rs[0], rs[1], rs[2], shp[3], rs[3]),
@@ -510,6 +555,7 @@ class CarNet(object):
     def activation_nchw(self, name):
         """float32 NCHW copy of a named conv output of the last forward (parity taps)."""
         t, (N, H, W, Cc) = self._last_plan.act[name]
+        t = t.contiguous()                                   # (a channel slice of a concat buffer is a strided view)
         out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=self.device)
         L.check(self._lib.yolo_nhwc_to_nchw(L.ptr(t), L.ptr(out), N, Cc, H, W, _LIB_DT[self.dtype], L.stream_ptr()),
                 'nhwc_to_nchw')
