@@ -248,6 +248,20 @@ int yolo_bn_train_bwd(const void* dz, const void* y, const float* mean, const fl
                       const float* gamma, const float* beta, void* dy, float* dgamma, float* dbeta,
                       double* workspace, long long npix, int C, float slope, int dtype, void* stream);
 
+/* The same two calls as TWO launches each: the per-layer finalize / parameter-gradient launches are folded into the apply
+ * pass.  `workspace` (2*C doubles) must be ZERO on entry and is left dirty; `zero_next` (a different buffer of
+ * zero_next_count doubles -- the next call may have more channels --, or NULL) is zeroed for the caller's next BatchNorm
+ * call: callers alternate two workspaces.  Same arithmetic as yolo_bn_train_fwd / _bwd. */
+int yolo_bn_train_fwd_pp(const void* y, const float* gamma, const float* beta, const void* residual,
+                         void* z, float* mean, float* invstd, float* running_mean, float* running_var,
+                         double* workspace, double* zero_next, int zero_next_count, long long npix, int C, float eps,
+                         float momentum, float slope, int dtype, void* stream);
+int yolo_bn_train_bwd_pp(const void* dz, const void* y, const float* mean, const float* invstd,
+                         const float* gamma, const float* beta, void* dy, float* dgamma, float* dbeta,
+                         double* workspace, double* zero_next, int zero_next_count, long long npix, int C, float slope,
+                         int dtype, void* stream);
+
+
 /* Weight gradient of Conv(k, stride, pad k/2): dw (Cout,Cin,k,k) float32 += sum over pixels of
  * dy (N,Ho,Wo,[dy_pixel_stride]) x (N,H,W,Cin), NHWC `dtype`.  The caller zero-fills dw once per step.
  * YOLO_F32: MFMA 32x32x2 f32.  YOLO_BF16: MFMA 32x32x16 bf16 fed by transposing LDS reads

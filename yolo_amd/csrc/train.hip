@@ -179,19 +179,53 @@ __global__ void bn_param_grad_kernel(double* __restrict__ sums, float* __restric
 // MODE 0 (forward):  z = lrelu(gamma*(y-mean)*invstd + beta) (+ residual)
 // MODE 1 (backward): dy = gamma*invstd * (da - mean(da) - xhat*mean(da*xhat))
 // Same thread <-> (octet, pixel lane) mapping as the reduction: channel constants live in registers.
-template <typename T, int MODE>
+// FUSED = 1: the per-layer finalize launches folded in.  The reduction's sums (double) are read by every block and turned
+// into the per-channel constants on the fly with bn_finalize_kernel's / bn_param_grad_kernel's exact expressions; block 0
+// also writes them out (mean / invstd / running statistics, or dgamma / dbeta) and zeroes `zero_next`, the workspace of the
+// caller's NEXT BatchNorm call (callers alternate two workspaces: this call's sums stay readable until the kernel ends).
+struct BnFused {
+    const double* sums;       // [2C] of this call (dirty after the call)
+    double* zero_next;        // [zero_n] zeroed for the next call (whose channel count may differ), or nullptr
+    int zero_n;
+    float* mean_out; float* invstd_out; float* running_mean; float* running_var;     // MODE 0
+    float* dgamma_out; float* dbeta_out;                                             // MODE 1
+    double inv_n;
+    float eps, momentum;
+};
+
+template <typename T, int MODE, int FUSED = 0>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ other,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                        float inv_n, T* __restrict__ out, int C, long long npix,
-                                                       int pix_per_block, float slope) {
+                                                       int pix_per_block, float slope, BnFused f) {
     constexpr int U = 4;
     const int noct = C >> 3;
     const int per = noct < 256 ? noct : 256;
     const int lanes = 256 / per;
     const long long p0 = (long long)blockIdx.x * pix_per_block;
     const long long p1 = min(p0 + pix_per_block, npix);
+    if (FUSED && blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            if (MODE == 0) {
+                const double m = f.sums[c] * f.inv_n;
+                double v = f.sums[C + c] * f.inv_n - m * m;
+                if (v < 0) v = 0;
+                f.mean_out[c] = (float)m;
+                f.invstd_out[c] = (float)(1.0 / sqrt(v + (double)f.eps));
+                if (f.running_mean) {
+                    f.running_mean[c] = f.momentum * f.running_mean[c] + (1.f - f.momentum) * (float)m;
+                    f.running_var[c] = f.momentum * f.running_var[c] + (1.f - f.momentum) * (float)v;
+                }
+            } else {
+                f.dbeta_out[c] = (float)f.sums[c];
+                f.dgamma_out[c] = (float)f.sums[C + c];
+            }
+        }
+        if (f.zero_next)
+            for (int i = threadIdx.x; i < f.zero_n; i += 256) f.zero_next[i] = 0.0;
+    }
     const int pl = threadIdx.x / per;
     if (pl >= lanes) return;
     for (int oct = threadIdx.x % per; oct < noct; oct += 256) {
@@ -199,9 +233,19 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = oct * 8 + e;
-            mu[e] = mean[c]; is[e] = invstd[c];
+            if (FUSED && MODE == 0) {
+                const double m = f.sums[c] * f.inv_n;
+                double v = f.sums[C + c] * f.inv_n - m * m;
+                if (v < 0) v = 0;
+                mu[e] = (float)m; is[e] = (float)(1.0 / sqrt(v + (double)f.eps));
+            } else {
+                mu[e] = mean[c]; is[e] = invstd[c];
+            }
             sc[e] = gamma[c]; sh[e] = beta[c];
-            if (MODE == 1) { k1[e] = dbeta[c] * inv_n; k2[e] = dgamma[c] * inv_n; }
+            if (MODE == 1) {
+                if (FUSED) { k1[e] = (float)f.sums[c] * inv_n; k2[e] = (float)f.sums[C + c] * inv_n; }
+                else { k1[e] = dbeta[c] * inv_n; k2[e] = dgamma[c] * inv_n; }
+            }
         }
         auto apply = [&](const float (&v)[8], const float (&o)[8], float (&r)[8]) {
 #pragma unroll
@@ -246,17 +290,26 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
 template <typename T>
 static int bn_fwd_t(const T* y, const float* gamma, const float* beta, const T* residual, T* z, float* mean,
                     float* invstd, float* running_mean, float* running_var, double* workspace, long long npix, int C,
-                    float eps, float momentum, float slope, hipStream_t st) {
+                    float eps, float momentum, float slope, hipStream_t st, bool fused = false, double* zero_next = nullptr, int zero_n = 0) {
     (void)hipGetLastError();
     int ppb, ppa; unsigned nb, na;
     bn_partition(npix, C, (int)sizeof(T), true, &ppb, &nb);
     bn_partition(npix, C, (int)sizeof(T), false, &ppa, &na);
     YOLO_LAUNCH((bn_reduce_kernel<T, 0>), dim3(nb, (C + BN_CG - 1) / BN_CG), dim3(256), 0, st, y, (const T*)nullptr, (const float*)nullptr,
                 (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, workspace, C, npix, ppb, slope);
+    BnFused f = {};
+    if (fused) {
+        f.sums = workspace; f.zero_next = zero_next; f.zero_n = zero_n; f.mean_out = mean; f.invstd_out = invstd;
+        f.running_mean = running_mean; f.running_var = running_var; f.inv_n = 1.0 / (double)npix; f.eps = eps; f.momentum = momentum;
+        YOLO_LAUNCH((bn_apply_kernel<T, 0, 1>), dim3(na), dim3(256), 0, st, y, residual, (const float*)nullptr, (const float*)nullptr,
+                    gamma, beta, (const float*)nullptr, (const float*)nullptr, 0.f, z, C, npix, ppa, slope, f);
+        YOLO_LAUNCH_CHECK();
+        return YOLO_OK;
+    }
     YOLO_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, mean, invstd, running_mean,
                 running_var, C, 1.0 / (double)npix, eps, momentum);
     YOLO_LAUNCH((bn_apply_kernel<T, 0>), dim3(na), dim3(256), 0, st, y, residual, mean, invstd, gamma, beta,
-                (const float*)nullptr, (const float*)nullptr, 0.f, z, C, npix, ppa, slope);
+                (const float*)nullptr, (const float*)nullptr, 0.f, z, C, npix, ppa, slope, f);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
@@ -279,16 +332,24 @@ extern "C" int yolo_bn_train_fwd(const void* y, const float* gamma, const float*
 template <typename T>
 static int bn_bwd_t(const T* dz, const T* y, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, T* dy, float* dgamma, float* dbeta, double* workspace, long long npix, int C,
-                    float slope, hipStream_t st) {
+                    float slope, hipStream_t st, bool fused = false, double* zero_next = nullptr, int zero_n = 0) {
     (void)hipGetLastError();
     int ppb, ppa; unsigned nb, na;
     bn_partition(npix, C, (int)sizeof(T), true, &ppb, &nb);
     bn_partition(npix, C, (int)sizeof(T), false, &ppa, &na);
     YOLO_LAUNCH((bn_reduce_kernel<T, 1>), dim3(nb, (C + BN_CG - 1) / BN_CG), dim3(256), 0, st, y, dz, mean, invstd, gamma, beta, workspace, C,
                 npix, ppb, slope);
+    BnFused f = {};
+    if (fused) {
+        f.sums = workspace; f.zero_next = zero_next; f.zero_n = zero_n; f.dgamma_out = dgamma; f.dbeta_out = dbeta;
+        YOLO_LAUNCH((bn_apply_kernel<T, 1, 1>), dim3(na), dim3(256), 0, st, y, dz, mean, invstd, gamma, beta,
+                    (const float*)nullptr, (const float*)nullptr, (float)(1.0 / (double)npix), dy, C, npix, ppa, slope, f);
+        YOLO_LAUNCH_CHECK();
+        return YOLO_OK;
+    }
     YOLO_LAUNCH(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, dgamma, dbeta, C);
     YOLO_LAUNCH((bn_apply_kernel<T, 1>), dim3(na), dim3(256), 0, st, y, dz, mean, invstd, gamma, beta,
-                (const float*)dgamma, (const float*)dbeta, (float)(1.0 / (double)npix), dy, C, npix, ppa, slope);
+                (const float*)dgamma, (const float*)dbeta, (float)(1.0 / (double)npix), dy, C, npix, ppa, slope, f);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
@@ -305,6 +366,41 @@ extern "C" int yolo_bn_train_bwd(const void* dz, const void* y, const float* mea
     if (dtype == YOLO_F32)
         return bn_bwd_t<float>((const float*)dz, (const float*)y, mean, invstd, gamma, beta, (float*)dy, dgamma, dbeta,
                                workspace, npix, C, slope, (hipStream_t)stream);
+    return YOLO_EINVAL;
+}
+
+// The same two calls with the per-layer finalize launches folded into the apply pass (bn_apply_kernel<.., FUSED = 1>): two
+// launches per call instead of three.  `workspace` (2*C doubles) must be ZERO on entry and is left dirty; `zero_next`
+// (a different buffer of zero_next_count doubles -- the NEXT call may have more channels --, or NULL) is zeroed for the
+// caller's next BatchNorm call: callers alternate two workspaces.
+extern "C" int yolo_bn_train_fwd_pp(const void* y, const float* gamma, const float* beta, const void* residual, void* z,
+                                    float* mean, float* invstd, float* running_mean, float* running_var,
+                                    double* workspace, double* zero_next, int zero_next_count, long long npix, int C,
+                                    float eps, float momentum, float slope, int dtype, void* stream) {
+    if (!y || !gamma || !beta || !z || !mean || !invstd || !workspace || npix <= 0 || C <= 0 || workspace == zero_next || zero_next_count < 0) return YOLO_EINVAL;
+    if (C % 8) return YOLO_EUNSUPPORTED;
+    if (dtype == YOLO_BF16)
+        return bn_fwd_t<bf16_t>((const bf16_t*)y, gamma, beta, (const bf16_t*)residual, (bf16_t*)z, mean, invstd,
+                                running_mean, running_var, workspace, npix, C, eps, momentum, slope, (hipStream_t)stream, true, zero_next, zero_next_count);
+    if (dtype == YOLO_F32)
+        return bn_fwd_t<float>((const float*)y, gamma, beta, (const float*)residual, (float*)z, mean, invstd,
+                               running_mean, running_var, workspace, npix, C, eps, momentum, slope, (hipStream_t)stream, true, zero_next, zero_next_count);
+    return YOLO_EINVAL;
+}
+
+extern "C" int yolo_bn_train_bwd_pp(const void* dz, const void* y, const float* mean, const float* invstd,
+                                    const float* gamma, const float* beta, void* dy, float* dgamma, float* dbeta,
+                                    double* workspace, double* zero_next, int zero_next_count, long long npix, int C,
+                                    float slope, int dtype, void* stream) {
+    if (!dz || !y || !mean || !invstd || !gamma || !beta || !dy || !dgamma || !dbeta || !workspace || workspace == zero_next || zero_next_count < 0) return YOLO_EINVAL;
+    if (npix <= 0 || C <= 0) return YOLO_EINVAL;
+    if (C % 8) return YOLO_EUNSUPPORTED;
+    if (dtype == YOLO_BF16)
+        return bn_bwd_t<bf16_t>((const bf16_t*)dz, (const bf16_t*)y, mean, invstd, gamma, beta, (bf16_t*)dy, dgamma, dbeta,
+                                workspace, npix, C, slope, (hipStream_t)stream, true, zero_next, zero_next_count);
+    if (dtype == YOLO_F32)
+        return bn_bwd_t<float>((const float*)dz, (const float*)y, mean, invstd, gamma, beta, (float*)dy, dgamma, dbeta,
+                               workspace, npix, C, slope, (hipStream_t)stream, true, zero_next, zero_next_count);
     return YOLO_EINVAL;
 }
 
@@ -390,7 +486,10 @@ static int yolo_conv_wgrad_f32(const float* dy, const float* x, float* dw_oihw, 
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-constexpr int WG_KC = 64;              // pixels per K-chunk
+#ifndef YOLO_WG_KC
+#define YOLO_WG_KC 64
+#endif
+constexpr int WG_KC = YOLO_WG_KC;      // pixels per K-chunk
 
 template <int PITCH>
 __device__ __forceinline__ uint4 tr_frag(const char* tile, int krow0, int col0, int lane) {

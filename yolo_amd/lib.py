@@ -71,6 +71,8 @@ SIGNATURES = {
     'yolo_pack_conv_weights_batch': (_i, [_vp, _vp, _i, _ll, _i, _vp]),
     'yolo_bn_train_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _f, _f, _i, _vp]),
     'yolo_bn_train_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _i, _vp]),
+    'yolo_bn_train_fwd_pp': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _f, _f, _f, _i, _vp]),
+    'yolo_bn_train_bwd_pp': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _f, _i, _vp]),
     'yolo_conv_wgrad_workspace_bytes': (_ll, [_i, _i, _i, _i]),
     'yolo_conv_wgrad': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ll, _i, _vp, _vp]),
     'yolo_bias_grad': (_i, [_vp, _vp, _ll, _i, _ll, _i, _vp]),

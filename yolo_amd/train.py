@@ -84,7 +84,11 @@ class Trainer(object):
         self._dgrad_algo = {}
         self._gb_cache = {}
         cmax = max(c.cout for c in g.convs())
-        self.ws = torch.zeros(3 * cmax, dtype=torch.float64, device=self.dev)
+        # two BatchNorm workspaces used alternately (yolo_bn_train_*_pp: a call leaves its own dirty and zeroes the next one's)
+        self.ws2 = [torch.zeros(2 * cmax, dtype=torch.float64, device=self.dev) for _ in range(2)]
+        self._ws_i = 0
+        self._bn3 = bool(os.environ.get('YOLO_TRAIN_BN3'))      # (the knob: separate finalize launches, for A/B runs)
+        self.ws = torch.zeros(2 * cmax, dtype=torch.float64, device=self.dev)
         wsb = max(self.lib.yolo_conv_wgrad_workspace_bytes(max(c.cin, 8), c.cout, c.k, self.ldt) for c in g.convs())
         self.wg_ws = torch.zeros(max(wsb, 16), dtype=torch.uint8, device=self.dev)       # (kept zeroed by the library)
         # weight gradients run on a side stream: they are off the backward pass's critical path (dy -> data gradient ->
@@ -233,6 +237,12 @@ class Trainer(object):
             x = cat
         return P
 
+    def _next_ws(self):
+        """(this call's BatchNorm workspace -- zero --, the one it zeroes for the next call)."""
+        a, b = self.ws2[self._ws_i], self.ws2[self._ws_i ^ 1]
+        self._ws_i ^= 1
+        return L.ptr(a), L.ptr(b)
+
     # ---- forward (train mode) -----------------------------------------------------------------------------
     def _forward(self, P, images):
         lib, st = self.lib, L.stream_ptr()
@@ -252,11 +262,19 @@ class Trainer(object):
                     L.check(lib.yolo_conv_fwd(C.byref(op['desc']), st), 'conv ' + c.name)
                 npix = y.shape[0] * y.shape[1] * y.shape[2]
                 p = self.net.params
-                L.check(lib.yolo_bn_train_fwd(L.ptr(y.val), L.ptr(p[c.name + '.gamma']), L.ptr(p[c.name + '.beta']),
-                                              L.ptr(op['res'].val) if op['res'] is not None else None, L.ptr(z.val),
-                                              L.ptr(op['mean']), L.ptr(op['invstd']), L.ptr(p[c.name + '.running_mean']),
-                                              L.ptr(p[c.name + '.running_var']), L.ptr(self.ws), npix, c.cout, BN_EPS,
-                                              BN_MOMENTUM, LEAKY_SLOPE, self.ldt, st), 'bn ' + c.name)
+                if self._bn3:
+                    L.check(lib.yolo_bn_train_fwd(L.ptr(y.val), L.ptr(p[c.name + '.gamma']), L.ptr(p[c.name + '.beta']),
+                                                  L.ptr(op['res'].val) if op['res'] is not None else None, L.ptr(z.val),
+                                                  L.ptr(op['mean']), L.ptr(op['invstd']), L.ptr(p[c.name + '.running_mean']),
+                                                  L.ptr(p[c.name + '.running_var']), L.ptr(self.ws), npix, c.cout, BN_EPS,
+                                                  BN_MOMENTUM, LEAKY_SLOPE, self.ldt, st), 'bn ' + c.name)
+                    continue
+                ws, wn = self._next_ws()
+                L.check(lib.yolo_bn_train_fwd_pp(L.ptr(y.val), L.ptr(p[c.name + '.gamma']), L.ptr(p[c.name + '.beta']),
+                                                 L.ptr(op['res'].val) if op['res'] is not None else None, L.ptr(z.val),
+                                                 L.ptr(op['mean']), L.ptr(op['invstd']), L.ptr(p[c.name + '.running_mean']),
+                                                 L.ptr(p[c.name + '.running_var']), ws, wn, self.ws2[0].numel(), npix, c.cout, BN_EPS,
+                                                 BN_MOMENTUM, LEAKY_SLOPE, self.ldt, st), 'bn ' + c.name)
             elif op['kind'] == 'out':
                 L.check(lib.yolo_conv_fwd(C.byref(op['desc']), st), 'out conv')
             else:
@@ -404,10 +422,17 @@ class Trainer(object):
                 npix = y.shape[0] * y.shape[1] * y.shape[2]
                 p = self.net.params
                 dy = torch.empty(y.shape, dtype=self.tdt, device=self.dev)
-                L.check(lib.yolo_bn_train_bwd(L.ptr(dz), L.ptr(y.val), L.ptr(op['mean']), L.ptr(op['invstd']),
-                                              L.ptr(p[c.name + '.gamma']), L.ptr(p[c.name + '.beta']), L.ptr(dy),
-                                              L.ptr(self.gview[c.name + '.gamma']), L.ptr(self.gview[c.name + '.beta']),
-                                              L.ptr(self.ws), npix, c.cout, LEAKY_SLOPE, self.ldt, st), 'bn bwd ' + c.name)
+                if self._bn3:
+                    L.check(lib.yolo_bn_train_bwd(L.ptr(dz), L.ptr(y.val), L.ptr(op['mean']), L.ptr(op['invstd']),
+                                                  L.ptr(p[c.name + '.gamma']), L.ptr(p[c.name + '.beta']), L.ptr(dy),
+                                                  L.ptr(self.gview[c.name + '.gamma']), L.ptr(self.gview[c.name + '.beta']),
+                                                  L.ptr(self.ws), npix, c.cout, LEAKY_SLOPE, self.ldt, st), 'bn bwd ' + c.name)
+                else:
+                    ws, wn = self._next_ws()
+                    L.check(lib.yolo_bn_train_bwd_pp(L.ptr(dz), L.ptr(y.val), L.ptr(op['mean']), L.ptr(op['invstd']),
+                                                     L.ptr(p[c.name + '.gamma']), L.ptr(p[c.name + '.beta']), L.ptr(dy),
+                                                     L.ptr(self.gview[c.name + '.gamma']), L.ptr(self.gview[c.name + '.beta']),
+                                                     ws, wn, self.ws2[0].numel(), npix, c.cout, LEAKY_SLOPE, self.ldt, st), 'bn bwd ' + c.name)
                 if capture is not None:
                     capture[c.name] = dict(dz=dz.clone(), dy=dy)
                 if op['res'] is not None:
