@@ -116,9 +116,9 @@ def synthetic_labels(batch, seed, num_class=24):
     return lab
 
 
-def bench_train(args, spec, size, B, rank, world, dev, dist):
+def train_pass(args, spec, size, B, rank, world, dev, dist, steps, warmup):
     """BASELINE configs[2] (N=1) / configs[3] (N>1): car/YOLO.py training step, B images per GPU, the gradient
-    bucket all-reduced over RCCL (one exchange per step), identical Adam on every rank."""
+    bucket all-reduced over RCCL (one exchange per step), identical Adam on every rank.  Returns the result dict."""
     from yolo_amd.net import CarNet
     from yolo_amd.train import Trainer
     net = CarNet(spec, dtype=args.dtype, device=dev, tune='measure', tune_cache=args.tune_cache,
@@ -134,11 +134,11 @@ def bench_train(args, spec, size, B, rank, world, dev, dist):
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1)):          # the first step also measures the kernel variants
+    for _ in range(max(warmup, 1)):               # the first step also measures the kernel variants
         tr.train_step(x, lab)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         losses = tr.train_step(x, lab)
     fence()
     el = time.perf_counter() - t0
@@ -146,12 +146,13 @@ def bench_train(args, spec, size, B, rank, world, dev, dist):
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-    value = world * B * args.steps / el
+    value = world * B * steps / el
     fl = 3 * net.graph.flops(*size)
-    out = {
+    tf = fl * value / 1e12 / world
+    return {
         'metric': 'training images/sec at %dx%d bs=%d per GPU (fwd + loss + bwd + train-mode BN + Adam)' % (size[0], size[1], B),
-        'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(el / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+        'ms_per_step': round(el / steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[%d]: car/YOLO.py training step, Darknet-53 spec + 3-scale YOLO head '
                                '(A=3, C=30), synthetic render_car-style targets, %dx%d, bs=%d per GPU, %s activations / '
@@ -160,9 +161,13 @@ def bench_train(args, spec, size, B, rank, world, dev, dist):
                    'parallelism': 'dp%d (batch-sharded; one RCCL all-reduce of the %d-element fp32 gradient bucket per step)'
                                   % (world, tr.gflat.numel()),
                    'gflop_per_image': round(fl / 1e9, 2)},
-        'net_tflops': round(fl * value / 1e12, 1),
+        'net_tflops': round(tf, 1), 'net_frac': round(tf / MFMA_PEAK_TFLOPS[args.dtype], 4),
         'final_losses': [round(float(v), 6) for v in losses.sum(dim=1).tolist()],
     }
+
+
+def bench_train(args, spec, size, B, rank, world, dev, dist):
+    out = train_pass(args, spec, size, B, rank, world, dev, dist, args.steps, args.warmup)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -255,6 +260,8 @@ def main():
                          "step (fwd + loss + bwd + train-mode BN + gradient all-reduce + Adam) per step")
     ap.add_argument('--no-northstar', action='store_true',
                     help='skip the extra 608x608 bs=64 passes (north-star shape, BASELINE configs[4] per-GPU shape) of the headline run')
+    ap.add_argument('--no-train-key', action='store_true', help='skip the extra training-step pass (BASELINE configs[2]) of the headline run')
+    ap.add_argument('--train-key', action='store_true', help='run that pass under N > 1 too (BASELINE configs[3]: RCCL gradient all-reduce)')
     ap.add_argument('--launch-check', action='store_true',
                     help='start the N ranks, rendezvous, barrier, MAX-reduce, print the world that ran, and exit (no benchmark)')
     args = ap.parse_args()
@@ -380,6 +387,15 @@ def main():
                         'ms_per_step': round(el6 / k6 * 1e3, 4), 'net_tflops': round(tf6, 1),
                         'frac_of_peak': round(tf6 / MFMA_PEAK_TFLOPS[args.dtype], 4), 'gflop_per_image': round(fl6 / 1e9, 2)}
         del x6
+    if (not args.no_train_key and (args.size, B, args.post) == (416, 32, 'top1') and args.dtype == 'bf16'
+            and (world == 1 or args.train_key)):
+        # BASELINE configs[2] (training step, 416x416 bs=64 per GPU) in the same driver-run line.  Under N > 1 (configs[3]:
+        # RCCL all-reduce of the gradient bucket) only on request: a collective that hangs must not cost the headline line.
+        del net
+        torch.cuda.empty_cache()
+        t = train_pass(args, spec, size, 64, rank, world, dev, dist, max(args.steps // 2, 5), 2)
+        out['train_416_bs64'] = {k: t[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'net_tflops', 'net_frac', 'final_losses')}
+        out['train_416_bs64']['workload'] = t['config']['workload']
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(size)
     if dist is not None:
