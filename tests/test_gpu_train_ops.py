@@ -162,6 +162,39 @@ def test_wgrad_bf16_transposing_reads(lib, cuda, case):
     np.testing.assert_allclose(dw.cpu().numpy() - 1.0, ref, rtol=1e-3, atol=2e-3 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize('algo', [2, 3])
+@pytest.mark.parametrize('case', [(2, 64, 8, 12, 128), (3, 128, 13, 13, 64), (2, 64, 17, 19, 192), (1, 64, 5, 4, 64),
+                                  (2, 128, 11, 26, 64), (1, 64, 9, 38, 128), (5, 64, 7, 33, 64), (1, 64, 2, 70, 64),
+                                  (70, 64, 13, 13, 128), (3, 192, 30, 52, 64),
+                                  # D53 shapes of BASELINE configs[2] (416x416; batch 8) and the 608x608 family's widths
+                                  (8, 64, 104, 104, 128), (8, 128, 52, 52, 256), (8, 256, 26, 26, 512),
+                                  (8, 512, 13, 13, 1024), (4, 256, 38, 38, 512), (4, 512, 19, 19, 1024),
+                                  (2, 128, 76, 76, 256)])
+def test_wgrad_bf16_row_walk(lib, cuda, case, algo):
+    """wgrad_walk_kernel (3x3 stride 1, Cin and Cout multiples of 64): LDS-DMA ring, x fragments of the three kernel
+    rows held in registers, walkers over the stacked padded rows -- one 16-column walker (algo 2) and four 4-column
+    walkers (algo 3) per block; ragged widths, walker ranges that cross image boundaries, several row slices.  Exact
+    fp32 accumulation of the bf16-rounded operands, as the other weight-gradient kernels."""
+    N, Cin, H, W, Cout = case
+    full = (N, Cin, H, W, Cout, 3, 1)
+    x, w, dy, dx_ref, dw_ref = _ref(full, 11)
+    rb = lambda a: torch.from_numpy(a).to(torch.bfloat16).float()
+    wt = torch.from_numpy(w).requires_grad_(True)
+    F.conv2d(rb(x), wt, None, stride=1, padding=1).backward(rb(dy))
+    xd, dyd = to_nhwc(x, 'bf16', cuda), to_nhwc(dy, 'bf16', cuda)
+    dw = torch.ones((Cout, Cin, 3, 3), device=cuda)
+    ws = torch.zeros(lib.yolo_conv_wgrad_workspace_bytes(Cin, Cout, 3, L.BF16), dtype=torch.uint8, device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.yolo_conv_wgrad_algo(dyd.data_ptr(), xd.data_ptr(), dw.data_ptr(), N, H, W, Cin, Cout, 3, 1, 0, L.BF16,
+                                    ws.data_ptr(), algo, st) == 0
+    ref = wt.grad.numpy()
+    np.testing.assert_allclose(dw.cpu().numpy() - 1.0, ref, rtol=1e-3, atol=2e-3 * np.abs(ref).max())
+    assert float(ws.view(torch.float32).abs().max()) == 0.0          # the workspace is left zeroed
+    # outside the kernel's domain: refused, not silently served by another kernel
+    assert lib.yolo_conv_wgrad_algo(dyd.data_ptr(), xd.data_ptr(), dw.data_ptr(), N, H, W, Cin, Cout, 3, 2, 0, L.BF16,
+                                    ws.data_ptr(), algo, st) == L.EUNSUPPORTED
+
+
 @pytest.mark.parametrize('case', [(2, 32, 16, 24, 64), (3, 64, 26, 26, 128), (2, 8, 12, 20, 32), (1, 128, 52, 52, 256),
                                   (4, 256, 26, 26, 512), (70, 32, 4, 4, 64), (1, 40, 6, 10, 96), (2, 64, 2, 2, 32)])
 def test_dgrad_s2_subpixel(lib, cuda, case):

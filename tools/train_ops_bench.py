@@ -10,6 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=32)
 ap.add_argument('--what', default='bn,wgrad')
 ap.add_argument('--iters', type=int, default=20)
+ap.add_argument('--algos', default='0', help='weight-gradient kernels to time (yolo_conv_wgrad_algo ids)')
 a = ap.parse_args()
 lib = L.load()
 dev = torch.device('cuda:0')
@@ -61,6 +62,11 @@ if 'wgrad' in a.what:
         dy = torch.randn((a.batch, ho, ho, co), device=dev).bfloat16()
         dw = torch.zeros((co, ci, k, k), device=dev)
         ws = torch.zeros(max(lib.yolo_conv_wgrad_workspace_bytes(co, ci, k, 1), 16), dtype=torch.uint8, device=dev)
-        t = timed(lambda: L.check(lib.yolo_conv_wgrad(p(dy), p(x), p(dw), a.batch, H, H, ci, co, k, s, co, 1, p(ws), st), "wgrad"))
         fl = 2.0 * a.batch * ho * ho * ci * co * k * k
-        print('wgrad %3d^2 %4d->%4d k%d s%d  %7.1f us  %6.1f TFLOP/s' % (ho, ci, co, k, s, t, fl / t / 1e6), flush=True)
+        for algo in [int(v) for v in a.algos.split(',')]:
+            rc = lib.yolo_conv_wgrad_algo(p(dy), p(x), p(dw), a.batch, H, H, ci, co, k, s, co, 1, p(ws), algo, st)
+            if rc == L.EUNSUPPORTED:
+                continue
+            L.check(rc, 'wgrad')
+            t = timed(lambda: L.check(lib.yolo_conv_wgrad_algo(p(dy), p(x), p(dw), a.batch, H, H, ci, co, k, s, co, 1, p(ws), algo, st), "wgrad"))
+            print('wgrad %3d^2 %4d->%4d k%d s%d algo %d  %7.1f us  %6.1f TFLOP/s' % (ho, ci, co, k, s, algo, t, fl / t / 1e6), flush=True)

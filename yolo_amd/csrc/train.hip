@@ -1019,10 +1019,24 @@ extern "C" long long yolo_conv_wgrad_workspace_bytes(int Cin, int Cout, int ksiz
     return (long long)Cin * Cout * ksize * ksize * 4;
 }
 
+// wgrad_walk.hip: the pipelined row-walk kernel of the 3x3 stride-1 layers (Cin, Cout multiples of 64)
+int wgrad_walk_dispatch(const void* dy, const void* x, float* dwt, int N, int H, int W, int Cin, int Cout, long long ps,
+                        int variant, hipStream_t st);
+
 extern "C" int yolo_conv_wgrad(const void* dy, const void* x, float* dw_oihw, int N, int H, int W, int Cin, int Cout,
                                int ksize, int stride, long long dy_pixel_stride, int dtype, void* workspace,
                                void* stream) {
+    return yolo_conv_wgrad_algo(dy, x, dw_oihw, N, H, W, Cin, Cout, ksize, stride, dy_pixel_stride, dtype, workspace, 0,
+                                stream);
+}
+
+// algo: 0 = the library's choice; 1 = the register-staged kernels (per-tap / strip / row-group); 2 / 3 = the row-walk
+// kernel with one 16-column walker / four 4-column walkers per block (EUNSUPPORTED outside its domain)
+extern "C" int yolo_conv_wgrad_algo(const void* dy, const void* x, float* dw_oihw, int N, int H, int W, int Cin, int Cout,
+                                    int ksize, int stride, long long dy_pixel_stride, int dtype, void* workspace, int algo,
+                                    void* stream) {
     if (!dy || !x || !dw_oihw || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return YOLO_EINVAL;
+    if (algo < 0 || algo > 3) return YOLO_EINVAL;
     if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return YOLO_EUNSUPPORTED;
     if (dtype == YOLO_F32)
         return yolo_conv_wgrad_f32((const float*)dy, (const float*)x, dw_oihw, N, H, W, Cin, Cout, ksize, stride,
@@ -1037,6 +1051,18 @@ extern "C" int yolo_conv_wgrad(const void* dy, const void* x, float* dw_oihw, in
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
     const long long total = (long long)Cin * Cout * taps;
+    if (algo != 1 && ksize == 3 && stride == 1) {
+        const int rc = wgrad_walk_dispatch(dy, x, (float*)workspace, N, H, W, Cin, Cout, ps, algo ? algo - 1 : 0, st);
+        if (rc == YOLO_OK) {
+            YOLO_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (float*)workspace,
+                        dw_oihw, Cout, Cin, taps, total);
+            YOLO_LAUNCH_CHECK();
+            return YOLO_OK;
+        }
+        if (rc != YOLO_EUNSUPPORTED || algo) return rc;
+    } else if (algo > 1) {
+        return YOLO_EUNSUPPORTED;
+    }
     if (ksize == 3 && Cin <= 64) {
         const uint16_t* d16 = (const uint16_t*)dy;
         const uint16_t* x16 = (const uint16_t*)x;

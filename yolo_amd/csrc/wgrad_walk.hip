@@ -1,0 +1,316 @@
+// bf16 weight gradient of the 3x3 stride-1 layers (Cin, Cout multiples of 64) as a PIPELINED row walk for gfx950:
+//   dW[tap][co][ci] += sum over pixels of dy[p][co] * x[p @ tap][ci]          (Convolution backward w.r.t. weights,
+//   car/YOLO.py:393 `sum(losses).backward()` through every _conv2d of basic_yolo.py:20-26,118-121).
+// MFMA 32x32x16 bf16 with K = output pixels; both operands are [pixel][channel] in HBM, so the fragments come from
+// the transposing LDS read ds_read_b64_tr_b16 (tools/probes/tr_b16_probe.hip).
+//
+// What the older kernels of train.hip leave on the table (wgrad_rows_kernel: ~600 TFLOP/s on the 26x26 / 13x13 maps,
+// the per-tap wgrad_bf16_kernel: less on the 52x52 ones): they stage through registers behind two __syncthreads per
+// chunk, and they read NINE shifted x fragments from LDS for every dy fragment (ten fragment reads per nine MFMAs;
+// ds_read_b64 needs ~4 waves per SIMD to reach its rate, these kernels hold two).  Here:
+//   * the images are one stack of padded rows R = n*(H+1) + y + 1 (row 0 mod H+1 is the zero row two images share,
+//     as in the forward kernels' padded-strip scheme); a WALKER owns SC columns and walks down a range of stacked
+//     rows.  A K-step (16 pixels) is the current row of 16/SC walkers that share the columns and differ in the row
+//     range, so narrow maps lose nothing to K padding with SC = 4 (52 = 13 x 4, 26 -> 28; 16 / SC = 1 walker of 16
+//     columns for the wide or 13-wide maps);
+//   * the x fragments of the three kernel rows are kept in REGISTERS across steps: output row R needs x rows R-1,
+//     R, R+1, of which only R+1 is new -- four fragment reads (1 dy + 3 kw shifts of the new x row) per nine MFMAs;
+//   * a block (4 waves = 2 x 2 over 64 cout x 64 cin, 9 x 32 x 32 accumulators per wave) runs phases of three
+//     steps; the rows of a phase (3 new x rows with their column halo, 3 dy rows: 16 KiB) arrive by LDS-DMA
+//     (global_load_lds_dwordx4) in a ring of RD slots, RD - 1 phases ahead, behind ONE counted s_waitcnt vmcnt +
+//     s_barrier per phase; padding, image edges and range ends are DMA'd from a zero page (no predication in the
+//     loop).  Lane-linear DMA images: the bank-conflict swizzle (64-byte halves of a pixel's 128 bytes exchanged
+//     on odd 256-byte lines) is applied to the per-lane SOURCE address and again by the reader;
+//   * blocks that share the rows (the cout x cin tiles of one walker set) are consecutive on one XCD.
+// Partial sums of the blocks are added atomically into the zeroed [tap][Cout][Cin] fp32 workspace, which
+// wgrad_finish_kernel (train.hip) folds into the OIHW gradient.
+#include "common.h"
+#include "conv_args.h"
+#include <type_traits>
+
+namespace {
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __attribute__((aligned(64))) unsigned int wgw_zero_page[16];
+
+struct WalkArgs {
+    const char* dy;
+    const char* x;
+    const char* zero;              // 64 zero bytes (padding, image edges, range ends are DMA'd from here)
+    float* dwt;
+    int H, W, Cin, Cout;
+    unsigned x_rowb, dy_rowb;      // bytes per image row of x / dy
+    unsigned x_pixb, dy_pixb;      // bytes per pixel
+    int tiles_ci, ntiles, ncolseg;
+    int L;                         // stacked rows per walker (a multiple of 3)
+    int NR;                        // N * (H + 1) stacked rows
+    int nphase;                    // 1 (fragment pre-load) + L / 3
+    FastDiv d_h1, d_tiles, d_colseg;
+};
+
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst_uniform) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ int xcd_order(int bid, int nblk) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+__device__ __forceinline__ uint2 tr_read(const char* p) {
+    return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p));
+}
+__device__ __forceinline__ void mma(f32x16& c, const uint4& a, const uint4& b) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+}  // namespace
+
+// SC: columns per walker (16 / SC walkers per block); RD: ring depth
+template <int SC, int RD>
+__global__ __launch_bounds__(256, 2) void wgrad_walk_kernel(WalkArgs a) {
+    constexpr int NW = 16 / SC;
+    constexpr int XPX = SC + 2;                         // x pixels per walker row (column halo)
+    constexpr int WXB = XPX * 128;                      // bytes of a walker's x row (64 channels)
+    constexpr int XROWB = (NW * WXB + 511) / 512 * 512;  // (whole 512-byte line pairs: the swizzle does not depend on the row)
+    constexpr int SLOT_X = 3 * XROWB;
+    constexpr int SLOT_XP = (SLOT_X + 1023) / 1024 * 1024;       // (whole DMAs: a DMA is x or dy, never both)
+    constexpr int DYROWB = 16 * 128;
+    constexpr int SLOT = 16384;
+    constexpr int ND = SLOT / 4096;                     // DMAs per wave per phase
+    static_assert(SLOT_XP + 3 * DYROWB <= SLOT, "slot layout");
+    static_assert(XROWB % 512 == 0 && SLOT_XP % 512 == 0 && DYROWB % 512 == 0 && SLOT % 512 == 0, "the swizzle follows 256-byte lines");
+    __shared__ __attribute__((aligned(1024))) char smem[RD * SLOT];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+
+    const int lid = xcd_order(blockIdx.x, gridDim.x);
+    const int rest = fdiv(lid, a.d_tiles);
+    const int tile = lid - rest * a.ntiles;
+    const int slice = fdiv(rest, a.d_colseg);
+    const int cseg = rest - slice * a.ncolseg;
+    const int tco = tile / a.tiles_ci, tci = tile - tco * a.tiles_ci;
+    const int co0 = tco * 64, ci0 = tci * 64;
+    const int c0 = cseg * SC;
+    const int L = a.L, NR = a.NR, H1 = a.H + 1;
+    const int Ra0 = slice * NW * L;                     // first stacked row of walker 0
+
+    // ---- per-lane DMA descriptors.  DMA k of this wave fills slot bytes [(k*4 + wave)*1024 + lane*16, +16) -------
+    //   code = row-in-phase | walker << 2 ; co = byte offset of the 16-byte unit inside its image row (~0: padding column)
+    unsigned d_co[ND];
+    int d_r0[ND];                                       // stacked row of the unit in slot-phase 0
+    int d_rl[ND];                                       // rows >= this are not loaded (dy: the walker's range end)
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+        const int o = (k * 4 + wave) * 1024 + lane * 16;
+        const int par = (o >> 8) & 1;
+        const int u = ((o >> 4) & 7) ^ (par << 2);      // the channel unit this LDS unit must hold
+        int i, w, col;
+        unsigned co = 0xffffffffu;
+        if (o < SLOT_XP) {
+            i = o / XROWB;
+            const int rem = o - i * XROWB;
+            w = rem / WXB;
+            const int px = (rem - w * WXB) >> 7;
+            col = c0 - 1 + px;
+            if (o < SLOT_X && rem < NW * WXB && col >= 0 && col < a.W) co = (unsigned)col * a.x_pixb + (unsigned)(ci0 * 2 + u * 16);
+            d_r0[k] = Ra0 + w * L + i - 2;              // x rows of slot-phase q: s + 1 + i, s = Ra + 3 (q - 1)
+            d_rl[k] = NR;
+        } else {
+            const int o2 = o - SLOT_XP;
+            i = o2 / DYROWB;
+            const int kk = (o2 - i * DYROWB) >> 7;
+            w = kk / SC;
+            col = c0 + kk - w * SC;
+            if (i < 3 && col < a.W) co = (unsigned)col * a.dy_pixb + (unsigned)(co0 * 2 + u * 16);
+            d_r0[k] = Ra0 + w * L + i - 3;              // dy rows of slot-phase q: s + i
+            d_rl[k] = min(Ra0 + (w + 1) * L, NR);
+        }
+        d_co[k] = co;
+    }
+    const uint32_t wave_lds = lds0 + wave * 1024;
+    auto issue = [&](int k, int qs) {                   // DMA k of slot-phase qs into ring slot qs % RD
+        const bool isx = (k * 4 + wave) * 1024 < SLOT_XP;                   // (wave-uniform)
+        const int R = d_r0[k] + 3 * qs;
+        const int n = fdiv(R, a.d_h1);
+        const int y = R - n * H1 - 1;
+        const bool ok = (unsigned)R < (unsigned)d_rl[k] && y >= 0 && d_co[k] != 0xffffffffu;
+        const unsigned rowb = isx ? a.x_rowb : a.dy_rowb;
+        const char* base = isx ? a.x : a.dy;
+        const char* src = base + ((size_t)(unsigned)(R - n - 1) * rowb + d_co[k]);
+        src = ok ? src : a.zero;
+        dma16(src, wave_lds + (qs % RD) * SLOT + k * 4096);
+    };
+
+    // ---- prologue: slot-phases 0 .. RD-2 ---------------------------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < RD - 1; ++q)
+#pragma unroll
+        for (int k = 0; k < ND; ++k) issue(k, q);
+
+    // ---- per-lane fragment addresses (bytes inside a slot; row i of the phase adds i * XROWB / i * DYROWB) -----
+    const int g = lane >> 4, j16 = lane & 15;
+    int xa[3][2], da[2];
+#pragma unroll
+    for (int hl = 0; hl < 2; ++hl) {
+        const int kk = (g >> 1) * 8 + hl * 4 + (j16 >> 2);          // K index = pixel of the K-step
+        const int w = kk / SC, pc = kk - w * SC;
+        const int sub = (g & 1) * 2 + ((j16 & 3) >> 1), in8 = (j16 & 1) * 8;
+        {
+            const int pb = SLOT_XP + kk * 128;
+            da[hl] = pb + (((wm * 4 + sub) ^ (((pb >> 8) & 1) << 2)) << 4) + in8;
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int pb = (w * XPX + pc + kw) * 128;
+            xa[kw][hl] = pb + (((wn * 4 + sub) ^ (((pb >> 8) & 1) << 2)) << 4) + in8;
+        }
+    }
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+    uint4 X[3][3];                                      // [x row mod 3][kw]
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) X[s_][kw] = make_uint4(0, 0, 0, 0);
+
+    auto xfrag = [&](const char* sl, int i, int kw) {
+        const uint2 lo = tr_read(sl + i * XROWB + xa[kw][0]), hi = tr_read(sl + i * XROWB + xa[kw][1]);
+        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    };
+    auto dfrag = [&](const char* sl, int i) {
+        const uint2 lo = tr_read(sl + i * DYROWB + da[0]), hi = tr_read(sl + i * DYROWB + da[1]);
+        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    };
+
+    wait_vm<(RD - 2) * ND>();
+    __builtin_amdgcn_s_barrier();
+
+    // ---- phase 0: the two x rows above the walkers' first output row go into the fragment registers -------------
+    {
+#pragma unroll
+        for (int k = 0; k < ND; ++k) issue(k, RD - 1);
+#pragma unroll
+        for (int i = 1; i < 3; ++i)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) X[(i + 1) % 3][kw] = xfrag(smem, i, kw);
+        wait_vm<(RD - 2) * ND>();
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- main loop ---------------------------------------------------------------------------------------------
+    const int nphase = a.nphase;
+    int ring = 1 % RD;
+    for (int q = 1; q < nphase; ++q) {
+        const char* sl = smem + ring * SLOT;
+        uint4 A = dfrag(sl, 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            uint4 Xn[3];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) Xn[kw] = xfrag(sl, i, kw);
+            uint4 An = A;
+            if (i < 2) An = dfrag(sl, i + 1);
+            // kernel rows 0 and 1 from the registers (x rows R-1, R), row 2 from the row just read (R+1)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) mma(acc[kw], A, X[(i + 2) % 3][kw]);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(i, q + RD - 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) mma(acc[3 + kw], A, X[i % 3][kw]);
+            if (i == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue(3, q + RD - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                X[(i + 1) % 3][kw] = Xn[kw];
+                mma(acc[6 + kw], A, Xn[kw]);
+            }
+            A = An;
+        }
+        static_assert(ND == 4, "issue points above");
+        wait_vm<(RD - 2) * ND>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        ring = (ring + 1 == RD) ? 0 : ring + 1;
+    }
+    wait_vm<0>();                                       // (the tail's dead DMAs must land before the LDS is released)
+
+    const int l31 = lane & 31, h = lane >> 5;
+    const int ci = ci0 + wn * 32 + l31;
+    const long long plane = (long long)a.Cout * a.Cin;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            atomicAdd(a.dwt + tp * plane + (long long)co * a.Cin + ci, acc[tp][r]);
+        }
+}
+
+template <int SC, int RD>
+static int wgrad_walk_launch(const void* dy, const void* x, float* dwt, int N, int H, int W, int Cin, int Cout, long long ps,
+                             int target_blocks, hipStream_t st) {
+    constexpr int NW = 16 / SC;
+    WalkArgs a;
+    a.dy = (const char*)dy; a.x = (const char*)x; a.dwt = dwt;
+    void* zp = nullptr;
+    if (hipGetSymbolAddress(&zp, HIP_SYMBOL(wgw_zero_page)) != hipSuccess || !zp) return YOLO_EINVAL;
+    a.zero = (const char*)zp;
+    a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.x_pixb = (unsigned)Cin * 2; a.dy_pixb = (unsigned)ps * 2;
+    a.x_rowb = (unsigned)W * a.x_pixb; a.dy_rowb = (unsigned)W * a.dy_pixb;
+    a.tiles_ci = Cin / 64;
+    a.ntiles = a.tiles_ci * (Cout / 64);
+    a.ncolseg = (W + SC - 1) / SC;
+    a.NR = N * (H + 1);
+    const long long per_slice = (long long)a.ntiles * a.ncolseg;
+    long long slices = (target_blocks + per_slice / 2) / per_slice;
+    if (slices < 1) slices = 1;
+    // rows per walker: a multiple of 3, at least 6 phases of work per block
+    long long Lw = (a.NR + slices * NW - 1) / (slices * NW);
+    Lw = (Lw + 2) / 3 * 3;
+    if (Lw < 18) Lw = 18;
+    slices = (a.NR + Lw * NW - 1) / (Lw * NW);
+    a.L = (int)Lw;
+    a.nphase = 1 + a.L / 3;
+    const long long grid = per_slice * slices;
+    if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
+    a.d_h1 = make_fastdiv((unsigned)(H + 1));
+    a.d_tiles = make_fastdiv((unsigned)a.ntiles);
+    a.d_colseg = make_fastdiv((unsigned)a.ncolseg);
+    YOLO_LAUNCH((wgrad_walk_kernel<SC, RD>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}
+
+// variant: 0 = pick by the map width; 1 = one 16-column walker; 2 = four 4-column walkers.  EUNSUPPORTED when the
+// shape is outside the kernel's domain (the caller falls back on the kernels of train.hip).
+int wgrad_walk_dispatch(const void* dy, const void* x, float* dwt, int N, int H, int W, int Cin, int Cout, long long ps,
+                        int variant, hipStream_t st) {
+    if ((Cin % 64) || (Cout % 64) || (ps % 8) || W < 4 || H < 2) return YOLO_EUNSUPPORTED;
+    if ((long long)N * H * W * Cin * 2 >= 0xffffff00LL || (long long)N * H * W * ps * 2 >= 0xffffff00LL) return YOLO_EUNSUPPORTED;
+    if ((long long)N * (H + 1) >= 0x3fffffffLL) return YOLO_EUNSUPPORTED;
+    if (variant == 0) {
+        // K-step efficiency W / (SC * ceil(W / SC)); four narrow walkers move 40 instead of 34 pixels per K-step row
+        const double e16 = (double)W / (16 * ((W + 15) / 16)), e4 = (double)W / (4 * ((W + 3) / 4));
+        variant = (e4 > e16 * 1.10) ? 2 : 1;
+    }
+    const int target = 512;                                  // two blocks per CU
+    if (variant == 1) return wgrad_walk_launch<16, 4>(dy, x, dwt, N, H, W, Cin, Cout, ps, target, st);
+    if (variant == 2) return wgrad_walk_launch<4, 4>(dy, x, dwt, N, H, W, Cin, Cout, ps, target, st);
+    return YOLO_EUNSUPPORTED;
+}

@@ -75,6 +75,7 @@ SIGNATURES = {
     'yolo_bn_train_bwd_pp': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _f, _i, _vp]),
     'yolo_conv_wgrad_workspace_bytes': (_ll, [_i, _i, _i, _i]),
     'yolo_conv_wgrad': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ll, _i, _vp, _vp]),
+    'yolo_conv_wgrad_algo': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ll, _i, _vp, _i, _vp]),
     'yolo_bias_grad': (_i, [_vp, _vp, _ll, _i, _ll, _i, _vp]),
     'yolo_gather_rows': (_i, [_vp, _vp, _i, _ll, _i, _i, _ll, _ll, _i, _vp]),
     'yolo_dilate2x': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
