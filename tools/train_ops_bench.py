@@ -11,6 +11,8 @@ ap.add_argument('--batch', type=int, default=32)
 ap.add_argument('--what', default='bn,wgrad')
 ap.add_argument('--iters', type=int, default=20)
 ap.add_argument('--algos', default='0', help='weight-gradient kernels to time (yolo_conv_wgrad_algo ids)')
+ap.add_argument('--k3s1', action='store_true', help='weight gradient: only the 3x3 stride-1 shapes with Cin >= 64')
+ap.add_argument('--cold', action='store_true', help='evict L2 / MALL (1 GiB fill) before every timed launch')
 a = ap.parse_args()
 lib = L.load()
 dev = torch.device('cuda:0')
@@ -21,6 +23,17 @@ p = lambda t: t.data_ptr() if t is not None else None
 def timed(fn):
     for _ in range(3):
         fn()
+    if a.cold:
+        global _scratch
+        if '_scratch' not in globals():
+            _scratch = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        tot = 0.0
+        for _ in range(a.iters):
+            _scratch.fill_(1.0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+            tot += e0.elapsed_time(e1)
+        return tot * 1e3 / a.iters
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.iters):
@@ -57,6 +70,8 @@ WG_SHAPES = [(208, 32, 64, 3, 2), (208, 32, 64, 3, 1), (208, 64, 32, 1, 1), (104
              (13, 512, 1024, 3, 1), (13, 1024, 512, 1, 1), (416, 8, 32, 3, 1)]
 if 'wgrad' in a.what:
     for ho, ci, co, k, s in WG_SHAPES:
+        if a.k3s1 and not (k == 3 and s == 1 and ci >= 64):
+            continue
         H = ho * s
         x = torch.randn((a.batch, H, H, ci), device=dev).bfloat16()
         dy = torch.randn((a.batch, ho, ho, co), device=dev).bfloat16()

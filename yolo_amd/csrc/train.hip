@@ -5,6 +5,7 @@
 // (yolo_pack_conv_weights_dgrad).  Reference: car/YOLO.py:350-498 (_train_batch, _find_best, _loss_mask,
 // _score_weight, _get_loss) + the mxnet/gluon operators they call.
 #include "common.h"
+#include <stdlib.h>
 #include "conv_args.h"
 #include <float.h>
 
@@ -1026,8 +1027,9 @@ int wgrad_walk_dispatch(const void* dy, const void* x, float* dwt, int N, int H,
 extern "C" int yolo_conv_wgrad(const void* dy, const void* x, float* dw_oihw, int N, int H, int W, int Cin, int Cout,
                                int ksize, int stride, long long dy_pixel_stride, int dtype, void* workspace,
                                void* stream) {
-    return yolo_conv_wgrad_algo(dy, x, dw_oihw, N, H, W, Cin, Cout, ksize, stride, dy_pixel_stride, dtype, workspace, 0,
-                                stream);
+    static const int legacy = getenv("YOLO_WGRAD_LEGACY") ? 1 : 0;      // (A/B knob: the register-staged kernels only)
+    return yolo_conv_wgrad_algo(dy, x, dw_oihw, N, H, W, Cin, Cout, ksize, stride, dy_pixel_stride, dtype, workspace,
+                                legacy, stream);
 }
 
 // algo: 0 = the library's choice; 1 = the register-staged kernels (per-tap / strip / row-group); 2 / 3 = the row-walk
@@ -1052,13 +1054,8 @@ extern "C" int yolo_conv_wgrad_algo(const void* dy, const void* x, float* dw_oih
     (void)hipGetLastError();
     const long long total = (long long)Cin * Cout * taps;
     if (algo != 1 && ksize == 3 && stride == 1) {
-        const int rc = wgrad_walk_dispatch(dy, x, (float*)workspace, N, H, W, Cin, Cout, ps, algo ? algo - 1 : 0, st);
-        if (rc == YOLO_OK) {
-            YOLO_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (float*)workspace,
-                        dw_oihw, Cout, Cin, taps, total);
-            YOLO_LAUNCH_CHECK();
-            return YOLO_OK;
-        }
+        // (adds straight into dw_oihw: no workspace, no finishing pass)
+        const int rc = wgrad_walk_dispatch(dy, x, dw_oihw, N, H, W, Cin, Cout, ps, algo ? algo - 1 : 0, st);
         if (rc != YOLO_EUNSUPPORTED || algo) return rc;
     } else if (algo > 1) {
         return YOLO_EUNSUPPORTED;

@@ -22,11 +22,12 @@
 //     loop).  Lane-linear DMA images: the bank-conflict swizzle (64-byte halves of a pixel's 128 bytes exchanged
 //     on odd 256-byte lines) is applied to the per-lane SOURCE address and again by the reader;
 //   * blocks that share the rows (the cout x cin tiles of one walker set) are consecutive on one XCD.
-// Partial sums of the blocks are added atomically into the zeroed [tap][Cout][Cin] fp32 workspace, which
-// wgrad_finish_kernel (train.hip) folds into the OIHW gradient.
+// Partial sums of the blocks are added atomically straight into the OIHW fp32 gradient (each wave transposes its
+// accumulators through LDS first: 256 contiguous bytes per atomic instruction, no workspace, no finishing pass).
 #include "common.h"
 #include "conv_args.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 typedef __attribute__((address_space(3))) char lds_char;
@@ -47,6 +48,7 @@ struct WalkArgs {
     int L;                         // stacked rows per walker (a multiple of 3)
     int NR;                        // N * (H + 1) stacked rows
     int nphase;                    // 1 (fragment pre-load) + L / 3
+    int dbg;                       // timing ablations (YOLO_WW_DBG): 1 = no epilogue atomics, 2 = DMAs from the zero page only
     FastDiv d_h1, d_tiles, d_colseg;
 };
 
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_walk_kernel(WalkArgs a) {
         const unsigned rowb = isx ? a.x_rowb : a.dy_rowb;
         const char* base = isx ? a.x : a.dy;
         const char* src = base + ((size_t)(unsigned)(R - n - 1) * rowb + d_co[k]);
-        src = ok ? src : a.zero;
+        src = (ok && !(a.dbg & 2)) ? src : a.zero;
         dma16(src, wave_lds + (qs % RD) * SLOT + k * 4096);
     };
 
@@ -247,18 +249,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_walk_kernel(WalkArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         ring = (ring + 1 == RD) ? 0 : ring + 1;
     }
-    wait_vm<0>();                                       // (the tail's dead DMAs must land before the LDS is released)
+    wait_vm<0>();                                       // (the tail's dead DMAs must land before the LDS is re-used / released)
 
+    // ---- epilogue: straight into the OIHW gradient.  A lane holds 16 cout x 1 cin x 9 taps; dw[co][ci][kh][kw] wants the
+    //      (cin, tap) pairs of one cout contiguous (288 floats per wave), so every wave transposes its tile through its
+    //      own 9 KiB of the (now idle) ring in four passes of 8 cout rows and adds 256 contiguous bytes per instruction.
+    __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring
+    if (a.dbg & 1) return;
     const int l31 = lane & 31, h = lane >> 5;
-    const int ci = ci0 + wn * 32 + l31;
-    const long long plane = (long long)a.Cout * a.Cin;
+    float* scr = (float*)(smem + wave * 9216);
+    float* drow = a.dwt + ((long long)(co0 + wm * 32) * a.Cin + (ci0 + wn * 32)) * 9;
+    const long long co_pitch = (long long)a.Cin * 9;
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp)
+    for (int p = 0; p < 4; ++p) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            atomicAdd(a.dwt + tp * plane + (long long)co * a.Cin + ci, acc[tp][r]);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) scr[((j + 4 * h) * 32 + l31) * 9 + tp] = acc[tp][4 * p + j];
+#pragma unroll
+        for (int t = 0; t < 36; ++t) {
+            const int idx = t * 64 + lane;              // [row 0..7][288]
+            const int row = idx / 288, rem = idx - row * 288;
+            const int co_l = (row & 3) + 8 * p + 4 * (row >> 2);
+            atomicAdd(drow + co_l * co_pitch + rem, scr[idx]);
         }
+    }
 }
 
 template <int SC, int RD>
@@ -278,15 +293,17 @@ static int wgrad_walk_launch(const void* dy, const void* x, float* dwt, int N, i
     a.ncolseg = (W + SC - 1) / SC;
     a.NR = N * (H + 1);
     const long long per_slice = (long long)a.ntiles * a.ncolseg;
-    long long slices = (target_blocks + per_slice / 2) / per_slice;
+    long long slices = target_blocks / per_slice;            // rounded DOWN: a few blocks over one resident round cost a second one
     if (slices < 1) slices = 1;
     // rows per walker: a multiple of 3, at least 6 phases of work per block
     long long Lw = (a.NR + slices * NW - 1) / (slices * NW);
     Lw = (Lw + 2) / 3 * 3;
     if (Lw < 18) Lw = 18;
-    slices = (a.NR + Lw * NW - 1) / (Lw * NW);
+    slices = (a.NR + Lw * NW - 1) / (Lw * NW);               // (never more than before: Lw was rounded up)
     a.L = (int)Lw;
     a.nphase = 1 + a.L / 3;
+    a.dbg = 0;
+    if (const char* e = getenv("YOLO_WW_DBG")) a.dbg = atoi(e);
     const long long grid = per_slice * slices;
     if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
     a.d_h1 = make_fastdiv((unsigned)(H + 1));
@@ -309,8 +326,12 @@ int wgrad_walk_dispatch(const void* dy, const void* x, float* dwt, int N, int H,
         const double e16 = (double)W / (16 * ((W + 15) / 16)), e4 = (double)W / (4 * ((W + 3) / 4));
         variant = (e4 > e16 * 1.10) ? 2 : 1;
     }
-    const int target = 512;                                  // two blocks per CU
-    if (variant == 1) return wgrad_walk_launch<16, 4>(dy, x, dwt, N, H, W, Cin, Cout, ps, target, st);
-    if (variant == 2) return wgrad_walk_launch<4, 4>(dy, x, dwt, N, H, W, Cin, Cout, ps, target, st);
+    int target = 512;                                        // two blocks per CU
+    int rd = 4;
+    if (const char* e = getenv("YOLO_WW_TARGET")) target = atoi(e);
+    if (const char* e = getenv("YOLO_WW_RD")) rd = atoi(e);
+#define WW_CASE(SC_, RD_) if (variant == (SC_ == 16 ? 1 : 2) && rd == RD_) return wgrad_walk_launch<SC_, RD_>(dy, x, dwt, N, H, W, Cin, Cout, ps, target, st);
+    WW_CASE(16, 3) WW_CASE(16, 4) WW_CASE(16, 5) WW_CASE(4, 3) WW_CASE(4, 4) WW_CASE(4, 5)
+#undef WW_CASE
     return YOLO_EUNSUPPORTED;
 }
