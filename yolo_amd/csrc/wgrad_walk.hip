@@ -321,10 +321,11 @@ int wgrad_walk_dispatch(const void* dy, const void* x, float* dwt, int N, int H,
     if ((Cin % 64) || (Cout % 64) || (ps % 8) || W < 4 || H < 2) return YOLO_EUNSUPPORTED;
     if ((long long)N * H * W * Cin * 2 >= 0xffffff00LL || (long long)N * H * W * ps * 2 >= 0xffffff00LL) return YOLO_EUNSUPPORTED;
     if ((long long)N * (H + 1) >= 0x3fffffffLL) return YOLO_EUNSUPPORTED;
+    // four 4-column walkers win on every map width of the 416 / 608 families (13 ... 152): no K padding beyond W % 4, and
+    // 40 instead of 34 staged pixels per K-step row cost less than the 16-column walker's padding
     if (variant == 0) {
-        // K-step efficiency W / (SC * ceil(W / SC)); four narrow walkers move 40 instead of 34 pixels per K-step row
-        const double e16 = (double)W / (16 * ((W + 15) / 16)), e4 = (double)W / (4 * ((W + 3) / 4));
-        variant = (e4 > e16 * 1.10) ? 2 : 1;
+        variant = 2;
+        if (const char* e = getenv("YOLO_WW_SC")) variant = atoi(e) == 16 ? 1 : 2;       // (A/B knob)
     }
     int target = 512;                                        // two blocks per CU
     int rd = 4;
