@@ -88,9 +88,28 @@ typedef struct yolo_conv_desc {
                               (N,2Ho,2Wo,*) map -- gluoncv _upsample(x, stride=2) (car/utils.py:92) fused into the
                               producing convolution; strides then refer to that map (y_batch_stride 0 =
                               4*Ho*Wo*y_pixel_stride); no residual, no out_f32                */
+    /* Training step: Gluon BatchNorm's batch statistics taken in the convolution's epilogue instead of
+     * in a pass of their own over the tensor.  stats != NULL: the kernel also writes yolo_conv_stats_rows() partial rows
+     * [row][2][yolo_padded_channels(Cout)] float32 of per-channel sums over its pixel tiles (no atomics), which
+     * yolo_bn_train_fwd_partials / yolo_bn_train_bwd_partials reduce in double.  stats_mode 1: sum(y), sum(y^2) of the
+     * output y (the BatchNorm that follows this convolution in the forward pass).  stats_mode 2 (a data gradient,
+     * y = d(loss)/d(z) of the layer BEHIND it): sum(da), sum(da * xhat) with da = y * lrelu'(gamma*xhat + beta),
+     * xhat = (stats_y - mean) * invstd, stats_y = that layer's raw convolution output (same shape as y, dense).
+     * bf16, pipelined kernels only (YOLO_EUNSUPPORTED otherwise: run the separate reduction). */
+    void* stats;
+    int stats_mode;
+    const void* stats_y;
+    const float* stats_mean;
+    const float* stats_invstd;
+    const float* stats_gamma;
+    const float* stats_beta;
+    float stats_slope;
 } yolo_conv_desc;
 
 int yolo_conv_fwd(const yolo_conv_desc* d, void* stream);
+/* Partial rows yolo_conv_fwd would write into d->stats (> 0), or YOLO_EUNSUPPORTED if the kernel it would launch for `d`
+ * has no statistics epilogue.  Host-only, no launch; d->stats only has to be non-NULL. */
+int yolo_conv_stats_rows(const yolo_conv_desc* d);
 /* Name of the kernel instantiation yolo_conv_fwd would launch for `d` (as rocprofv3 prints it);
  * used by bench.py to attribute measured time to the dominant kernel.  Host-only, no launch. */
 int yolo_conv_kernel_name(const yolo_conv_desc* d, char* buf, int len);

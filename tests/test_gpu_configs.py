@@ -43,7 +43,11 @@ def _kink_flips(dy, dy_ref, a_ref, tol, frac=2e-5):
     bad = err > tol
     if bool(bad.any()):
         assert float(bad.double().mean()) <= frac, 'too many elements off: %d of %d' % (int(bad.sum()), bad.numel())
-        assert float(a_ref[bad].abs().max()) <= 2e-5 * float(a_ref.abs().max()), 'an element far from the kink is off'
+        far = float(a_ref[bad].abs().max()) > 2e-5 * float(a_ref.abs().max())
+        if far:
+            print('off elements (n, c, y, x) -> got / want:',
+                  [(i, float(dy[tuple(i)]), float(dy_ref[tuple(i)])) for i in bad.nonzero()[:24].tolist()])
+        assert not far, 'an element far from the kink is off'
     return bad
 
 
@@ -112,8 +116,12 @@ def _one_hop_check(tr, P, cap, params, tol, tol_w, rb, exact_kink=True):
             np.testing.assert_allclose(op['mean'].cpu().numpy(), yraw.double().mean(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-5)
             # backward, one hop (for the branch decisions the implementation took at the kink of LeakyReLU)
             dy = _nchw(cap[c.name]['dy'])
+            assert bool(torch.isfinite(dy).all()), 'dy of %s has elements its BatchNorm backward did not write' % c.name
             if exact_kink:
-                flips = _kink_flips(dy, dy_ref, aref, tol)
+                try:
+                    flips = _kink_flips(dy, dy_ref, aref, tol)
+                except AssertionError as e:
+                    raise AssertionError('bn bwd dy %s: %s' % (c.name, str(e).splitlines()[0]))
                 if bool(flips.any()):
                     nflip[0] += int(flips.sum())
                     _, dy_ref, dg_ref, db_ref, _ = ot.bn_act_backward(yraw, gam, bet, dz, flip=flips)

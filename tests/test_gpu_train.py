@@ -308,3 +308,43 @@ def test_carlpnet_train_step(cuda):
     for _ in range(30):
         last = float(tr.train_step(xt, lt, lp_labels=lpt).sum())
     assert last < 0.7 * first, (first, last)
+
+
+def test_two_stream_step_every_bn_backward_consistent(cuda):
+    """The weight gradients run on a side stream beside the BatchNorm backward and the data gradients.  Every dy the
+    BatchNorm backward stored is re-derived on the GPU from exactly what the kernel read (the captured dz, the saved raw
+    output and statistics): built with packed fp32 operations (v_pk_mul_f32 / v_pk_add_f32) the apply pass stored wrong
+    values -- the low element of a pair in lanes 48-63, exact zeros mostly, 1-3 times per step at batch 4 -- whenever MFMA
+    kernels of the other stream shared its CUs (csrc/Makefile: -packed-fp32-ops).  D53 spec, 416x416, six steps."""
+    from yolo_amd.net import CarNet
+    from yolo_amd.train import Trainer
+    from yolo_amd.spec import darknet53_spec, LEAKY_SLOPE
+    net = CarNet(darknet53_spec(), dtype='bf16', device=cuda).initialize(seed=1234)
+    tr = Trainer(net, (416, 416))
+    B = 4
+    x = torch.rand((B, 3, 416, 416), generator=torch.Generator().manual_seed(1)).to(cuda)
+    lab = -torch.ones((B, 1, 30)); lab[:, 0, 0] = 3.0; lab[:, 0, 1:5] = torch.tensor([.5, .5, .4, .3]); lab[:, 0, 5] = 0.1
+    lab[:, 0, 6:] = 1.0 / 24
+    lab = lab.to(cuda)
+    bad = []
+    for it in range(6):
+        cap = {}
+        tr.train_step(x, lab, update=False, capture=cap)
+        torch.cuda.synchronize()
+        for op in tr._last[0].fwd:
+            if op['kind'] != 'conv_bn':
+                continue
+            c = op['c']
+            dz, dy, y = cap[c.name]['dz'].float(), cap[c.name]['dy'].float(), op['yraw'].val.float()
+            g, b = net.params[c.name + '.gamma'].float(), net.params[c.name + '.beta'].float()
+            xh = (y - op['mean']) * op['invstd']
+            a = g * xh + b
+            da = dz * torch.where(a > 0, 1.0, LEAKY_SLOPE)
+            n = y.shape[0] * y.shape[1] * y.shape[2]
+            k1 = (da.double().sum(dim=(0, 1, 2)) / n).float()
+            k2 = ((da * xh).double().sum(dim=(0, 1, 2)) / n).float()
+            ref = g * op['invstd'] * (da - k1 - xh * k2)
+            off = ((dy - ref).abs() > 0.02 * ref.abs().max()) & (a.abs() > 1e-3)
+            if bool(off.any()):
+                bad.append((it, c.name, int(off.sum()), int((dy[off] == 0).sum())))
+    assert not bad, bad

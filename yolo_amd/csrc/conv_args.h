@@ -39,6 +39,13 @@ struct ConvArgs {
     long long y_bs, y_ps;
     long long r_bs, r_ps;   // residual strides (elements); differ from y's when y is a channel slice of a wider buffer
     FastDiv d_PW, d_H1, d_TWt, d_Ho, d_HoWo, d_tc, d_tps;   // divisors PW, H+1, TWt, Ho, Ho*Wo, tiles_c, tiles_per_strip
+    // BatchNorm batch statistics folded into the epilogue (training step; conv_epilogue.h): per (pixel tile, pixel wave)
+    // partial column sums [rows][2][Cout_pad] fp32, summed in double by bn_stats_finish_kernel (train.hip)
+    float* stats;           // nullptr: none
+    int stats_mode;         // 1: sum(y), sum(y^2) of the output; 2: sum(da), sum(da * xhat) of the BatchNorm BEHIND the output
+    const char* s_y;        // mode 2: that layer's raw convolution output (same shape as the output here), dense
+    const float* s_mean; const float* s_invstd; const float* s_gamma; const float* s_beta;
+    float s_slope;
 };
 
 static inline void conv_args_fastdiv(ConvArgs& a) {
@@ -49,7 +56,7 @@ static inline void conv_args_fastdiv(ConvArgs& a) {
 
 // `name` != nullptr: write the kernel instantiation that WOULD run (rocprofv3's demangled name) and
 // do not launch.
-struct NameOut { char* buf; int len; };
+struct NameOut { char* buf; int len; int* stats_rows; };     // stats_rows: receives the partial-row count (-1: the kernel has no statistics epilogue)
 
 // Worst-case number of LDS slots of the zero-padded input halo tile for a BP-pixel output tile on
 // strips of width d (stride S; KS = 3: 3x3, pad 1; KS = 2: 2x2 window anchored at the output pixel, zero row / column

@@ -17,9 +17,16 @@
 // (residual offsets, when the residual's strides differ from the output's)
 #define YOLO_EPI_WAVE_BYTES 9728
 
-template <typename T, int MI, int NI>
+// STATS (bf16, transposed path only; the host checks): BatchNorm batch statistics of the training step taken here instead
+// of in a pass of their own over the tensor.  After the transpose a lane owns 8 channels of one pixel row, so the column
+// sums are plain per-lane accumulations over the lane's rows; the 64 / LPR lanes that share the channels are combined
+// through the wave's scratch once per tile and the wave writes ONE partial row (no atomics: the atomic version of this
+// fusion doubled the step time).  1: sum(v), sum(v^2) of the output; 2: the backward sums of the BatchNorm whose output
+// gradient this kernel produces (a data gradient): da = v * lrelu'(gamma*xhat + beta), sum(da), sum(da * xhat).
+template <typename T, int MI, int NI, int STATS = 0>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long long (&yoff)[NI], char* wsm,
-                                              const ConvArgs& a, int co_w, int lane, const long long* roff = nullptr) {
+                                              const ConvArgs& a, int co_w, int lane, const long long* roff = nullptr,
+                                              float* srow = nullptr) {
     constexpr int WN = MI * 32;                 // couts of the wave tile
     constexpr int RS = WN * 4 + 16;             // fp32 row stride in the scratch (bytes)
     constexpr int ES = (int)sizeof(T);
@@ -151,6 +158,19 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
     const bool res_sep = has_res && roff != nullptr && (a.r_ps != a.y_ps || a.r_bs != a.y_bs);
     long long yo[2][NPASS];
     uint4 rv[2][NPASS];
+    uint4 sv[2][NPASS];                     // STATS == 2: the forward raw outputs under this lane's gradients
+    float ssum[CPL], qsum[CPL], smu[CPL], sis[CPL], sga[CPL], sbe[CPL];
+    if constexpr (STATS != 0) {
+        static_assert(ES == 2, "statistics epilogue: bf16 only");
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) {
+            ssum[e] = qsum[e] = 0.f;
+            if (STATS == 2) {
+                smu[e] = co_ok ? a.s_mean[co + e] : 0.f; sis[e] = co_ok ? a.s_invstd[co + e] : 0.f;
+                sga[e] = co_ok ? a.s_gamma[co + e] : 0.f; sbe[e] = co_ok ? a.s_beta[co + e] : 0.f;
+            }
+        }
+    }
     auto prefetch = [&](int ni) {
         if (h == 0) ytab[(ni & 1) * 32 + l31] = yoff[ni];
         if (res_sep && h == 1) rtab[(ni & 1) * 32 + l31] = roff[ni];
@@ -162,6 +182,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                 rv[ni & 1][k] = make_uint4(0, 0, 0, 0);
                 const long long ro = res_sep ? rtab[(ni & 1) * 32 + row0 + k * RPP] : yo[ni & 1][k];
                 if (yo[ni & 1][k] >= 0) rv[ni & 1][k] = *(const uint4*)(a.res + (ro + cofs) * ES);
+            }
+        }
+        if constexpr (STATS == 2) {
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k) {
+                sv[ni & 1][k] = make_uint4(0, 0, 0, 0);
+                if (yo[ni & 1][k] >= 0) sv[ni & 1][k] = *(const uint4*)(a.s_y + (yo[ni & 1][k] + cofs) * ES);
             }
         }
     };
@@ -202,6 +229,20 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                         v[2 * q + 1] += bf16_bits_to_f32(w[q] >> 16);
                     }
                 }
+                if constexpr (STATS == 1) {
+                    // (rows past the end of the tensor carry zeros: their inputs were DMA'd from the zero page)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; qsum[e] += v[e] * v[e]; }
+                } else if constexpr (STATS == 2) {
+                    const uint32_t yw[4] = {sv[ni & 1][k].x, sv[ni & 1][k].y, sv[ni & 1][k].z, sv[ni & 1][k].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float yv = bf16_bits_to_f32((e & 1) ? (yw[e >> 1] >> 16) : (yw[e >> 1] & 0xffffu));
+                        const float xh = (yv - smu[e]) * sis[e];
+                        const float da = (yo[ni & 1][k] >= 0) ? v[e] * ((sga[e] * xh + sbe[e]) > 0.f ? 1.f : a.s_slope) : 0.f;
+                        ssum[e] += da; qsum[e] += da * xh;
+                    }
+                }
                 ov = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
                                 pack_bf16x2(v[6], v[7]));
             } else {
@@ -221,6 +262,22 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                     *(uint4*)(dst + (2LL * a.Wo + 1) * a.y_ps * ES) = ov;
                 }
             }
+        }
+    }
+    if constexpr (STATS != 0) {
+        // combine the RPP lanes that share a channel run: every lane parks its 16 sums in the scratch (64 B per lane), then
+        // lane o (and o + 64) of the LPR * 16 outputs adds its column and writes it into the wave's partial row
+        float* sc4 = (float*)wsm;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc4[lane * 16 + e] = ssum[e]; sc4[lane * 16 + 8 + e] = qsum[e]; }
+#pragma unroll
+        for (int o = lane; o < LPR * 16; o += 64) {
+            const int cx = o >> 4, val = o & 15;
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < RPP; ++r) t += sc4[(r * LPR + cx) * 16 + val];
+            const int c = co_w + cx * CPL + (val & 7);
+            if (c < a.Cout_pad) srow[(val >> 3) * a.Cout_pad + c] = t;
         }
     }
 }

@@ -333,8 +333,21 @@ extern "C" int yolo_conv_fwd(const yolo_conv_desc* d, void* stream) { return con
 
 extern "C" int yolo_conv_kernel_name(const yolo_conv_desc* d, char* buf, int len) {
     if (!buf || len < 16) return YOLO_EINVAL;
-    NameOut nm{buf, len};
+    NameOut nm{buf, len, nullptr};
     return conv_dispatch(d, nullptr, &nm);
+}
+
+// Number of partial rows ([rows][2][yolo_padded_channels(Cout)] float32) yolo_conv_fwd writes into d->stats for this
+// descriptor, or YOLO_EUNSUPPORTED when the kernel it would run has no statistics epilogue.  Host-only, no launch
+// (d->stats only has to be non-NULL).
+extern "C" int yolo_conv_stats_rows(const yolo_conv_desc* d) {
+    if (!d || !d->stats) return YOLO_EINVAL;
+    char buf[256];
+    int rows = -1;
+    NameOut nm{buf, (int)sizeof(buf), &rows};
+    const int rc = conv_dispatch(d, nullptr, &nm);
+    if (rc != YOLO_OK) return rc;
+    return rows > 0 ? rows : YOLO_EUNSUPPORTED;
 }
 
 static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* nm) {
@@ -375,6 +388,18 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     if (a.up2 && (a.res || d->out_f32)) return YOLO_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (d->algo < 0) return YOLO_EINVAL;
+    a.stats = (float*)d->stats; a.stats_mode = d->stats_mode;
+    a.s_y = (const char*)d->stats_y; a.s_mean = d->stats_mean; a.s_invstd = d->stats_invstd;
+    a.s_gamma = d->stats_gamma; a.s_beta = d->stats_beta; a.s_slope = d->stats_slope;
+    if (a.stats) {
+        // BatchNorm statistics in the epilogue: the pipelined kernels only (yolo_conv_stats_rows tells the caller beforehand)
+        if (a.stats_mode != 1 && a.stats_mode != 2) return YOLO_EINVAL;
+        if (a.stats_mode == 2 && (!a.s_y || !a.s_mean || !a.s_invstd || !a.s_gamma || !a.s_beta)) return YOLO_EINVAL;
+        int algo = d->algo;
+        if (algo == 0) algo = conv_auto_algo(a, d->ksize, d->stride, d->dtype);
+        if (algo < 2 || algo == 13 || algo == 14) return YOLO_EUNSUPPORTED;
+        return conv_pipe_dispatch(a, d->ksize, d->stride, d->dtype, algo, st, nm);
+    }
     if (d->algo == 13 || d->algo == 14) return conv_stream_dispatch(a, d->ksize, d->stride, d->dtype, d->algo, st, nm);
     if (d->algo >= 2) return conv_pipe_dispatch(a, d->ksize, d->stride, d->dtype, d->algo, st, nm);
     if (d->algo == 0) {
@@ -417,7 +442,8 @@ extern "C" int yolo_conv_dgrad_s2(const yolo_conv_desc* d, void* stream) {
     a.Cout_pad = round_up(d->Cout, YOLO_COUT_PAD);
     a.nchunks = (d->Cin * 2 + 63) / 64;
     a.out_f32 = 0; a.d2s = 1; a.up2 = 0; a.x_ps = d->Cin; a.slope = d->slope;
-    if (d->x_pixel_stride || d->upsample2x) return YOLO_EUNSUPPORTED;
+    a.stats = nullptr; a.stats_mode = 0;
+    if (d->x_pixel_stride || d->upsample2x || d->stats) return YOLO_EUNSUPPORTED;
     a.y_ps = d->Cout / 4;
     a.y_bs = (long long)a.Ho * a.Wo * d->Cout;
     a.r_ps = a.y_ps; a.r_bs = a.y_bs;                    // (accumulation into dx: same depth-to-space addressing)

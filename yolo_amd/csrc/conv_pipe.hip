@@ -87,7 +87,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // they are interleaved between the MFMAs, and the second half of the waves (which shares SIMDs with
 // the first half) issues them at shifted positions, so a wave stuck in a DMA issue is covered by its
 // SIMD partner's MFMAs.
-template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1, int RD = 0, int KC = 1, int LEAN = 0>
+template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1, int RD = 0, int KC = 1, int LEAN = 0, int STATS = 0>
 __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvArgs a) {
     constexpr int PT = 1;
     constexpr int NW = WAVES_P * WAVES_C;
@@ -448,7 +448,9 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         roff[ni] = (long long)n * a.r_bs + (long long)pix * a.r_ps;
     }
     STAMP(3);
-    conv_epilogue<T, MI, NI>(acc, yoff, smem + wave * YOLO_EPI_WAVE_BYTES, a, co0 + wave_c * MI * 32, lane, roff);
+    // (STATS: one partial row of BatchNorm sums per (pixel tile, pixel wave))
+    float* srow = STATS ? a.stats + ((size_t)tile_p * WAVES_P + wave_p) * 2 * a.Cout_pad : nullptr;
+    conv_epilogue<T, MI, NI, STATS>(acc, yoff, smem + wave * YOLO_EPI_WAVE_BYTES, a, co0 + wave_c * MI * 32, lane, roff, srow);
     STAMP(4);
 #ifdef YOLO_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -487,10 +489,33 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     const long long grid = (long long)a.nstrips * a.tiles_per_strip * a.tiles_c;
     if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
     conv_args_fastdiv(a);
+    // BatchNorm statistics in the epilogue: bf16, the transposed store path (conv_epilogue.h), no sub-pixel / up-sampled
+    // stores; the data-gradient sums (mode 2) only on stride-1 kernels
+    constexpr bool kStats = sizeof(T) == 2 && KS != 2;
+    const bool stats_ok = kStats && !a.out_f32 && !a.d2s && !a.up2 && (a.Cout % 8) == 0 && (a.y_ps % 8) == 0 && (a.y_bs % 8) == 0 &&
+                          (a.stats_mode == 1 || (a.stats_mode == 2 && S == 1 && a.y_ps == a.Cout));
+    if (a.stats && !stats_ok) return YOLO_EUNSUPPORTED;
     if (name) {
         snprintf(name->buf, name->len, "void conv_pipe_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d>(ConvArgs)",
                  sizeof(T) == 2 ? "bf16_t" : "float", KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC, LEAN);
+        if (name->stats_rows) *name->stats_rows = (a.stats && stats_ok) ? a.nstrips * a.tiles_per_strip * WAVES_P : -1;
         return YOLO_OK;
+    }
+    if constexpr (kStats) {
+        if (a.stats && a.stats_mode == 1) {
+            YOLO_LAUNCH((conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC, LEAN, 1>), dim3((unsigned)grid),
+                        dim3(WAVES_P * WAVES_C * 64), 0, st, a);
+            YOLO_LAUNCH_CHECK();
+            return YOLO_OK;
+        }
+        if constexpr (S == 1) {
+            if (a.stats && a.stats_mode == 2) {
+                YOLO_LAUNCH((conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC, LEAN, 2>), dim3((unsigned)grid),
+                            dim3(WAVES_P * WAVES_C * 64), 0, st, a);
+                YOLO_LAUNCH_CHECK();
+                return YOLO_OK;
+            }
+        }
     }
     YOLO_LAUNCH((conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC, LEAN>), dim3((unsigned)grid),
                 dim3(WAVES_P * WAVES_C * 64), 0, st, a);

@@ -25,7 +25,10 @@ class ConvDesc(C.Structure):
                 ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int),
                 ('ksize', C.c_int), ('stride', C.c_int), ('dtype', C.c_int), ('out_f32', C.c_int),
                 ('slope', C.c_float), ('y_batch_stride', C.c_longlong), ('y_pixel_stride', C.c_longlong),
-                ('algo', C.c_int), ('x_pixel_stride', C.c_longlong), ('upsample2x', C.c_int)]
+                ('algo', C.c_int), ('x_pixel_stride', C.c_longlong), ('upsample2x', C.c_int),
+                ('stats', C.c_void_p), ('stats_mode', C.c_int), ('stats_y', C.c_void_p), ('stats_mean', C.c_void_p),
+                ('stats_invstd', C.c_void_p), ('stats_gamma', C.c_void_p), ('stats_beta', C.c_void_p),
+                ('stats_slope', C.c_float)]
 
 
 class GridDesc(C.Structure):
@@ -47,6 +50,7 @@ SIGNATURES = {
     'yolo_nhwc_to_nchw': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'yolo_conv_fwd': (_i, [C.POINTER(ConvDesc), _vp]),
     'yolo_conv_kernel_name': (_i, [C.POINTER(ConvDesc), C.c_char_p, _i]),
+    'yolo_conv_stats_rows': (_i, [C.POINTER(ConvDesc)]),
     'yolo_stem_conv_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'yolo_stem_down_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'yolo_res_block_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),

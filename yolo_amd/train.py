@@ -349,12 +349,21 @@ class Trainer(object):
         L.check(lib.yolo_conv_fwd(C.byref(d), st), 'dgrad ' + c.name)
         xin.grad, xin.ready = out, True
 
-    def _wgrad(self, dy, names, launch):
+    def _wgrad_tag(self, c, cin):
+        """Which weight-gradient kernel serves conv c ('walk' = csrc/wgrad_walk.hip); only YOLO_SIDE_FILTER (diagnostics:
+        the classes that go to the side stream) looks at it."""
+        if self.ldt == L.BF16 and c.k == 3 and c.stride == 1 and cin % 64 == 0 and c.cout % 64 == 0:
+            return 'walk'
+        return 'k%ds%d' % (c.k, c.stride)
+
+    def _wgrad(self, dy, names, launch, tag=''):
         """Run launch(stream) -- a weight-gradient call reading dy, which the current stream has just produced -- on the
         side stream (all of them, in order: they share one workspace).  The gradient buckets hear about `names` one
         layer later, once the current stream has been made to wait for that layer's side-stream work."""
         main = torch.cuda.current_stream()
-        if not self._overlap:
+        flt = os.environ.get('YOLO_SIDE_FILTER')                  # (diagnostics: exactly these classes go to the side stream)
+        side = (tag in flt.split(',')) if flt is not None else True
+        if not self._overlap or not side:
             launch(main.cuda_stream)
             self.buckets.done(names)
             return
@@ -404,7 +413,7 @@ class Trainer(object):
                 N, Hh, Ww, Cx = xin.shape
                 self._wgrad(op['dyp'], [c.name + '.weight', c.name + '.bias'], lambda s_, c=c, op=op, xin=xin, N=N, Hh=Hh, Ww=Ww, Cx=Cx, cpad=cpad: L.check(
                     lib.yolo_conv_wgrad(L.ptr(op['dyp']), L.ptr(xin.val), L.ptr(self.gview[c.name + '.weight']),
-                                        N, Hh, Ww, Cx, c.cout, 1, 1, cpad, self.ldt, L.ptr(self.wg_ws), s_), 'wgrad out'))
+                                        N, Hh, Ww, Cx, c.cout, 1, 1, cpad, self.ldt, L.ptr(self.wg_ws), s_), 'wgrad out'), tag='out')
                 self._dgrad(c, op['dyp'], (N, Hh, Ww, cpad), xin, cpad)
             elif kind == 'upcat':
                 up, r, cat = op['up'], op['route'], op['cat']
@@ -422,6 +431,8 @@ class Trainer(object):
                 npix = y.shape[0] * y.shape[1] * y.shape[2]
                 p = self.net.params
                 dy = torch.empty(y.shape, dtype=self.tdt, device=self.dev)
+                if capture is not None and capture.get('_poison'):
+                    dy.fill_(float('nan'))          # (diagnostics: an element the kernel does not write must show)
                 if self._bn3:
                     L.check(lib.yolo_bn_train_bwd(L.ptr(dz), L.ptr(y.val), L.ptr(op['mean']), L.ptr(op['invstd']),
                                                   L.ptr(p[c.name + '.gamma']), L.ptr(p[c.name + '.beta']), L.ptr(dy),
@@ -446,11 +457,12 @@ class Trainer(object):
                         L.check(lib.yolo_conv_wgrad(L.ptr(dy), L.ptr(xin.val), L.ptr(dw8), N, Hh, Ww, 8, c.cout, 3, 1, 0, self.ldt,
                                                     L.ptr(self.wg_ws), s_), 'wgrad stem')
                         self.gview[c.name + '.weight'].copy_(dw8[:, :3])
-                    self._wgrad(dy, names, stem_wgrad)
+                    self._wgrad(dy, names, stem_wgrad, tag='stem')
                 else:
                     self._wgrad(dy, names, lambda s_, c=c, dy=dy, xin=xin, N=N, Hh=Hh, Ww=Ww, Cx=Cx: L.check(
                         lib.yolo_conv_wgrad(L.ptr(dy), L.ptr(xin.val), L.ptr(self.gview[c.name + '.weight']), N, Hh, Ww,
-                                            Cx, c.cout, c.k, c.stride, 0, self.ldt, L.ptr(self.wg_ws), s_), 'wgrad ' + c.name))
+                                            Cx, c.cout, c.k, c.stride, 0, self.ldt, L.ptr(self.wg_ws), s_), 'wgrad ' + c.name),
+                                tag=self._wgrad_tag(c, Cx))
                     self._dgrad(c, dy, y.shape, xin, c.cout)
         self._flush_wgrad()
         if self._overlap:
