@@ -279,6 +279,19 @@ int yolo_bn_train_bwd_pp(const void* dz, const void* y, const float* mean, const
                          const float* gamma, const float* beta, void* dy, float* dgamma, float* dbeta,
                          double* workspace, double* zero_next, int zero_next_count, long long npix, int C, float slope,
                          int dtype, void* stream);
+/* The same two calls with the reduction pass over the tensor(s) replaced by the partial rows a convolution's statistics
+ * epilogue wrote (yolo_conv_desc.stats: stats_mode 1 for the forward call, 2 for the backward call; rows =
+ * yolo_conv_stats_rows(), cout_pad = yolo_padded_channels(C)): one small kernel sums the rows in double, then the apply
+ * pass runs as in the _pp calls.  YOLO_BF16 only. */
+int yolo_bn_train_fwd_partials(const float* partials, int rows, int cout_pad, const void* y, const float* gamma,
+                               const float* beta, const void* residual, void* z, float* mean, float* invstd,
+                               float* running_mean, float* running_var, double* workspace, double* zero_next,
+                               int zero_next_count, long long npix, int C, float eps, float momentum, float slope,
+                               int dtype, void* stream);
+int yolo_bn_train_bwd_partials(const float* partials, int rows, int cout_pad, const void* dz, const void* y,
+                               const float* mean, const float* invstd, const float* gamma, const float* beta,
+                               void* dy, float* dgamma, float* dbeta, double* workspace, double* zero_next,
+                               int zero_next_count, long long npix, int C, float slope, int dtype, void* stream);
 
 
 /* Weight gradient of Conv(k, stride, pad k/2): dw (Cout,Cin,k,k) float32 += sum over pixels of

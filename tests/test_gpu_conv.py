@@ -400,3 +400,96 @@ def test_conv_strided_input_and_upsampled_output(lib, cuda, dtype, case):
         got = ybuf.float().cpu().numpy()
         assert (got[..., :y0] == -7.0).all() and (got[..., y0 + Cout:] == -7.0).all()
         np.testing.assert_array_equal(got[..., y0:y0 + Cout].transpose(0, 3, 1, 2), ref)
+
+
+STATS_CASES = [(2, 64, 13, 13, 128, 3, 1), (3, 64, 26, 26, 64, 1, 1), (2, 32, 16, 24, 24, 3, 1), (1, 128, 52, 52, 256, 3, 1),
+               (4, 256, 13, 13, 512, 1, 1), (2, 64, 26, 26, 128, 3, 2), (5, 32, 7, 9, 16, 1, 1), (2, 128, 19, 19, 72, 3, 1)]
+
+
+@pytest.mark.parametrize('mode', [1, 2])
+@pytest.mark.parametrize('algo', [0, 2, 3, 4, 5, 6, 7, 8, 11, 12, 16, 17, 18, 22, 23])
+@pytest.mark.parametrize('case', STATS_CASES)
+def test_conv_statistics_epilogue(lib, cuda, case, algo, mode):
+    """yolo_conv_desc.stats: Gluon BatchNorm's batch sums taken in the convolution's epilogue (per pixel-tile partial rows,
+    summed in double by yolo_bn_train_*_partials).  Mode 1: sum(y), sum(y^2) of the stored bf16 output; mode 2 (a data
+    gradient with accumulation into an existing gradient): sum(da), sum(da * xhat) of the BatchNorm behind the output.
+    Checked through the whole call: the BatchNorm forward / backward fed by the partial rows must equal the one that
+    reduces the stored tensor itself."""
+    import ctypes as C
+    N, Cin, H, W, Cout, k, stride = case
+    if mode == 2 and stride != 1:
+        pytest.skip('data-gradient sums: stride-1 kernels')
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    st = torch.cuda.current_stream().cuda_stream
+    xd = to_nhwc(x, 'bf16', cuda)
+    wp = torch.empty(lib.yolo_packed_weight_bytes(Cout, Cin, k, L.BF16), dtype=torch.uint8, device=cuda)
+    L.check(lib.yolo_pack_conv_weights(torch.from_numpy(w).to(cuda).data_ptr(), wp.data_ptr(), Cout, Cin, k, L.BF16, st), 'pack')
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    npix = N * Ho * Wo
+    cp = lib.yolo_padded_channels(Cout)
+    gamma = torch.from_numpy(rng.uniform(.5, 1.5, Cout).astype(np.float32)).to(cuda)
+    beta = torch.from_numpy((0.2 * rng.standard_normal(Cout)).astype(np.float32)).to(cuda)
+    y = torch.full((N, Ho, Wo, Cout), float('nan'), dtype=torch.bfloat16, device=cuda)
+    d = L.ConvDesc()
+    d.x, d.w_packed, d.y = xd.data_ptr(), wp.data_ptr(), y.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.dtype, d.slope, d.algo = N, H, W, Cin, Cout, k, stride, L.BF16, 1.0, algo
+    ws = [torch.zeros(2 * Cout, dtype=torch.float64, device=cuda) for _ in range(4)]
+    mk = lambda: (torch.empty(Cout, device=cuda), torch.empty(Cout, device=cuda))
+    if mode == 1:
+        d.stats, d.stats_mode = 1, 1
+        rows = lib.yolo_conv_stats_rows(C.byref(d))
+        if rows == L.EUNSUPPORTED:
+            pytest.skip('variant not eligible for this shape')
+        assert rows > 0
+        part = torch.full((rows, 2, cp), float('nan'), device=cuda)
+        d.stats = part.data_ptr()
+        assert lib.yolo_conv_fwd(C.byref(d), st) == 0
+        (m1, i1), (m2, i2) = mk(), mk()
+        z1, z2 = torch.empty_like(y), torch.empty_like(y)
+        rm, rv = torch.zeros(Cout, device=cuda), torch.ones(Cout, device=cuda)
+        assert lib.yolo_bn_train_fwd_partials(part.data_ptr(), rows, cp, y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None,
+                                              z1.data_ptr(), m1.data_ptr(), i1.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                                              ws[0].data_ptr(), ws[1].data_ptr(), 2 * Cout, npix, Cout, 1e-5, 0.9, 0.1, L.BF16, st) == 0
+        assert lib.yolo_bn_train_fwd_pp(y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, z2.data_ptr(), m2.data_ptr(),
+                                        i2.data_ptr(), rm.data_ptr(), rv.data_ptr(), ws[2].data_ptr(), ws[3].data_ptr(), 2 * Cout,
+                                        npix, Cout, 1e-5, 0.9, 0.1, L.BF16, st) == 0
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(y.float()).all())
+        np.testing.assert_allclose(m1.cpu().numpy(), m2.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(i1.cpu().numpy(), i2.cpu().numpy(), rtol=1e-5)
+        assert float((z1.float() - z2.float()).abs().max()) <= 1e-2 * float(z2.float().abs().max())
+        return
+    # mode 2: the convolution is a data gradient accumulating into an existing gradient; yb = the forward raw output of the
+    # layer behind it, with that layer's saved statistics
+    yb = torch.from_numpy(rng.standard_normal((N, Ho, Wo, Cout)).astype(np.float32)).to(cuda).bfloat16()
+    acc0 = torch.from_numpy((0.5 * rng.standard_normal((N, Ho, Wo, Cout))).astype(np.float32)).to(cuda).bfloat16()
+    mean = yb.float().mean(dim=(0, 1, 2)).contiguous()
+    invstd = (1.0 / torch.sqrt(yb.float().var(dim=(0, 1, 2), unbiased=False) + 1e-5)).contiguous()
+    y.copy_(acc0)
+    d.residual = y.data_ptr()
+    d.stats, d.stats_mode, d.stats_y = 1, 2, yb.data_ptr()
+    d.stats_mean, d.stats_invstd, d.stats_gamma, d.stats_beta, d.stats_slope = (mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                                                               beta.data_ptr(), 0.1)
+    rows = lib.yolo_conv_stats_rows(C.byref(d))
+    if rows == L.EUNSUPPORTED:
+        pytest.skip('variant not eligible for this shape')
+    assert rows > 0
+    part = torch.full((rows, 2, cp), float('nan'), device=cuda)
+    d.stats = part.data_ptr()
+    assert lib.yolo_conv_fwd(C.byref(d), st) == 0
+    dy1, dy2 = torch.empty_like(y), torch.empty_like(y)
+    (g1, b1), (g2, b2) = mk(), mk()
+    assert lib.yolo_bn_train_bwd_partials(part.data_ptr(), rows, cp, y.data_ptr(), yb.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                          gamma.data_ptr(), beta.data_ptr(), dy1.data_ptr(), g1.data_ptr(), b1.data_ptr(),
+                                          ws[0].data_ptr(), ws[1].data_ptr(), 2 * Cout, npix, Cout, 0.1, L.BF16, st) == 0
+    assert lib.yolo_bn_train_bwd_pp(y.data_ptr(), yb.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                    beta.data_ptr(), dy2.data_ptr(), g2.data_ptr(), b2.data_ptr(), ws[2].data_ptr(),
+                                    ws[3].data_ptr(), 2 * Cout, npix, Cout, 0.1, L.BF16, st) == 0
+    torch.cuda.synchronize()
+    sc = float(g2.abs().max()) + float(b2.abs().max())
+    np.testing.assert_allclose(g1.cpu().numpy(), g2.cpu().numpy(), rtol=1e-4, atol=1e-5 * sc)
+    np.testing.assert_allclose(b1.cpu().numpy(), b2.cpu().numpy(), rtol=1e-4, atol=1e-5 * sc)
+    assert float((dy1.float() - dy2.float()).abs().max()) <= 1e-2 * float(dy2.float().abs().max())

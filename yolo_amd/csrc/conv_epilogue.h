@@ -229,22 +229,31 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                         v[2 * q + 1] += bf16_bits_to_f32(w[q] >> 16);
                     }
                 }
-                if constexpr (STATS == 1) {
-                    // (rows past the end of the tensor carry zeros: their inputs were DMA'd from the zero page)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; qsum[e] += v[e] * v[e]; }
-                } else if constexpr (STATS == 2) {
-                    const uint32_t yw[4] = {sv[ni & 1][k].x, sv[ni & 1][k].y, sv[ni & 1][k].z, sv[ni & 1][k].w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float yv = bf16_bits_to_f32((e & 1) ? (yw[e >> 1] >> 16) : (yw[e >> 1] & 0xffffu));
-                        const float xh = (yv - smu[e]) * sis[e];
-                        const float da = (yo[ni & 1][k] >= 0) ? v[e] * ((sga[e] * xh + sbe[e]) > 0.f ? 1.f : a.s_slope) : 0.f;
-                        ssum[e] += da; qsum[e] += da * xh;
-                    }
-                }
                 ov = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
                                 pack_bf16x2(v[6], v[7]));
+                if constexpr (STATS != 0) {
+                    // the statistics of the STORED (bf16-rounded) values: what the separate reduction pass would read
+                    const uint32_t ow[4] = {ov.x, ov.y, ov.z, ov.w};
+                    float vr[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vr[e] = bf16_bits_to_f32((e & 1) ? (ow[e >> 1] >> 16) : (ow[e >> 1] & 0xffffu));
+                    if constexpr (STATS == 1) {
+                        // (lanes past the end of the tensor compute a copy of the tile's first pixel: masked like the store)
+                        if (yo[ni & 1][k] >= 0) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { ssum[e] += vr[e]; qsum[e] += vr[e] * vr[e]; }
+                        }
+                    } else {
+                        const uint32_t yw[4] = {sv[ni & 1][k].x, sv[ni & 1][k].y, sv[ni & 1][k].z, sv[ni & 1][k].w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float yv = bf16_bits_to_f32((e & 1) ? (yw[e >> 1] >> 16) : (yw[e >> 1] & 0xffffu));
+                            const float xh = (yv - smu[e]) * sis[e];
+                            const float da = (yo[ni & 1][k] >= 0) ? vr[e] * ((sga[e] * xh + sbe[e]) > 0.f ? 1.f : a.s_slope) : 0.f;
+                            ssum[e] += da; qsum[e] += da * xh;
+                        }
+                    }
+                }
             } else {
                 if (has_res) {
                     v[0] += __uint_as_float(rv[ni & 1][k].x); v[1] += __uint_as_float(rv[ni & 1][k].y);

@@ -288,16 +288,63 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
     }
 }
 
+// The per-channel sums from the partial rows a convolution's statistics epilogue wrote (conv_epilogue.h, STATS):
+// part [rows][2][Cp] float32 -> sums[0..C) += sum over rows of part[.][0][c], sums[C..2C) += ... part[.][1][c], in double.
+// Block = 64 channels x 4 row lanes over a slice of the rows; one double atomic per (slice, channel, quantity).
+__global__ __launch_bounds__(256) void bn_stats_finish_kernel(const float* __restrict__ part, int rows, int C, int Cp,
+                                                              double* __restrict__ sums, int rows_per_block) {
+    __shared__ double red[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, rows);
+    double s = 0, q = 0;
+    if (c < C) {
+        int r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {                          // four independent loads per quantity in flight
+            float a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = part[((long long)(r + 4 * u) * 2) * Cp + c];
+                b[u] = part[((long long)(r + 4 * u) * 2 + 1) * Cp + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s += a[u]; q += b[u]; }
+        }
+        for (; r < r1; r += 4) { s += part[((long long)r * 2) * Cp + c]; q += part[((long long)r * 2 + 1) * Cp + c]; }
+    }
+    red[0][rl][cl] = s; red[1][rl][cl] = q;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int w = threadIdx.x >> 6;
+        const double t = red[w][0][cl] + red[w][1][cl] + red[w][2][cl] + red[w][3][cl];
+        if (c < C) atomicAdd(&sums[w * C + c], t);
+    }
+}
+
+static void bn_stats_finish(const float* part, int rows, int C, int Cp, double* sums, hipStream_t st) {
+    const int cg = (C + 63) / 64;
+    int split = (192 + cg - 1) / cg;                             // ~192 blocks
+    if (split > (rows + 15) / 16) split = (rows + 15) / 16;      // at least 16 rows per block
+    if (split < 1) split = 1;
+    const int rpb = (rows + split - 1) / split;
+    split = (rows + rpb - 1) / rpb;
+    YOLO_LAUNCH(bn_stats_finish_kernel, dim3(cg, split), dim3(256), 0, st, part, rows, C, Cp, sums, rpb);
+}
+
 template <typename T>
 static int bn_fwd_t(const T* y, const float* gamma, const float* beta, const T* residual, T* z, float* mean,
                     float* invstd, float* running_mean, float* running_var, double* workspace, long long npix, int C,
-                    float eps, float momentum, float slope, hipStream_t st, bool fused = false, double* zero_next = nullptr, int zero_n = 0) {
+                    float eps, float momentum, float slope, hipStream_t st, bool fused = false, double* zero_next = nullptr, int zero_n = 0,
+                    const float* part = nullptr, int part_rows = 0, int part_cp = 0) {
     (void)hipGetLastError();
     int ppb, ppa; unsigned nb, na;
     bn_partition(npix, C, (int)sizeof(T), true, &ppb, &nb);
     bn_partition(npix, C, (int)sizeof(T), false, &ppa, &na);
-    YOLO_LAUNCH((bn_reduce_kernel<T, 0>), dim3(nb, (C + BN_CG - 1) / BN_CG), dim3(256), 0, st, y, (const T*)nullptr, (const float*)nullptr,
-                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, workspace, C, npix, ppb, slope);
+    if (part)       // the producing convolution already took the sums (its statistics epilogue): no pass over y
+        bn_stats_finish(part, part_rows, C, part_cp, workspace, st);
+    else
+        YOLO_LAUNCH((bn_reduce_kernel<T, 0>), dim3(nb, (C + BN_CG - 1) / BN_CG), dim3(256), 0, st, y, (const T*)nullptr, (const float*)nullptr,
+                    (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, workspace, C, npix, ppb, slope);
     BnFused f = {};
     if (fused) {
         f.sums = workspace; f.zero_next = zero_next; f.zero_n = zero_n; f.mean_out = mean; f.invstd_out = invstd;
@@ -333,13 +380,17 @@ extern "C" int yolo_bn_train_fwd(const void* y, const float* gamma, const float*
 template <typename T>
 static int bn_bwd_t(const T* dz, const T* y, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, T* dy, float* dgamma, float* dbeta, double* workspace, long long npix, int C,
-                    float slope, hipStream_t st, bool fused = false, double* zero_next = nullptr, int zero_n = 0) {
+                    float slope, hipStream_t st, bool fused = false, double* zero_next = nullptr, int zero_n = 0,
+                    const float* part = nullptr, int part_rows = 0, int part_cp = 0) {
     (void)hipGetLastError();
     int ppb, ppa; unsigned nb, na;
     bn_partition(npix, C, (int)sizeof(T), true, &ppb, &nb);
     bn_partition(npix, C, (int)sizeof(T), false, &ppa, &na);
-    YOLO_LAUNCH((bn_reduce_kernel<T, 1>), dim3(nb, (C + BN_CG - 1) / BN_CG), dim3(256), 0, st, y, dz, mean, invstd, gamma, beta, workspace, C,
-                npix, ppb, slope);
+    if (part)       // the data gradient that produced dz already took sum(da), sum(da * xhat): no pass over dz and y
+        bn_stats_finish(part, part_rows, C, part_cp, workspace, st);
+    else
+        YOLO_LAUNCH((bn_reduce_kernel<T, 1>), dim3(nb, (C + BN_CG - 1) / BN_CG), dim3(256), 0, st, y, dz, mean, invstd, gamma, beta, workspace, C,
+                    npix, ppb, slope);
     BnFused f = {};
     if (fused) {
         f.sums = workspace; f.zero_next = zero_next; f.zero_n = zero_n; f.dgamma_out = dgamma; f.dbeta_out = dbeta;
@@ -403,6 +454,32 @@ extern "C" int yolo_bn_train_bwd_pp(const void* dz, const void* y, const float* 
         return bn_bwd_t<float>((const float*)dz, (const float*)y, mean, invstd, gamma, beta, (float*)dy, dgamma, dbeta,
                                workspace, npix, C, slope, (hipStream_t)stream, true, zero_next, zero_next_count);
     return YOLO_EINVAL;
+}
+
+// yolo_bn_train_fwd_pp / _bwd_pp with the reduction pass replaced by the partial rows of a convolution's statistics
+// epilogue (yolo_conv_desc.stats; rows = yolo_conv_stats_rows(), cout_pad = yolo_padded_channels(C)); bf16 only.
+extern "C" int yolo_bn_train_fwd_partials(const float* partials, int rows, int cout_pad, const void* y, const float* gamma,
+                                          const float* beta, const void* residual, void* z, float* mean, float* invstd,
+                                          float* running_mean, float* running_var, double* workspace, double* zero_next,
+                                          int zero_next_count, long long npix, int C, float eps, float momentum, float slope,
+                                          int dtype, void* stream) {
+    if (!partials || rows <= 0 || cout_pad < C || !y || !gamma || !beta || !z || !mean || !invstd || !workspace || npix <= 0 ||
+        C <= 0 || workspace == zero_next || zero_next_count < 0) return YOLO_EINVAL;
+    if ((C % 8) || dtype != YOLO_BF16) return YOLO_EUNSUPPORTED;
+    return bn_fwd_t<bf16_t>((const bf16_t*)y, gamma, beta, (const bf16_t*)residual, (bf16_t*)z, mean, invstd, running_mean,
+                            running_var, workspace, npix, C, eps, momentum, slope, (hipStream_t)stream, true, zero_next,
+                            zero_next_count, partials, rows, cout_pad);
+}
+
+extern "C" int yolo_bn_train_bwd_partials(const float* partials, int rows, int cout_pad, const void* dz, const void* y,
+                                          const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                          void* dy, float* dgamma, float* dbeta, double* workspace, double* zero_next,
+                                          int zero_next_count, long long npix, int C, float slope, int dtype, void* stream) {
+    if (!partials || rows <= 0 || cout_pad < C || !dz || !y || !mean || !invstd || !gamma || !beta || !dy || !dgamma || !dbeta ||
+        !workspace || workspace == zero_next || zero_next_count < 0 || npix <= 0 || C <= 0) return YOLO_EINVAL;
+    if ((C % 8) || dtype != YOLO_BF16) return YOLO_EUNSUPPORTED;
+    return bn_bwd_t<bf16_t>((const bf16_t*)dz, (const bf16_t*)y, mean, invstd, gamma, beta, (bf16_t*)dy, dgamma, dbeta, workspace,
+                            npix, C, slope, (hipStream_t)stream, true, zero_next, zero_next_count, partials, rows, cout_pad);
 }
 
 // ------------------------------------------------------------------------------------------------

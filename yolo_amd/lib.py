@@ -77,6 +77,8 @@ SIGNATURES = {
     'yolo_bn_train_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _i, _vp]),
     'yolo_bn_train_fwd_pp': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _f, _f, _f, _i, _vp]),
     'yolo_bn_train_bwd_pp': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _f, _i, _vp]),
+    'yolo_bn_train_fwd_partials': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _f, _f, _f, _i, _vp]),
+    'yolo_bn_train_bwd_partials': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _f, _i, _vp]),
     'yolo_conv_wgrad_workspace_bytes': (_ll, [_i, _i, _i, _i]),
     'yolo_conv_wgrad': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ll, _i, _vp, _vp]),
     'yolo_conv_wgrad_algo': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ll, _i, _vp, _i, _vp]),

@@ -24,10 +24,10 @@ LP_DEFAULT_SCALE = {'LP_score': 0.1, 'LP_xy': 10.0, 'LP_z': 1.0, 'LP_r': 0.1, 'L
 
 class _T(object):
     """An activation of the training graph: forward value + (lazily) its gradient."""
-    __slots__ = ('val', 'shape', 'grad', 'ready')
+    __slots__ = ('val', 'shape', 'grad', 'ready', 'ngot')
 
     def __init__(self, val, shape):
-        self.val, self.shape, self.grad, self.ready = val, shape, None, False
+        self.val, self.shape, self.grad, self.ready, self.ngot = val, shape, None, False, 0
 
 
 class Trainer(object):
@@ -95,6 +95,12 @@ class Trainer(object):
         # previous layer's BN backward) and MFMA-bound, while the BN passes they overlap are HBM-bound
         self._side = torch.cuda.Stream(device=self.dev)
         self._overlap = not os.environ.get('YOLO_TRAIN_SERIAL_WGRAD')          # (the knob keeps the serial order for A/B runs)
+        # BatchNorm sums taken in the producing convolution's epilogue (yolo_conv_desc.stats) instead of in a reduction pass
+        # of their own; (the knob: the separate passes, for A/B runs)
+        self._fuse_stats = self.ldt == L.BF16 and not os.environ.get('YOLO_TRAIN_NO_STATS_FUSION')
+        self._stats_b = None            # partial rows of the data gradients' statistics epilogues (grown on demand)
+        modes = os.environ.get('YOLO_TRAIN_STATS_MODES', '1')    # '1' forward sums, '2' backward sums, '12' both
+        self._fuse_fwd, self._fuse_bwd = self._fuse_stats and '1' in modes, self._fuse_stats and '2' in modes
         self._identity = not os.environ.get('YOLO_TRAIN_UNIT_EPILOGUE')        # (the knob: scale 1 / bias 0 arrays instead of the identity epilogue)
         self._repack()
         self._packed_version = net._version
@@ -163,6 +169,7 @@ class Trainer(object):
         g = self.net.graph
         P = type('Plan', (), {})()
         P.fwd, P.tensors = [], []
+        P.stats_floats = 0
         P.x8 = self._new((B, H, W, 8))
 
         def conv_bn(c, xin, residual=None):
@@ -175,7 +182,16 @@ class Trainer(object):
             ident = (None, None) if self._identity else (ones, zeros)     # raw convolution: identity epilogue
             d = self._conv_desc(xin.val, xin.shape, wp, ident[0], ident[1], yraw.val, Cc, c.cout, c.k, c.stride)
             self._tune(d)
-            P.fwd.append(dict(kind='conv_bn', c=c, x=xin, yraw=yraw, z=z, mean=mean, invstd=invstd, res=residual, desc=d))
+            op = dict(kind='conv_bn', c=c, x=xin, yraw=yraw, z=z, mean=mean, invstd=invstd, res=residual, desc=d, srows=0, brows=0)
+            if self._fuse_fwd and not (c is g.stem) and self._pipe_kernel(d):
+                d.stats, d.stats_mode = 1, 1                      # (any non-NULL pointer for the query)
+                rows = self.lib.yolo_conv_stats_rows(C.byref(d))
+                if rows > 0:
+                    op['srows'] = rows
+                    P.stats_floats = max(P.stats_floats, rows * 2 * self.lib.yolo_padded_channels(c.cout))
+                else:
+                    d.stats, d.stats_mode = None, 0
+            P.fwd.append(op)
             return z
 
         x = conv_bn(g.stem, P.x8)
@@ -235,7 +251,26 @@ class Trainer(object):
             cat = self._new((r.shape[0], r.shape[1], r.shape[2], x.shape[3] + r.shape[3]))
             P.fwd.append(dict(kind='upcat', up=x, route=r, cat=cat))
             x = cat
+        # forward statistics partials: one buffer, consumed by the BatchNorm call right behind each convolution
+        P.stats_f = torch.empty(max(P.stats_floats, 4), dtype=torch.float32, device=self.dev)
+        for op in P.fwd:
+            if op['kind'] == 'conv_bn' and op['srows']:
+                op['desc'].stats = L.ptr(P.stats_f)
+        # which layer produced a tensor, and how many gradient contributions it will receive (its consumers)
+        P.prod, P.nuse = {}, {}
+        for op in P.fwd:
+            if op['kind'] == 'conv_bn':
+                P.prod[id(op['z'])] = op
+            for k in ('x', 'res', 'up', 'route'):
+                t = op.get(k)
+                if t is not None:
+                    P.nuse[id(t)] = P.nuse.get(id(t), 0) + 1
         return P
+
+    def _pipe_kernel(self, d):
+        """True when yolo_conv_fwd serves d with a pipelined kernel (the ones that have a statistics epilogue)."""
+        buf = C.create_string_buffer(256)
+        return self.lib.yolo_conv_kernel_name(C.byref(d), buf, 256) == 0 and b'conv_pipe_kernel' in buf.value
 
     def _next_ws(self):
         """(this call's BatchNorm workspace -- zero --, the one it zeroes for the next call)."""
@@ -270,6 +305,14 @@ class Trainer(object):
                                                   BN_MOMENTUM, LEAKY_SLOPE, self.ldt, st), 'bn ' + c.name)
                     continue
                 ws, wn = self._next_ws()
+                if op['srows']:
+                    L.check(lib.yolo_bn_train_fwd_partials(L.ptr(P.stats_f), op['srows'], lib.yolo_padded_channels(c.cout),
+                                                           L.ptr(y.val), L.ptr(p[c.name + '.gamma']), L.ptr(p[c.name + '.beta']),
+                                                           L.ptr(op['res'].val) if op['res'] is not None else None, L.ptr(z.val),
+                                                           L.ptr(op['mean']), L.ptr(op['invstd']), L.ptr(p[c.name + '.running_mean']),
+                                                           L.ptr(p[c.name + '.running_var']), ws, wn, self.ws2[0].numel(), npix, c.cout,
+                                                           BN_EPS, BN_MOMENTUM, LEAKY_SLOPE, self.ldt, st), 'bn (partials) ' + c.name)
+                    continue
                 L.check(lib.yolo_bn_train_fwd_pp(L.ptr(y.val), L.ptr(p[c.name + '.gamma']), L.ptr(p[c.name + '.beta']),
                                                  L.ptr(op['res'].val) if op['res'] is not None else None, L.ptr(z.val),
                                                  L.ptr(op['mean']), L.ptr(op['invstd']), L.ptr(p[c.name + '.running_mean']),
@@ -285,6 +328,7 @@ class Trainer(object):
     # ---- backward -------------------------------------------------------------------------------------------
     def _accum(self, t, src):
         """grad[t] (+)= src (a tensor of the same shape).  First contribution aliases src."""
+        t.ngot += 1
         if not t.ready:
             t.grad, t.ready = src, True
         else:
@@ -319,6 +363,7 @@ class Trainer(object):
                 rc = lib.yolo_conv_dgrad_s2(C.byref(d), st)
             if rc == 0:
                 xin.grad, xin.ready = out, True
+                xin.ngot += 1
                 return
             if rc != L.EUNSUPPORTED:
                 L.check(rc, 'dgrad_s2 ' + c.name)
@@ -337,6 +382,9 @@ class Trainer(object):
         if self._identity:
             ones = zeros = None
         d = self._conv_desc(src, sshape, wd, ones, zeros, out, cin_of_dy, Cx, c.k, 1, residual=resid)
+        # this call completes d(loss)/d(xin): take the BatchNorm-backward sums of the layer that produced xin in the epilogue
+        P = self._P
+        prod = P.prod.get(id(xin)) if (self._fuse_bwd and c.stride == 1 and xin.ngot + 1 == P.nuse.get(id(xin), 0)) else None
         if getattr(self.net, 'tune', None) == 'measure':
             key = (sshape, cin_of_dy, Cx, c.k, resid is not None)
             if key not in self._dgrad_algo:
@@ -346,8 +394,23 @@ class Trainer(object):
                                      residual=scratch if resid is not None else None)
                 self._dgrad_algo[key] = self.net._measure_algo(dm)
             d.algo = self._dgrad_algo[key]
+        if prod is not None and self._pipe_kernel(d):
+            pc, pp = prod['c'], self.net.params
+            d.stats, d.stats_mode, d.stats_y = 1, 2, L.ptr(prod['yraw'].val)
+            d.stats_mean, d.stats_invstd = L.ptr(prod['mean']), L.ptr(prod['invstd'])
+            d.stats_gamma, d.stats_beta, d.stats_slope = L.ptr(pp[pc.name + '.gamma']), L.ptr(pp[pc.name + '.beta']), LEAKY_SLOPE
+            rows = lib.yolo_conv_stats_rows(C.byref(d))
+            if rows > 0:
+                need = rows * 2 * lib.yolo_padded_channels(Cx)
+                if self._stats_b is None or self._stats_b.numel() < need:
+                    self._stats_b = torch.empty(need, dtype=torch.float32, device=self.dev)
+                d.stats = L.ptr(self._stats_b)
+                prod['brows'] = rows
+            else:
+                d.stats, d.stats_mode = None, 0
         L.check(lib.yolo_conv_fwd(C.byref(d), st), 'dgrad ' + c.name)
         xin.grad, xin.ready = out, True
+        xin.ngot += 1
 
     def _wgrad_tag(self, c, cin):
         """Which weight-gradient kernel serves conv c ('walk' = csrc/wgrad_walk.hip); only YOLO_SIDE_FILTER (diagnostics:
@@ -396,11 +459,14 @@ class Trainer(object):
         self.gflat.zero_()
         self.buckets.reset(enabled=exchange)
         self._pending_wgrad = None
+        self._P = P
         for op in P.fwd:
             for k in ('x', 'z', 'up', 'route', 'cat', 'res'):
                 t = op.get(k)
                 if t is not None:
-                    t.grad, t.ready = None, False
+                    t.grad, t.ready, t.ngot = None, False, 0
+            if op['kind'] == 'conv_bn':
+                op['brows'] = 0
         B = P.merged.shape[0]
         for op in reversed(P.fwd):
             kind = op['kind']
@@ -425,6 +491,8 @@ class Trainer(object):
                                                        r.shape[2], up.shape[3], r.shape[3], int(up.ready), int(r.ready), self.ldt, st),
                         'upcat bwd')
                 up.ready = r.ready = True
+                up.ngot += 1
+                r.ngot += 1
             else:
                 c, xin, y, z = op['c'], op['x'], op['yraw'], op['z']
                 dz = z.grad
@@ -438,6 +506,15 @@ class Trainer(object):
                                                   L.ptr(p[c.name + '.gamma']), L.ptr(p[c.name + '.beta']), L.ptr(dy),
                                                   L.ptr(self.gview[c.name + '.gamma']), L.ptr(self.gview[c.name + '.beta']),
                                                   L.ptr(self.ws), npix, c.cout, LEAKY_SLOPE, self.ldt, st), 'bn bwd ' + c.name)
+                elif op['brows']:
+                    # the data gradient that completed dz took sum(da), sum(da * xhat) in its epilogue
+                    ws, wn = self._next_ws()
+                    L.check(lib.yolo_bn_train_bwd_partials(L.ptr(self._stats_b), op['brows'], lib.yolo_padded_channels(c.cout),
+                                                           L.ptr(dz), L.ptr(y.val), L.ptr(op['mean']), L.ptr(op['invstd']),
+                                                           L.ptr(p[c.name + '.gamma']), L.ptr(p[c.name + '.beta']), L.ptr(dy),
+                                                           L.ptr(self.gview[c.name + '.gamma']), L.ptr(self.gview[c.name + '.beta']),
+                                                           ws, wn, self.ws2[0].numel(), npix, c.cout, LEAKY_SLOPE, self.ldt, st),
+                            'bn bwd (partials) ' + c.name)
                 else:
                     ws, wn = self._next_ws()
                     L.check(lib.yolo_bn_train_bwd_pp(L.ptr(dz), L.ptr(y.val), L.ptr(op['mean']), L.ptr(op['invstd']),
