@@ -252,6 +252,15 @@ typedef struct yolo_pack_item { const float* w_oihw; void* packed; int Cout, Cin
 long long yolo_pack_batch_blocks(int Cout, int Cin, int ksize, int dtype);
 int yolo_pack_conv_weights_batch(const void* items_device, const long long* first_block_device, int n_items,
                                  long long total_blocks, int dtype, void* stream);
+/* The forward and the data-gradient image of every listed conv from ONE read of its weights (YOLO_BF16; Cout and Cin
+ * multiples of 32; 1x1 and 3x3): items_device = n_items records { const float* w_oihw; void* packed_fwd; void*
+ * packed_dgrad; int Cout, Cin, ksize, reserved; } (40 bytes), first_block_device = prefix sums of yolo_pack_pair_blocks()
+ * (YOLO_EUNSUPPORTED for a conv this entry does not take).  Bit-identical to yolo_pack_conv_weights +
+ * yolo_pack_conv_weights_dgrad except that the padding rows of the images are not written: zero-fill the buffers once. */
+typedef struct yolo_pack_pair { const float* w_oihw; void* packed_fwd; void* packed_dgrad; int Cout, Cin, ksize, reserved; } yolo_pack_pair;
+long long yolo_pack_pair_blocks(int Cout, int Cin, int ksize);
+int yolo_pack_conv_weights_pairs(const void* items_device, const long long* first_block_device, int n_items,
+                                 long long total_blocks, void* stream);
 
 /* Gluon BatchNorm in training mode fused with LeakyReLU (+ residual add):
  * batch mean / biased variance over (N,H,W) of the NHWC conv output y (npix x C, dtype; C % 8 == 0),

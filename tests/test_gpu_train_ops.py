@@ -321,3 +321,31 @@ def test_bn_train_two_launch_variants_are_bit_identical(lib, cuda, shape, dtype)
     for n, a, b in zip(names, outs[0], outs[1]):
         np.testing.assert_allclose(a.float().cpu().numpy(), b.float().cpu().numpy(), rtol=2e-6 if n not in ('z', 'dy') or dtype == 'f32' else 1e-2,
                                    atol=1e-6 if dtype == 'f32' or n not in ('z', 'dy') else 1e-2, err_msg=n)
+
+
+def test_pack_pairs_bit_identical(lib, cuda):
+    """yolo_pack_conv_weights_pairs (forward + data-gradient image from one read of the weights, LDS transpose, 16-byte
+    stores) against yolo_pack_conv_weights + yolo_pack_conv_weights_dgrad, bit for bit, several convs in one launch."""
+    rng = np.random.default_rng(5)
+    st = torch.cuda.current_stream().cuda_stream
+    convs = [(64, 32, 3), (32, 64, 1), (256, 128, 3), (128, 256, 1), (1024, 512, 3), (96, 160, 3), (288, 32, 1)]
+    assert lib.yolo_pack_pair_blocks(90, 64, 1) == L.EUNSUPPORTED and lib.yolo_pack_pair_blocks(64, 8, 3) == L.EUNSUPPORTED
+    recs, first, keep = [], [0], []
+    dt = np.dtype([('w', '<u8'), ('fwd', '<u8'), ('dgrad', '<u8'), ('cout', '<i4'), ('cin', '<i4'), ('k', '<i4'), ('r', '<i4')])
+    for co, ci, k in convs:
+        w = torch.from_numpy(rng.standard_normal((co, ci, k, k)).astype(np.float32)).to(cuda)
+        f1 = torch.zeros(lib.yolo_packed_weight_bytes(co, ci, k, L.BF16), dtype=torch.uint8, device=cuda)
+        d1 = torch.zeros(lib.yolo_packed_weight_bytes(ci, co, k, L.BF16), dtype=torch.uint8, device=cuda)
+        f2, d2 = torch.full_like(f1, 0x5a), torch.full_like(d1, 0x5a)
+        assert lib.yolo_pack_conv_weights(w.data_ptr(), f2.data_ptr(), co, ci, k, L.BF16, st) == 0
+        assert lib.yolo_pack_conv_weights_dgrad(w.data_ptr(), d2.data_ptr(), co, ci, k, L.BF16, st) == 0
+        recs.append((w.data_ptr(), f1.data_ptr(), d1.data_ptr(), co, ci, k, 0))
+        first.append(first[-1] + lib.yolo_pack_pair_blocks(co, ci, k))
+        keep.append((w, f1, d1, f2, d2))
+    items = torch.from_numpy(np.array(recs, dtype=dt).view(np.uint8).copy()).to(cuda)
+    fb = torch.tensor(first, dtype=torch.int64, device=cuda)
+    assert lib.yolo_pack_conv_weights_pairs(items.data_ptr(), fb.data_ptr(), len(recs), first[-1], st) == 0
+    torch.cuda.synchronize()
+    for (co, ci, k), (w, f1, d1, f2, d2) in zip(convs, keep):
+        assert torch.equal(f1, f2), ('fwd', co, ci, k)
+        assert torch.equal(d1, d2), ('dgrad', co, ci, k)

@@ -73,6 +73,8 @@ SIGNATURES = {
     'yolo_conv_dgrad_s2': (_i, [C.POINTER(ConvDesc), _vp]),
     'yolo_pack_batch_blocks': (_ll, [_i, _i, _i, _i]),
     'yolo_pack_conv_weights_batch': (_i, [_vp, _vp, _i, _ll, _i, _vp]),
+    'yolo_pack_pair_blocks': (_ll, [_i, _i, _i]),
+    'yolo_pack_conv_weights_pairs': (_i, [_vp, _vp, _i, _ll, _vp]),
     'yolo_bn_train_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _f, _f, _i, _vp]),
     'yolo_bn_train_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _i, _vp]),
     'yolo_bn_train_fwd_pp': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _f, _f, _f, _i, _vp]),

@@ -113,19 +113,28 @@ class Trainer(object):
         if not self._prep:
             items = np.zeros(0, dtype=[('w', '<u8'), ('packed', '<u8'), ('cout', '<i4'), ('cin', '<i4'), ('k', '<i4'), ('dgrad', '<i4')])
             recs, first = [], [0]
+            pairs, pfirst = [], [0]
+            pair_dt = np.dtype([('w', '<u8'), ('fwd', '<u8'), ('dgrad', '<u8'), ('cout', '<i4'), ('cin', '<i4'), ('k', '<i4'), ('r', '<i4')])
             for c in self.net.graph.convs():
                 w = self.pview[c.name + '.weight']
-                wp = torch.empty(lib.yolo_packed_weight_bytes(c.cout, c.cin, c.k, self.ldt), dtype=torch.uint8, device=self.dev)
-                wd = torch.empty(lib.yolo_packed_weight_bytes(c.cin, c.cout, c.k, self.ldt), dtype=torch.uint8, device=self.dev)
+                # (zero-filled: the pair kernel never writes the images' padding rows)
+                wp = torch.zeros(lib.yolo_packed_weight_bytes(c.cout, c.cin, c.k, self.ldt), dtype=torch.uint8, device=self.dev)
+                wd = torch.zeros(lib.yolo_packed_weight_bytes(c.cin, c.cout, c.k, self.ldt), dtype=torch.uint8, device=self.dev)
                 cp = lib.yolo_padded_channels(max(c.cout, c.cin))
                 ones = torch.zeros(cp, dtype=torch.float32, device=self.dev); ones[:max(c.cout, c.cin)] = 1.0
                 bias = torch.zeros(cp, dtype=torch.float32, device=self.dev)
                 self._prep[c.name] = (wp, wd, ones, bias, torch.zeros(cp, dtype=torch.float32, device=self.dev))
-                # (the dgrad record carries the arguments of yolo_pack_conv_weights_dgrad after its swap: rows = Cin_f)
-                recs.append((w.data_ptr(), wp.data_ptr(), c.cout, c.cin, c.k, 0))
-                first.append(first[-1] + lib.yolo_pack_batch_blocks(c.cout, c.cin, c.k, self.ldt))
-                recs.append((w.data_ptr(), wd.data_ptr(), c.cin, c.cout, c.k, 1))
-                first.append(first[-1] + lib.yolo_pack_batch_blocks(c.cin, c.cout, c.k, self.ldt))
+                nb = lib.yolo_pack_pair_blocks(c.cout, c.cin, c.k) if (self.ldt == L.BF16 and not os.environ.get('YOLO_TRAIN_OLD_PACK')) else -1
+                if nb > 0:
+                    # both images from one read of the weights (yolo_pack_conv_weights_pairs)
+                    pairs.append((w.data_ptr(), wp.data_ptr(), wd.data_ptr(), c.cout, c.cin, c.k, 0))
+                    pfirst.append(pfirst[-1] + nb)
+                else:
+                    # (the dgrad record carries the arguments of yolo_pack_conv_weights_dgrad after its swap: rows = Cin_f)
+                    recs.append((w.data_ptr(), wp.data_ptr(), c.cout, c.cin, c.k, 0))
+                    first.append(first[-1] + lib.yolo_pack_batch_blocks(c.cout, c.cin, c.k, self.ldt))
+                    recs.append((w.data_ptr(), wd.data_ptr(), c.cin, c.cout, c.k, 1))
+                    first.append(first[-1] + lib.yolo_pack_batch_blocks(c.cin, c.cout, c.k, self.ldt))
                 if (c.k == 3 and c.stride == 2 and self.ldt == L.BF16 and c.cin % 8 == 0 and c.cout % 32 == 0
                         and not os.environ.get('YOLO_TRAIN_DILATED_DGRAD')):      # (the knob keeps the old form for A/B runs)
                     # sub-pixel data gradient (yolo_conv_dgrad_s2): 2x2-window image with 4 x Cin_f output channels
@@ -139,8 +148,16 @@ class Trainer(object):
             self._pack_items = torch.from_numpy(items.view(np.uint8).copy()).to(self.dev)
             self._pack_first = torch.tensor(first, dtype=torch.int64, device=self.dev)
             self._pack_n, self._pack_blocks = len(recs), first[-1]
-        L.check(lib.yolo_pack_conv_weights_batch(L.ptr(self._pack_items), L.ptr(self._pack_first), self._pack_n,
-                                                 self._pack_blocks, self.ldt, st), 'pack batch')
+            self._pair_n, self._pair_blocks = len(pairs), pfirst[-1]
+            if pairs:
+                self._pair_items = torch.from_numpy(np.array(pairs, dtype=pair_dt).view(np.uint8).copy()).to(self.dev)
+                self._pair_first = torch.tensor(pfirst, dtype=torch.int64, device=self.dev)
+        if self._pack_n:
+            L.check(lib.yolo_pack_conv_weights_batch(L.ptr(self._pack_items), L.ptr(self._pack_first), self._pack_n,
+                                                     self._pack_blocks, self.ldt, st), 'pack batch')
+        if self._pair_n:
+            L.check(lib.yolo_pack_conv_weights_pairs(L.ptr(self._pair_items), L.ptr(self._pair_first), self._pair_n,
+                                                     self._pair_blocks, st), 'pack pairs')
         for c in self.net.graph.convs():
             if not c.bn:
                 self._prep[c.name][3][:c.cout].copy_(self.pview[c.name + '.bias'])
