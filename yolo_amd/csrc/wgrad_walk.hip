@@ -260,6 +260,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_walk_kernel(WalkArgs a) {
     float* scr = (float*)(smem + wave * 9216);
     float* drow = a.dwt + ((long long)(co0 + wm * 32) * a.Cin + (ci0 + wn * 32)) * 9;
     const long long co_pitch = (long long)a.Cin * 9;
+    const int rot = (a.dbg & 4) ? 0 : (int)((unsigned)(slice * 7 + cseg * 11) % 36u);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
 #pragma unroll
@@ -268,7 +269,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_walk_kernel(WalkArgs a) {
             for (int tp = 0; tp < 9; ++tp) scr[((j + 4 * h) * 32 + l31) * 9 + tp] = acc[tp][4 * p + j];
 #pragma unroll
         for (int t = 0; t < 36; ++t) {
-            const int idx = t * 64 + lane;              // [row 0..7][288]
+            // (the K-slices of a tile finish together: each starts its pass at another row, so that they do not queue on
+            //  the same addresses of the memory-side atomic units)
+            int tt = t + rot;
+            tt = tt >= 36 ? tt - 36 : tt;
+            const int idx = tt * 64 + lane;             // [row 0..7][288]
             const int row = idx / 288, rem = idx - row * 288;
             const int co_l = (row & 3) + 8 * p + 4 * (row >> 2);
             atomicAdd(drow + co_l * co_pitch + rem, scr[idx]);
