@@ -496,8 +496,9 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
                           (a.stats_mode == 1 || (a.stats_mode == 2 && S == 1 && a.y_ps == a.Cout));
     if (a.stats && !stats_ok) return YOLO_EUNSUPPORTED;
     if (name) {
-        snprintf(name->buf, name->len, "void conv_pipe_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d>(ConvArgs)",
-                 sizeof(T) == 2 ? "bf16_t" : "float", KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC, LEAN);
+        snprintf(name->buf, name->len, "void conv_pipe_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d>(ConvArgs)",
+                 sizeof(T) == 2 ? "bf16_t" : "float", KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC, LEAN,
+                 (a.stats && stats_ok) ? a.stats_mode : 0);
         if (name->stats_rows) *name->stats_rows = (a.stats && stats_ok) ? a.nstrips * a.tiles_per_strip * WAVES_P : -1;
         return YOLO_OK;
     }
