@@ -162,7 +162,7 @@ def test_wgrad_bf16_transposing_reads(lib, cuda, case):
     np.testing.assert_allclose(dw.cpu().numpy() - 1.0, ref, rtol=1e-3, atol=2e-3 * np.abs(ref).max())
 
 
-@pytest.mark.parametrize('algo', [2, 3])
+@pytest.mark.parametrize('algo', [2, 3, 4])
 @pytest.mark.parametrize('case', [(2, 64, 8, 12, 128), (3, 128, 13, 13, 64), (2, 64, 17, 19, 192), (1, 64, 5, 4, 64),
                                   (2, 128, 11, 26, 64), (1, 64, 9, 38, 128), (5, 64, 7, 33, 64), (1, 64, 2, 70, 64),
                                   (70, 64, 13, 13, 128), (3, 192, 30, 52, 64),

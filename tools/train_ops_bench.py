@@ -67,7 +67,10 @@ if 'bn' in a.what:
 # (Ho=Wo, Cin, Cout, k, stride)
 WG_SHAPES = [(208, 32, 64, 3, 2), (208, 32, 64, 3, 1), (208, 64, 32, 1, 1), (104, 64, 128, 3, 1), (104, 128, 64, 1, 1),
              (52, 128, 256, 3, 1), (52, 256, 128, 1, 1), (26, 256, 512, 3, 1), (26, 512, 256, 1, 1),
-             (13, 512, 1024, 3, 1), (13, 1024, 512, 1, 1), (416, 8, 32, 3, 1)]
+             (13, 512, 1024, 3, 1), (13, 1024, 512, 1, 1), (416, 8, 32, 3, 1),
+             # head layers, and the 608x608 family's widths
+             (13, 1024, 2048, 3, 1), (26, 512, 1024, 3, 1), (52, 256, 512, 3, 1), (19, 512, 1024, 3, 1), (38, 256, 512, 3, 1),
+             (76, 128, 256, 3, 1), (152, 64, 128, 3, 1)]
 if 'wgrad' in a.what:
     for ho, ci, co, k, s in WG_SHAPES:
         if a.k3s1 and not (k == 3 and s == 1 and ci >= 64):

@@ -1110,12 +1110,13 @@ extern "C" int yolo_conv_wgrad(const void* dy, const void* x, float* dw_oihw, in
 }
 
 // algo: 0 = the library's choice; 1 = the register-staged kernels (per-tap / strip / row-group); 2 / 3 = the row-walk
-// kernel with one 16-column walker / four 4-column walkers per block (EUNSUPPORTED outside its domain)
+// kernel with one 16-column walker / four 4-column walkers per block, 4 = 3 with 8-wave blocks that reduce two K-slices
+// through LDS before the atomics (EUNSUPPORTED outside its domain)
 extern "C" int yolo_conv_wgrad_algo(const void* dy, const void* x, float* dw_oihw, int N, int H, int W, int Cin, int Cout,
                                     int ksize, int stride, long long dy_pixel_stride, int dtype, void* workspace, int algo,
                                     void* stream) {
     if (!dy || !x || !dw_oihw || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return YOLO_EINVAL;
-    if (algo < 0 || algo > 3) return YOLO_EINVAL;
+    if (algo < 0 || algo > 4) return YOLO_EINVAL;
     if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return YOLO_EUNSUPPORTED;
     if (dtype == YOLO_F32)
         return yolo_conv_wgrad_f32((const float*)dy, (const float*)x, dw_oihw, N, H, W, Cin, Cout, ksize, stride,

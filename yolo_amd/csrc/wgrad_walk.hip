@@ -71,9 +71,11 @@ __device__ __forceinline__ void mma(f32x16& c, const uint4& a, const uint4& b) {
 }
 }  // namespace
 
-// SC: columns per walker (16 / SC walkers per block); RD: ring depth
-template <int SC, int RD>
-__global__ __launch_bounds__(256, 2) void wgrad_walk_kernel(WalkArgs a) {
+// SC: columns per walker (16 / SC walkers per block); RD: ring depth; KH: K-halves per block -- KH = 2: 8 waves, waves 4-7
+// run the same tile over the NEXT row slice in their own ring and hand their accumulators to waves 0-3 through LDS before
+// the atomics (half the atomic volume at the same two waves per SIMD)
+template <int SC, int RD, int KH = 1>
+__global__ __launch_bounds__(256 * KH, 2 / KH) void wgrad_walk_kernel(WalkArgs a) {
     constexpr int NW = 16 / SC;
     constexpr int XPX = SC + 2;                         // x pixels per walker row (column halo)
     constexpr int WXB = XPX * 128;                      // bytes of a walker's x row (64 channels)
@@ -85,18 +87,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_walk_kernel(WalkArgs a) {
     constexpr int ND = SLOT / 4096;                     // DMAs per wave per phase
     static_assert(SLOT_XP + 3 * DYROWB <= SLOT, "slot layout");
     static_assert(XROWB % 512 == 0 && SLOT_XP % 512 == 0 && DYROWB % 512 == 0 && SLOT % 512 == 0, "the swizzle follows 256-byte lines");
-    __shared__ __attribute__((aligned(1024))) char smem[RD * SLOT];
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)smem;
-
+    __shared__ __attribute__((aligned(1024))) char smem_all[KH * RD * SLOT];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave8 >> 2, wave = wave8 & 3;
+    char* smem = smem_all + half * RD * SLOT;           // this half's ring
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)smem;
     const int wm = wave & 1, wn = wave >> 1;
 
     const int lid = xcd_order(blockIdx.x, gridDim.x);
     const int rest = fdiv(lid, a.d_tiles);
     const int tile = lid - rest * a.ntiles;
-    const int slice = fdiv(rest, a.d_colseg);
-    const int cseg = rest - slice * a.ncolseg;
+    const int bslice = fdiv(rest, a.d_colseg);
+    const int cseg = rest - bslice * a.ncolseg;
+    const int slice = bslice * KH + half;
     const int tco = tile / a.tiles_ci, tci = tile - tco * a.tiles_ci;
     const int co0 = tco * 64, ci0 = tci * 64;
     const int c0 = cseg * SC;
@@ -256,8 +260,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_walk_kernel(WalkArgs a) {
     //      own 9 KiB of the (now idle) ring in four passes of 8 cout rows and adds 256 contiguous bytes per instruction.
     __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring
     if (a.dbg & 1) return;
+    if constexpr (KH == 2) {
+        // waves 4-7 park their accumulators in LDS (lane-linear, 256 B per register; taps 0-4 then 5-8: 80 / 64 KiB), waves
+        // 0-3 add them to their own and go on alone
+        float* park = (float*)smem_all + wave * (5 * 16 * 64);
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const int t0 = part * 5, t1 = part ? 9 : 5;
+            if (half == 1) {
+#pragma unroll
+                for (int tp = t0; tp < t1; ++tp)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) park[((tp - t0) * 16 + r) * 64 + lane] = acc[tp][r];
+            }
+            __syncthreads();
+            if (half == 0) {
+#pragma unroll
+                for (int tp = t0; tp < t1; ++tp)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tp][r] += park[((tp - t0) * 16 + r) * 64 + lane];
+            }
+            __syncthreads();
+        }
+        if (half == 1) return;
+    }
     const int l31 = lane & 31, h = lane >> 5;
-    float* scr = (float*)(smem + wave * 9216);
+    float* scr = (float*)(smem_all + wave * 9216);
     float* drow = a.dwt + ((long long)(co0 + wm * 32) * a.Cin + (ci0 + wn * 32)) * 9;
     const long long co_pitch = (long long)a.Cin * 9;
     const int rot = (a.dbg & 4) ? 0 : (int)((unsigned)(slice * 7 + cseg * 11) % 36u);
@@ -281,10 +309,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_walk_kernel(WalkArgs a) {
     }
 }
 
-template <int SC, int RD>
+template <int SC, int RD, int KH = 1>
 static int wgrad_walk_launch(const void* dy, const void* x, float* dwt, int N, int H, int W, int Cin, int Cout, long long ps,
                              int target_blocks, hipStream_t st) {
-    constexpr int NW = 16 / SC;
+    constexpr int NW = 16 / SC * KH;                    // walkers (row ranges) per block
+    target_blocks /= KH;
     WalkArgs a;
     a.dy = (const char*)dy; a.x = (const char*)x; a.dwt = dwt;
     void* zp = nullptr;
@@ -314,12 +343,12 @@ static int wgrad_walk_launch(const void* dy, const void* x, float* dwt, int N, i
     a.d_h1 = make_fastdiv((unsigned)(H + 1));
     a.d_tiles = make_fastdiv((unsigned)a.ntiles);
     a.d_colseg = make_fastdiv((unsigned)a.ncolseg);
-    YOLO_LAUNCH((wgrad_walk_kernel<SC, RD>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    YOLO_LAUNCH((wgrad_walk_kernel<SC, RD, KH>), dim3((unsigned)grid), dim3(256 * KH), 0, st, a);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
 
-// variant: 0 = pick by the map width; 1 = one 16-column walker; 2 = four 4-column walkers.  EUNSUPPORTED when the
+// variant: 0 = the default; 1 = one 16-column walker; 2 = four 4-column walkers; 3 = 2, with 8-wave blocks of two K-halves.  EUNSUPPORTED when the
 // shape is outside the kernel's domain (the caller falls back on the kernels of train.hip).
 int wgrad_walk_dispatch(const void* dy, const void* x, float* dwt, int N, int H, int W, int Cin, int Cout, long long ps,
                         int variant, hipStream_t st) {
@@ -339,5 +368,6 @@ int wgrad_walk_dispatch(const void* dy, const void* x, float* dwt, int N, int H,
 #define WW_CASE(SC_, RD_) if (variant == (SC_ == 16 ? 1 : 2) && rd == RD_) return wgrad_walk_launch<SC_, RD_>(dy, x, dwt, N, H, W, Cin, Cout, ps, target, st);
     WW_CASE(16, 3) WW_CASE(16, 4) WW_CASE(16, 5) WW_CASE(4, 3) WW_CASE(4, 4) WW_CASE(4, 5)
 #undef WW_CASE
+    if (variant == 3) return wgrad_walk_launch<4, 4, 2>(dy, x, dwt, N, H, W, Cin, Cout, ps, target, st);   // two K-halves per block
     return YOLO_EUNSUPPORTED;
 }
