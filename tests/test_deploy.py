@@ -21,6 +21,51 @@ def test_car_box_row_azimuth():
     assert abs(deploy.car_box_row(row)[5] + 15 * math.pi / 180) < 1e-4
 
 
+def test_symbol_json_round_trip_and_rejections(tmp_path):
+    """export-symbol.json (the half of HybridBlock.export the reference's init_executor builds its graph from,
+    yolo_gluon.py:206-208): written from the graph, parsed back into the spec's structure for every spec of the repo; the
+    heads are listed fine -> coarse (all_output[::-1], car/utils.py:95); older `attr` keys are read; anything that is not
+    the CarNet topology is refused."""
+    import copy
+    import json
+    from oracle import graph as og
+    from yolo_amd.spec import NetGraph, darknet53_spec
+    for spec in (darknet53_spec(), og.spec_micro(), og.spec_car_v1()):
+        g = NetGraph(spec)
+        sym = deploy.symbol_json(g)
+        got = deploy.spec_from_symbol(sym)
+        assert got['layers'] == list(spec['layers']) and got['channels'] == list(spec['channels'])
+        assert got['slice_point'][-1] == spec['slice_point'][-1]
+        assert [len(a) for a in got['all_anchors']] == [len(a) for a in spec['all_anchors']]
+        n_conv = sum(1 for n in sym['nodes'] if n['op'] == 'Convolution')
+        assert n_conv == len(g.convs()) and len(sym['heads']) == len(spec['all_anchors'])
+        # every parameter of the .params file is a variable node of the symbol, and nothing else is
+        names = {n['name'] for n in sym['nodes'] if n['op'] == 'null'} - {'data'}
+        from yolo_amd import mxparams
+        assert names == set(mxparams.gluon_param_names(g).values())
+        # fine -> coarse: the first head's output conv sees the largest map (the fewest stride-2 convs upstream... the
+        # deepest head is built first, so its reshape node comes first in the file and LAST in `heads`)
+        assert sym['heads'][-1][0] < sym['heads'][0][0]
+    spec = og.spec_micro()
+    sym = deploy.symbol_json(NetGraph(spec))
+    old = copy.deepcopy(sym)
+    for n in old['nodes']:
+        if 'attrs' in n:
+            n['attr'] = n.pop('attrs')
+    path = tmp_path / 'export-symbol.json'
+    path.write_text(json.dumps(old))
+    assert deploy.spec_from_symbol(str(path))['channels'] == list(spec['channels'])
+    bad = copy.deepcopy(sym)
+    conv = [n for n in bad['nodes'] if n['op'] == 'Convolution'][5]
+    conv['attrs']['num_filter'] = str(int(conv['attrs']['num_filter']) + 8)
+    with pytest.raises(ValueError):
+        deploy.spec_from_symbol(bad)
+    bad = copy.deepcopy(sym)
+    bad['nodes'].append({'op': 'Pooling', 'name': 'pool0', 'attrs': {}, 'inputs': [[len(bad['nodes']) - 1, 0, 0]]})
+    with pytest.raises(ValueError):
+        deploy.spec_from_symbol(bad)
+
+
 @pytest.mark.gpu
 def test_export_and_init_executor(cuda, tmp_path):
     import torch
@@ -31,10 +76,17 @@ def test_export_and_init_executor(cuda, tmp_path):
     net = CarNet(spec, dtype='bf16', device=cuda).load_params(P)
     x = torch.rand((1, 3) + size, device=cuda)
     ref = [o.clone() for o in net(x)]
-    path = deploy.export_params(net, str(tmp_path), epoch=3)
-    assert path.endswith('export-0003.params')
+    path = deploy.export(net, str(tmp_path), epoch=3)
+    assert path.endswith('export-0003.params') and (tmp_path / 'export-symbol.json').exists()
     ex = deploy.init_executor(str(tmp_path), spec, size, device=cuda, step=3)
     out = ex.forward(is_train=False, data=x)
     assert len(out) == 3 and all(torch.equal(a, b) for a, b in zip(out, ref))
+    # as the reference does it: no spec, the structure comes from export-symbol.json alone (yolo_gluon.py:204-208)
+    ex2 = deploy.init_executor(str(tmp_path), None, size, device=cuda, step=3)
+    out2 = ex2.forward(is_train=False, data=x)
+    assert all(torch.equal(a, b) for a, b in zip(out2, ref))
+    other = dict(spec); other['channels'] = [c * 2 for c in spec['channels']]
+    with pytest.raises(ValueError):
+        deploy.init_executor(str(tmp_path), other, size, device=cuda, step=3)
     with pytest.raises(ValueError):
         ex.forward(is_train=True, data=x)
