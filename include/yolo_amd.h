@@ -316,7 +316,8 @@ int yolo_conv_wgrad(const void* dy, const void* x, float* dw_oihw, int N, int H,
  * runs); 1 = the register-staged kernels (per-tap / column-strip / row-group); 2 / 3 = the pipelined row-walk kernel of
  * the 3x3 stride-1 layers with Cin and Cout multiples of 64 (LDS-DMA ring, x fragments of the three kernel rows held
  * in registers), one 16-column walker / four 4-column walkers per block; 4 = 3 with 8-wave blocks whose two halves walk
- * different row slices and are summed through LDS before the atomics; YOLO_EUNSUPPORTED outside a kernel's domain. */
+ * different row slices and are summed through LDS before the atomics; 5 / 6 = the LDS-DMA GEMM of the 1x1 layers (Cin, Cout
+ * multiples of 128) with a 128 x 128 / 256 cout x 128 cin tile; YOLO_EUNSUPPORTED outside a kernel's domain. */
 int yolo_conv_wgrad_algo(const void* dy, const void* x, float* dw_oihw, int N, int H, int W, int Cin, int Cout,
                          int ksize, int stride, long long dy_pixel_stride, int dtype, void* workspace, int algo,
                          void* stream);

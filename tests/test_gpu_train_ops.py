@@ -162,6 +162,33 @@ def test_wgrad_bf16_transposing_reads(lib, cuda, case):
     np.testing.assert_allclose(dw.cpu().numpy() - 1.0, ref, rtol=1e-3, atol=2e-3 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize('algo', [5, 6])
+@pytest.mark.parametrize('case', [(2, 128, 8, 12, 128), (3, 256, 13, 13, 128), (1, 128, 5, 13, 256), (4, 384, 9, 7, 256),
+                                  (70, 128, 13, 13, 128), (8, 256, 52, 52, 128), (8, 512, 26, 26, 256), (8, 1024, 13, 13, 512),
+                                  (8, 2048, 13, 13, 1024), (2, 768, 38, 38, 256)])
+def test_wgrad_bf16_1x1_gemm(lib, cuda, case, algo):
+    """wgrad_gemm_kernel (1x1 layers, Cin and Cout multiples of 128): LDS-DMA ring + transposing fragment reads, K-slices
+    ending inside a phase (zero page), partial sums added straight into the gradient; both tile variants."""
+    N, Cin, H, W, Cout = case
+    x, w, dy, dx_ref, dw_ref = _ref((N, Cin, H, W, Cout, 1, 1), 13)
+    rb = lambda a: torch.from_numpy(a).to(torch.bfloat16).float()
+    wt = torch.from_numpy(w).requires_grad_(True)
+    F.conv2d(rb(x), wt, None).backward(rb(dy))
+    xd, dyd = to_nhwc(x, 'bf16', cuda), to_nhwc(dy, 'bf16', cuda)
+    dw = torch.ones((Cout, Cin, 1, 1), device=cuda)
+    ws = torch.zeros(lib.yolo_conv_wgrad_workspace_bytes(Cin, Cout, 1, L.BF16), dtype=torch.uint8, device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.yolo_conv_wgrad_algo(dyd.data_ptr(), xd.data_ptr(), dw.data_ptr(), N, H, W, Cin, Cout, 1, 1, 0, L.BF16, ws.data_ptr(), algo, st)
+    if algo == 6 and Cout % 256:
+        assert rc == L.EUNSUPPORTED
+        return
+    assert rc == 0
+    ref = wt.grad.numpy()
+    np.testing.assert_allclose(dw.cpu().numpy() - 1.0, ref, rtol=1e-3, atol=2e-3 * np.abs(ref).max())
+    assert lib.yolo_conv_wgrad_algo(dyd.data_ptr(), xd.data_ptr(), dw.data_ptr(), N, H, W, Cin, Cout, 3, 1, 0, L.BF16,
+                                    ws.data_ptr(), algo, st) == L.EUNSUPPORTED
+
+
 @pytest.mark.parametrize('algo', [2, 3, 4])
 @pytest.mark.parametrize('case', [(2, 64, 8, 12, 128), (3, 128, 13, 13, 64), (2, 64, 17, 19, 192), (1, 64, 5, 4, 64),
                                   (2, 128, 11, 26, 64), (1, 64, 9, 38, 128), (5, 64, 7, 33, 64), (1, 64, 2, 70, 64),

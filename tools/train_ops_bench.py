@@ -12,6 +12,7 @@ ap.add_argument('--what', default='bn,wgrad')
 ap.add_argument('--iters', type=int, default=20)
 ap.add_argument('--algos', default='0', help='weight-gradient kernels to time (yolo_conv_wgrad_algo ids)')
 ap.add_argument('--k3s1', action='store_true', help='weight gradient: only the 3x3 stride-1 shapes with Cin >= 64')
+ap.add_argument('--k1', action='store_true', help='weight gradient: only the 1x1 shapes')
 ap.add_argument('--cold', action='store_true', help='evict L2 / MALL (1 GiB fill) before every timed launch')
 a = ap.parse_args()
 lib = L.load()
@@ -70,9 +71,13 @@ WG_SHAPES = [(208, 32, 64, 3, 2), (208, 32, 64, 3, 1), (208, 64, 32, 1, 1), (104
              (13, 512, 1024, 3, 1), (13, 1024, 512, 1, 1), (416, 8, 32, 3, 1),
              # head layers, and the 608x608 family's widths
              (13, 1024, 2048, 3, 1), (26, 512, 1024, 3, 1), (52, 256, 512, 3, 1), (19, 512, 1024, 3, 1), (38, 256, 512, 3, 1),
-             (76, 128, 256, 3, 1), (152, 64, 128, 3, 1)]
+             (76, 128, 256, 3, 1), (152, 64, 128, 3, 1),
+             # 1x1 head layers
+             (13, 2048, 1024, 1, 1), (26, 1024, 512, 1, 1), (52, 512, 256, 1, 1)]
 if 'wgrad' in a.what:
     for ho, ci, co, k, s in WG_SHAPES:
+        if a.k1 and k != 1:
+            continue
         if a.k3s1 and not (k == 3 and s == 1 and ci >= 64):
             continue
         H = ho * s

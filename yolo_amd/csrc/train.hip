@@ -1100,6 +1100,9 @@ extern "C" long long yolo_conv_wgrad_workspace_bytes(int Cin, int Cout, int ksiz
 // wgrad_walk.hip: the pipelined row-walk kernel of the 3x3 stride-1 layers (Cin, Cout multiples of 64)
 int wgrad_walk_dispatch(const void* dy, const void* x, float* dwt, int N, int H, int W, int Cin, int Cout, long long ps,
                         int variant, hipStream_t st);
+// wgrad_walk.hip: the LDS-DMA GEMM of the 1x1 layers (Cin, Cout multiples of 128)
+int wgrad_gemm_dispatch(const void* dy, const void* x, float* dw, long long P, int Cin, int Cout, long long ps, int variant,
+                        hipStream_t st);
 
 extern "C" int yolo_conv_wgrad(const void* dy, const void* x, float* dw_oihw, int N, int H, int W, int Cin, int Cout,
                                int ksize, int stride, long long dy_pixel_stride, int dtype, void* workspace,
@@ -1116,7 +1119,7 @@ extern "C" int yolo_conv_wgrad_algo(const void* dy, const void* x, float* dw_oih
                                     int ksize, int stride, long long dy_pixel_stride, int dtype, void* workspace, int algo,
                                     void* stream) {
     if (!dy || !x || !dw_oihw || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return YOLO_EINVAL;
-    if (algo < 0 || algo > 4) return YOLO_EINVAL;
+    if (algo < 0 || algo > 6) return YOLO_EINVAL;
     if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return YOLO_EUNSUPPORTED;
     if (dtype == YOLO_F32)
         return yolo_conv_wgrad_f32((const float*)dy, (const float*)x, dw_oihw, N, H, W, Cin, Cout, ksize, stride,
@@ -1131,11 +1134,18 @@ extern "C" int yolo_conv_wgrad_algo(const void* dy, const void* x, float* dw_oih
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
     const long long total = (long long)Cin * Cout * taps;
+    if ((algo == 0 || algo == 5 || algo == 6) && ksize == 1) {
+        // (adds straight into dw_oihw: [cout][cin] is the OIHW layout of a 1x1)
+        const int rc = wgrad_gemm_dispatch(dy, x, dw_oihw, (long long)N * H * W, Cin, Cout, ps, algo ? algo - 4 : 0, st);
+        if (rc != YOLO_EUNSUPPORTED || algo) return rc;
+    } else if (algo >= 5) {
+        return YOLO_EUNSUPPORTED;
+    }
     if (algo != 1 && ksize == 3 && stride == 1) {
         // (adds straight into dw_oihw: no workspace, no finishing pass)
         const int rc = wgrad_walk_dispatch(dy, x, dw_oihw, N, H, W, Cin, Cout, ps, algo ? algo - 1 : 0, st);
         if (rc != YOLO_EUNSUPPORTED || algo) return rc;
-    } else if (algo > 1) {
+    } else if (algo > 1 && algo < 5) {
         return YOLO_EUNSUPPORTED;
     }
     if (ksize == 3 && Cin <= 64) {

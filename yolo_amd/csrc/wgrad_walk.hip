@@ -348,6 +348,206 @@ static int wgrad_walk_launch(const void* dy, const void* x, float* dwt, int N, i
     return YOLO_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 1x1 weight gradient: dW[co][ci] += sum over pixels of dy[p][co] * x[p][ci] -- a plain GEMM with K = pixels, both operands
+// K-strided.  Same machinery as the row walk (LDS-DMA ring, counted waits, one barrier per phase, transposing fragment
+// reads, zero page past the slice end) without its register re-use: a 1x1 moves 2-3x the bytes per MFMA.  Block = 4 waves
+// (2 x 2), wave tile (MI*32) cout x (NI*32) cin, phase = 32 pixels.  LDS rows are one pixel of the tile (256 or 512
+// bytes): the 64-byte chunk c of pixel p sits at chunk c ^ (p & 3), so the four pixel rows of a transposing read fall on
+// four different bank quarters.  [cout][cin] IS the OIHW layout of a 1x1: the accumulators are added straight into the
+// gradient.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct GemmArgs {
+    const char* dy;
+    const char* x;
+    const char* zero;
+    float* dw;
+    int Cin, Cout;
+    unsigned x_pixb, dy_pixb;
+    int tiles_ci, ntiles;
+    long long P;                   // pixels
+    int Ls;                        // pixels per K-slice (a multiple of 32)
+    int nphase;                    // Ls / 32
+    FastDiv d_tiles;
+};
+}  // namespace
+
+template <int MI, int NI, int RD>
+__global__ __launch_bounds__(256, (MI * NI > 4) ? 2 : 3) void wgrad_gemm_kernel(GemmArgs a) {
+    constexpr int KP = 32;
+    constexpr int BM = 2 * MI * 32, BN = 2 * NI * 32;
+    constexpr int PBD = BM * 2, PBX = BN * 2;           // LDS row bytes (one pixel of the tile)
+    constexpr int SLOT_D = KP * PBD, SLOT = KP * (PBD + PBX);
+    constexpr int ND = SLOT / 4096;                     // DMAs per wave per phase
+    static_assert(SLOT % 4096 == 0 && SLOT_D % 1024 == 0 && PBD >= 256 && PBX >= 256, "slot layout");
+    __shared__ __attribute__((aligned(1024))) char smem[RD * SLOT];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int lid = xcd_order(blockIdx.x, gridDim.x);
+    const int slice = fdiv(lid, a.d_tiles);
+    const int tile = lid - slice * a.ntiles;
+    const int tco = tile / a.tiles_ci, tci = tile - tco * a.tiles_ci;
+    const int co0 = tco * BM, ci0 = tci * BN;
+    const long long p0 = (long long)slice * a.Ls;
+    const long long p1 = min(p0 + a.Ls, a.P);
+
+    // ---- per-lane DMA sources (advance by one phase = 32 pixels per issue) --------------------------------------------
+    const char* d_src[ND];
+    int d_left[ND];                                     // phases for which DMA k still loads real pixels (then: the zero page)
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+        const int o = (k * 4 + wave) * 1024 + lane * 16;
+        const bool isd = (k * 4 + wave) * 1024 < SLOT_D;           // (wave-uniform: a DMA is dy or x, never both)
+        const int oo = isd ? o : o - SLOT_D;
+        const int pb = isd ? PBD : PBX;
+        const int row = oo / pb, unit = (oo - row * pb) >> 4;
+        const int chunk = (unit >> 2) ^ (row & 3);
+        const unsigned pixb = isd ? a.dy_pixb : a.x_pixb;
+        const long long left = p1 - p0 - row;
+        d_left[k] = left > 0 ? (int)((left + KP - 1) / KP) : 0;
+        d_src[k] = (isd ? a.dy + (size_t)co0 * 2 : a.x + (size_t)ci0 * 2) + (size_t)(p0 + row) * pixb + chunk * 64 + (unit & 3) * 16;
+    }
+    const uint32_t wave_lds = lds0 + wave * 1024;
+    auto issue = [&](int k, int ring) {
+        const bool isd = (k * 4 + wave) * 1024 < SLOT_D;
+        const char* src = d_left[k] > 0 ? d_src[k] : a.zero;
+        dma16(src, wave_lds + ring * SLOT + k * 4096);
+        d_src[k] += (isd ? a.dy_pixb : a.x_pixb) * KP;
+        d_left[k] -= 1;
+    };
+#pragma unroll
+    for (int q = 0; q < RD - 1; ++q)
+#pragma unroll
+        for (int k = 0; k < ND; ++k) issue(k, q);
+
+    // ---- per-lane fragment offsets: pixel row k of a K-step = (g >> 1) * 8 + hl * 4 + (j16 >> 2), so k & 3 = j16 >> 2 ------
+    const int g = lane >> 4, j16 = lane & 15;
+    const int sw = j16 >> 2;
+    const int within = (g & 1) * 32 + (j16 & 3) * 8;
+    int ao[MI], bo[NI], krow[2];
+#pragma unroll
+    for (int hl = 0; hl < 2; ++hl) krow[hl] = (g >> 1) * 8 + hl * 4 + (j16 >> 2);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) ao[mi] = (((wm * MI + mi) ^ sw) << 6) + within;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bo[ni] = SLOT_D + (((wn * NI + ni) ^ sw) << 6) + within;
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    wait_vm<(RD - 2) * ND>();
+    __builtin_amdgcn_s_barrier();
+    const int nphase = a.nphase;
+    int ring = 0;
+    for (int q = 0; q < nphase; ++q) {
+        const char* sl = smem + ring * SLOT;
+        const int wr = ring == 0 ? RD - 1 : ring - 1;   // the slot the previous phase read
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 af[MI], bf[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const uint2 lo = tr_read(sl + (ks * 16 + krow[0]) * PBD + ao[mi]), hi = tr_read(sl + (ks * 16 + krow[1]) * PBD + ao[mi]);
+                af[mi] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const uint2 lo = tr_read(sl + (ks * 16 + krow[0]) * PBX + bo[ni]), hi = tr_read(sl + (ks * 16 + krow[1]) * PBX + bo[ni]);
+                bf[ni] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    mma(acc[mi][ni], af[mi], bf[ni]);
+                    // the DMAs of the phase RD - 1 ahead, spread between the MFMAs
+                    constexpr int NM = 2 * MI * NI;
+                    const int m = (ks * MI + mi) * NI + ni;
+#pragma unroll
+                    for (int k = 0; k < ND; ++k)
+                        if (m == (k * NM) / ND) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue(k, wr);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                }
+        }
+        wait_vm<(RD - 2) * ND>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        ring = (ring + 1 == RD) ? 0 : ring + 1;
+    }
+    wait_vm<0>();
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int ci = ci0 + (wn * NI + ni) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                atomicAdd(a.dw + (long long)co * a.Cin + ci, acc[mi][ni][r]);
+            }
+        }
+}
+
+template <int MI, int NI>
+static int wgrad_gemm_launch(const void* dy, const void* x, float* dw, long long P, int Cin, int Cout, long long ps, hipStream_t st) {
+    constexpr int BM = 2 * MI * 32, BN = 2 * NI * 32, RD = 3;    // (3 slots: 48 / 72 KiB per block -> 3 / 2 blocks per CU)
+    constexpr int SLOT = 32 * (BM + BN) * 2;
+    GemmArgs a;
+    a.dy = (const char*)dy; a.x = (const char*)x; a.dw = dw;
+    void* zp = nullptr;
+    if (hipGetSymbolAddress(&zp, HIP_SYMBOL(wgw_zero_page)) != hipSuccess || !zp) return YOLO_EINVAL;
+    a.zero = (const char*)zp;
+    a.Cin = Cin; a.Cout = Cout; a.x_pixb = (unsigned)Cin * 2; a.dy_pixb = (unsigned)ps * 2;
+    a.tiles_ci = Cin / BN;
+    a.ntiles = a.tiles_ci * (Cout / BM);
+    a.P = P;
+    const int resident = 256 * (163840 / (RD * SLOT) < 3 ? 163840 / (RD * SLOT) : 3);
+    long long slices = resident / a.ntiles;
+    if (slices < 1) slices = 1;
+    long long Ls = (P + slices - 1) / slices;
+    Ls = (Ls + 31) / 32 * 32;
+    if (Ls < 256) Ls = 256;                                      // at least 8 phases per block
+    slices = (P + Ls - 1) / Ls;
+    a.Ls = (int)Ls;
+    a.nphase = (int)(Ls / 32);
+    a.d_tiles = make_fastdiv((unsigned)a.ntiles);
+    const long long grid = (long long)a.ntiles * slices;
+    if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
+    YOLO_LAUNCH((wgrad_gemm_kernel<MI, NI, RD>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}
+
+// variant: 0 = by the channel counts; 1 = 128 x 128 tile; 2 = 256 cout x 128 cin.  EUNSUPPORTED outside the domain.
+int wgrad_gemm_dispatch(const void* dy, const void* x, float* dw, long long P, int Cin, int Cout, long long ps, int variant,
+                        hipStream_t st) {
+    if ((Cin % 128) || (Cout % 128) || (ps % 8) || P < 64) return YOLO_EUNSUPPORTED;
+    if (P * Cin * 2 >= 0x7fffff00LL * 2 || P * ps * 2 >= 0x7fffff00LL * 2) return YOLO_EUNSUPPORTED;
+    if (variant == 0) {
+        // measured (bs 64): 45-GFLOP head layers 96-125 -> 70-86 us against the register-staged per-tap kernel; the 11-GFLOP
+        // backbone layers tie at ~46 us (both sit on their split-K atomics: 768 blocks x 64 KiB onto a 2 MiB gradient), and
+        // the 256 x 128 tile loses everywhere (one block per SIMD pair) -- so: the 128 x 128 tile, big layers only
+        if (2.0 * (double)P * Cin * Cout < 2.0e10) return YOLO_EUNSUPPORTED;
+        variant = 1;
+    }
+    if (variant == 2 && (Cout % 256)) return YOLO_EUNSUPPORTED;
+    if (variant == 1) return wgrad_gemm_launch<2, 2>(dy, x, dw, P, Cin, Cout, ps, st);
+    if (variant == 2) return wgrad_gemm_launch<4, 2>(dy, x, dw, P, Cin, Cout, ps, st);
+    return YOLO_EUNSUPPORTED;
+}
+
 // variant: 0 = the default; 1 = one 16-column walker; 2 = four 4-column walkers; 3 = 2, with 8-wave blocks of two K-halves.  EUNSUPPORTED when the
 // shape is outside the kernel's domain (the caller falls back on the kernels of train.hip).
 int wgrad_walk_dispatch(const void* dy, const void* x, float* dwt, int N, int H, int W, int Cin, int Cout, long long ps,
