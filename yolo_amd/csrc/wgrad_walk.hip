@@ -336,8 +336,8 @@ static int wgrad_walk_launch(const void* dy, const void* x, float* dwt, int N, i
     slices = (a.NR + Lw * NW - 1) / (Lw * NW);               // (never more than before: Lw was rounded up)
     a.L = (int)Lw;
     a.nphase = 1 + a.L / 3;
-    a.dbg = 0;
-    if (const char* e = getenv("YOLO_WW_DBG")) a.dbg = atoi(e);
+    static const int dbg = getenv("YOLO_WW_DBG") ? atoi(getenv("YOLO_WW_DBG")) : 0;
+    a.dbg = dbg;
     const long long grid = per_slice * slices;
     if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
     a.d_h1 = make_fastdiv((unsigned)(H + 1));
@@ -558,13 +558,12 @@ int wgrad_walk_dispatch(const void* dy, const void* x, float* dwt, int N, int H,
     // four 4-column walkers win on every map width of the 416 / 608 families (13 ... 152): no K padding beyond W % 4, and
     // 40 instead of 34 staged pixels per K-step row cost less than the 16-column walker's padding
     if (variant == 0) {
-        variant = 2;
-        if (const char* e = getenv("YOLO_WW_SC")) variant = atoi(e) == 16 ? 1 : 2;       // (A/B knob)
+        static const int sc = getenv("YOLO_WW_SC") ? atoi(getenv("YOLO_WW_SC")) : 4;     // (A/B knob)
+        variant = sc == 16 ? 1 : 2;
     }
-    int target = 512;                                        // two blocks per CU
-    int rd = 4;
-    if (const char* e = getenv("YOLO_WW_TARGET")) target = atoi(e);
-    if (const char* e = getenv("YOLO_WW_RD")) rd = atoi(e);
+    // (ablation knobs, read once: YOLO_WW_TARGET = blocks per launch, YOLO_WW_RD = ring depth, YOLO_WW_DBG see WalkArgs)
+    static const int target = getenv("YOLO_WW_TARGET") ? atoi(getenv("YOLO_WW_TARGET")) : 512;    // two blocks per CU
+    static const int rd = getenv("YOLO_WW_RD") ? atoi(getenv("YOLO_WW_RD")) : 4;
 #define WW_CASE(SC_, RD_) if (variant == (SC_ == 16 ? 1 : 2) && rd == RD_) return wgrad_walk_launch<SC_, RD_>(dy, x, dwt, N, H, W, Cin, Cout, ps, target, st);
     WW_CASE(16, 3) WW_CASE(16, 4) WW_CASE(16, 5) WW_CASE(4, 3) WW_CASE(4, 4) WW_CASE(4, 5)
 #undef WW_CASE
