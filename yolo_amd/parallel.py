@@ -126,13 +126,18 @@ class GradBuckets(object):
         self.works = []
         self.launched = [False] * len(self.ranges)
 
-    def done(self, names):
+    def done(self, names, before_launch=None):
+        """before_launch: called once, right before the first all-reduce these names complete (the caller makes the current
+        stream wait for work of another stream that wrote the bucket: the collective is ordered behind the CURRENT stream)."""
         if not self.active():
             return
         for n in names:
             k = self.owner[n]
             self.pending[k] -= 1
             if self.pending[k] == 0 and not self.launched[k]:
+                if before_launch is not None:
+                    before_launch()
+                    before_launch = None
                 a, b = self.ranges[k]
                 self.launched[k] = True
                 self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))

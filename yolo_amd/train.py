@@ -464,8 +464,9 @@ class Trainer(object):
             names, done = self._pending_wgrad
             self._pending_wgrad = None
             if self.buckets.active():
-                torch.cuda.current_stream().wait_event(done)
-                self.buckets.done(names)
+                # the main stream waits for the side stream only when these parameters COMPLETE a bucket (4 times per step,
+                # not once per layer: the side stream runs its kernels in order, so its latest event covers the earlier ones)
+                self.buckets.done(names, before_launch=lambda: torch.cuda.current_stream().wait_event(done))
 
     def _backward(self, P, exchange=True, capture=None):
         """capture: optional dict that receives, per conv name, the gradient w.r.t. the layer output as the layer saw it
