@@ -122,6 +122,14 @@ int yolo_stem_conv_fwd(const float* x_nchw, const float* w_oihw, const float* sc
                        void* y, int N, int H, int W, int Cin, int Cout, int dtype, float slope,
                        void* stream);
 
+/* The same with BatchNorm's batch sums of the stored output taken in the kernel (training step; see yolo_conv_desc.stats):
+ * partials = yolo_stem_stats_rows() rows of [2][Cout] float32 (pass cout_pad = Cout to yolo_bn_train_fwd_partials).
+ * Cout % 8 == 0 and 64 % (Cout / 8) == 0 (YOLO_EUNSUPPORTED otherwise). */
+int yolo_stem_stats_rows(int N, int H, int W, int Cout);
+int yolo_stem_conv_fwd_stats(const float* x_nchw, const float* w_oihw, const float* scale, const float* bias,
+                             void* y, int N, int H, int W, int Cin, int Cout, int dtype, float slope,
+                             float* partials, void* stream);
+
 /* One DarknetBasicBlockV3 (basic_yolo.py:26; gluoncv darknet.py: x + conv3x3(C)(conv1x1(C/2)(x)), each conv with
  * folded BN + LeakyReLU, no activation after the add) as ONE inference kernel for the first stages: x, y (N,H,W,C)
  * bf16 NHWC; w1_packed / w2_packed = yolo_pack_conv_weights images of the (C/2,C,1,1) and (C,C/2,3,3) convs; scale /

@@ -493,3 +493,41 @@ def test_conv_statistics_epilogue(lib, cuda, case, algo, mode):
     np.testing.assert_allclose(g1.cpu().numpy(), g2.cpu().numpy(), rtol=1e-4, atol=1e-5 * sc)
     np.testing.assert_allclose(b1.cpu().numpy(), b2.cpu().numpy(), rtol=1e-4, atol=1e-5 * sc)
     assert float((dy1.float() - dy2.float()).abs().max()) <= 1e-2 * float(dy2.float().abs().max())
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 96, 32), (1, 37, 61, 32), (3, 20, 130, 64), (2, 416, 416, 32), (1, 9, 7, 16)])
+def test_stem_statistics(lib, cuda, shape):
+    """yolo_stem_conv_fwd_stats: the stem kernel's own batch sums (partial rows per wave) give the same BatchNorm as the
+    reduction over the stored map; the stored map itself is bit-identical to yolo_stem_conv_fwd's."""
+    N, H, W, Cout = shape
+    rng = np.random.default_rng(3)
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.from_numpy(rng.random((N, 3, H, W), dtype=np.float32)).to(cuda)
+    w = torch.from_numpy((rng.standard_normal((Cout, 3, 3, 3)) / 5).astype(np.float32)).to(cuda)
+    ones, zeros = torch.ones(Cout, device=cuda), torch.zeros(Cout, device=cuda)
+    y1 = torch.empty((N, H, W, Cout), dtype=torch.bfloat16, device=cuda); y2 = torch.empty_like(y1)
+    rows = lib.yolo_stem_stats_rows(N, H, W, Cout)
+    assert rows > 0
+    part = torch.full((rows, 2, Cout), float('nan'), device=cuda)
+    assert lib.yolo_stem_conv_fwd_stats(x.data_ptr(), w.data_ptr(), ones.data_ptr(), zeros.data_ptr(), y1.data_ptr(), N, H, W, 3,
+                                        Cout, L.BF16, 1.0, part.data_ptr(), st) == 0
+    assert lib.yolo_stem_conv_fwd(x.data_ptr(), w.data_ptr(), ones.data_ptr(), zeros.data_ptr(), y2.data_ptr(), N, H, W, 3, Cout,
+                                  L.BF16, 1.0, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y1.view(torch.int16), y2.view(torch.int16)) and bool(torch.isfinite(part).all())
+    gamma, beta = torch.rand(Cout, device=cuda) + .5, torch.randn(Cout, device=cuda) * .1
+    ws = [torch.zeros(2 * Cout, dtype=torch.float64, device=cuda) for _ in range(4)]
+    m1, i1, m2, i2 = (torch.empty(Cout, device=cuda) for _ in range(4))
+    z1, z2 = torch.empty_like(y1), torch.empty_like(y1)
+    rm, rv = torch.zeros(Cout, device=cuda), torch.ones(Cout, device=cuda)
+    npix = N * H * W
+    assert lib.yolo_bn_train_fwd_partials(part.data_ptr(), rows, Cout, y1.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None,
+                                          z1.data_ptr(), m1.data_ptr(), i1.data_ptr(), rm.data_ptr(), rv.data_ptr(), ws[0].data_ptr(),
+                                          ws[1].data_ptr(), 2 * Cout, npix, Cout, 1e-5, 0.9, 0.1, L.BF16, st) == 0
+    assert lib.yolo_bn_train_fwd_pp(y1.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, z2.data_ptr(), m2.data_ptr(),
+                                    i2.data_ptr(), rm.data_ptr(), rv.data_ptr(), ws[2].data_ptr(), ws[3].data_ptr(), 2 * Cout, npix,
+                                    Cout, 1e-5, 0.9, 0.1, L.BF16, st) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(m1.cpu().numpy(), m2.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(i1.cpu().numpy(), i2.cpu().numpy(), rtol=1e-5)
+    assert float((z1.float() - z2.float()).abs().max()) <= 1e-2 * float(z2.float().abs().max())

@@ -14,12 +14,15 @@ constexpr int STEM_RW = 4;             // output rows per wave
 constexpr int STEM_TH = 4 * STEM_RW;   // output rows per tile (4 waves)
 constexpr int STEM_PW = STEM_TW + 4;   // LDS row pitch in pixels (halo + over-read slack)
 
-template <int MI>
+// STATS (training): per-channel sum / sum of squares of the STORED bf16 outputs, one partial row [2][Cout] per wave
+// (row = block * 4 + wave), for yolo_bn_train_fwd_partials -- BatchNorm's batch statistics without a pass over the
+// 416 x 416 x 32 map (the largest reduction of the step).  Needs the 16-byte store path (Cout % 8 == 0, 64 % (Cout / 8) == 0).
+template <int MI, int STATS = 0>
 __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ bias, uint16_t* __restrict__ y,
                                                         int N, int H, int W, int Cout, float slope, int tiles_x,
-                                                        int tiles_y) {
+                                                        int tiles_y, float* __restrict__ part = nullptr) {
     __shared__ __attribute__((aligned(16))) uint2 tile[(STEM_TH + 2) * STEM_PW];
     __shared__ __attribute__((aligned(16))) uint2 obuf[4 * 64 * (MI * 32 * 2 + 16) / 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,6 +81,9 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     char* ot = (char*)obuf + wave * (64 * OP);
     const int upp = Cout / 4;                          // 8-byte units per output pixel
     const int npx = min(STEM_TW, W - x0);
+    float ssum[8], qsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ssum[e] = qsum[e] = 0.f;
 #pragma unroll 1
     for (int rw = 0; rw < STEM_RW; ++rw) {
         const int lr = wave * STEM_RW + rw;            // output row within the tile
@@ -133,7 +139,16 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
             const int upp16 = Cout / 8;
             for (int u = lane; u < npx * upp16; u += 64) {
                 const int px = u / upp16, q = u - px * upp16;
-                *(uint4*)(yrow + (long long)px * Cout + q * 8) = *(const uint4*)(ot + px * OP + q * 16);
+                const uint4 o = *(const uint4*)(ot + px * OP + q * 16);
+                *(uint4*)(yrow + (long long)px * Cout + q * 8) = o;
+                if constexpr (STATS) {                 // (q = lane % upp16 for every u of this lane: 64 % upp16 == 0)
+                    const uint32_t ow[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float t = bf16_bits_to_f32((e & 1) ? (ow[e >> 1] >> 16) : (ow[e >> 1] & 0xffffu));
+                        ssum[e] += t; qsum[e] += t * t;
+                    }
+                }
             }
         } else {
             for (int u = lane; u < npx * upp; u += 64) {
@@ -142,6 +157,45 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
             }
         }
     }
+    if constexpr (STATS) {
+        // combine the 64 / upp16 lanes that own the same 8 channels through the wave's scratch, one partial row per wave
+        const int upp16 = Cout / 8, nl = 64 / upp16;
+        float* sc4 = (float*)ot;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc4[lane * 16 + e] = ssum[e]; sc4[lane * 16 + 8 + e] = qsum[e]; }
+        float* prow = part + ((long long)blockIdx.x * 4 + wave) * 2 * Cout;
+        for (int o = lane; o < upp16 * 16; o += 64) {
+            const int qx = o >> 4, val = o & 15;
+            float t = 0.f;
+            for (int r = 0; r < nl; ++r) t += sc4[(r * upp16 + qx) * 16 + val];
+            prow[(val >> 3) * Cout + qx * 8 + (val & 7)] = t;
+        }
+    }
+}
+
+extern "C" int yolo_stem_stats_rows(int N, int H, int W, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0) return YOLO_EINVAL;
+    if ((Cout % 8) || Cout > 64 || (64 % (Cout / 8))) return YOLO_EUNSUPPORTED;
+    const long long rows = (long long)N * ((W + STEM_TW - 1) / STEM_TW) * ((H + STEM_TH - 1) / STEM_TH) * 4;
+    return rows > 0x7fffffffLL ? YOLO_EUNSUPPORTED : (int)rows;
+}
+
+extern "C" int yolo_stem_conv_fwd_stats(const float* x_nchw, const float* w_oihw, const float* scale, const float* bias,
+                                        void* y, int N, int H, int W, int Cin, int Cout, int dtype, float slope,
+                                        float* partials, void* stream) {
+    if (!x_nchw || !w_oihw || !scale || !bias || !y || !partials || N <= 0 || H <= 0 || W <= 0) return YOLO_EINVAL;
+    if (!(slope >= 0.f && slope <= 1.f)) return YOLO_EINVAL;
+    if (Cin != 3 || dtype != YOLO_BF16 || yolo_stem_stats_rows(N, H, W, Cout) <= 0) return YOLO_EUNSUPPORTED;
+    const int tiles_x = (W + STEM_TW - 1) / STEM_TW, tiles_y = (H + STEM_TH - 1) / STEM_TH;
+    const long long grid = (long long)N * tiles_x * tiles_y;
+    if (Cout <= 32)
+        YOLO_LAUNCH((stem_mfma_kernel<1, 1>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x_nchw, w_oihw, scale,
+                    bias, (uint16_t*)y, N, H, W, Cout, slope, tiles_x, tiles_y, partials);
+    else
+        YOLO_LAUNCH((stem_mfma_kernel<2, 1>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x_nchw, w_oihw, scale,
+                    bias, (uint16_t*)y, N, H, W, Cout, slope, tiles_x, tiles_y, partials);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
 }
 
 extern "C" int yolo_stem_conv_fwd(const float* x_nchw, const float* w_oihw, const float* scale, const float* bias,
@@ -155,10 +209,10 @@ extern "C" int yolo_stem_conv_fwd(const float* x_nchw, const float* w_oihw, cons
     const long long grid = (long long)N * tiles_x * tiles_y;
     if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
     if (Cout <= 32)
-        YOLO_LAUNCH(stem_mfma_kernel<1>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x_nchw, w_oihw, scale,
+        YOLO_LAUNCH((stem_mfma_kernel<1, 0>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x_nchw, w_oihw, scale,
                     bias, (uint16_t*)y, N, H, W, Cout, slope, tiles_x, tiles_y);
     else
-        YOLO_LAUNCH(stem_mfma_kernel<2>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x_nchw, w_oihw, scale,
+        YOLO_LAUNCH((stem_mfma_kernel<2, 0>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x_nchw, w_oihw, scale,
                     bias, (uint16_t*)y, N, H, W, Cout, slope, tiles_x, tiles_y);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;

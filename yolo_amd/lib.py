@@ -52,6 +52,8 @@ SIGNATURES = {
     'yolo_conv_kernel_name': (_i, [C.POINTER(ConvDesc), C.c_char_p, _i]),
     'yolo_conv_stats_rows': (_i, [C.POINTER(ConvDesc)]),
     'yolo_stem_conv_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'yolo_stem_stats_rows': (_i, [_i, _i, _i, _i]),
+    'yolo_stem_conv_fwd_stats': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     'yolo_stem_down_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'yolo_res_block_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'yolo_composite': (_i, [_vp, _vp, _vp, _vp, _ll, _vp]),

@@ -308,6 +308,23 @@ class Trainer(object):
                 if c is g.stem and self.ldt == L.BF16 and c.cin == 3 and c.cout % 4 == 0 and c.cout <= 64:
                     # the fused NCHW-image stem kernel of the inference path (identity scale/bias, linear): raw y
                     wp, wd, ones, bias, zeros = self._prep[c.name]
+                    rows = lib.yolo_stem_stats_rows(B, H, W, c.cout) if self._fuse_fwd else -1
+                    if rows > 0:
+                        # the stem's batch sums are taken in the kernel too (the largest reduction pass of the step)
+                        if getattr(P, 'stem_part', None) is None:
+                            P.stem_part = torch.empty(rows * 2 * c.cout, dtype=torch.float32, device=self.dev)
+                        L.check(lib.yolo_stem_conv_fwd_stats(images.data_ptr(), L.ptr(self.pview[c.name + '.weight']), L.ptr(ones),
+                                                             L.ptr(zeros), L.ptr(y.val), B, H, W, 3, c.cout, self.ldt, 1.0,
+                                                             L.ptr(P.stem_part), st), 'stem')
+                        npix, p = B * H * W, self.net.params
+                        ws, wn = self._next_ws()
+                        L.check(lib.yolo_bn_train_fwd_partials(L.ptr(P.stem_part), rows, c.cout, L.ptr(y.val),
+                                                               L.ptr(p[c.name + '.gamma']), L.ptr(p[c.name + '.beta']), None,
+                                                               L.ptr(z.val), L.ptr(op['mean']), L.ptr(op['invstd']),
+                                                               L.ptr(p[c.name + '.running_mean']), L.ptr(p[c.name + '.running_var']),
+                                                               ws, wn, self.ws2[0].numel(), npix, c.cout, BN_EPS, BN_MOMENTUM,
+                                                               LEAKY_SLOPE, self.ldt, st), 'bn (stem partials)')
+                        continue
                     L.check(lib.yolo_stem_conv_fwd(images.data_ptr(), L.ptr(self.pview[c.name + '.weight']), L.ptr(ones),
                                                    L.ptr(zeros), L.ptr(y.val), B, H, W, 3, c.cout, self.ldt, 1.0, st), 'stem')
                 else:
