@@ -42,7 +42,7 @@ template <> struct Frag<float> {
 // KS: kernel size; S: stride; block = WAVES_P x WAVES_C waves (=4), wave tile = NI*32 pixels x
 // MI*32 couts; XSLOTS: LDS input slots (64 B each) per plane; TS: K-steps ("taps") per barrier
 // round: the 3 kw taps of one kh row for KS=3, TS consecutive K-chunks for KS=1.
-template <typename T, int KS, int S, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int TS>
+template <typename T, int KS, int S, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int TS, int STATS = 0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     static_assert(WAVES_P * WAVES_C == 4, "256 threads");
     static_assert(KS == 1 || TS == 3, "3x3: one kh row per step");
@@ -237,7 +237,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
     // ---- epilogue (conv_epilogue.h): every wave transposes its slab through its own LDS scratch ------
     __syncthreads();                     // all waves are done reading the staged tiles
-    conv_epilogue<T, MI, NI>(acc, yoff, smem + wave * YOLO_EPI_WAVE_BYTES, a, co0 + wave_c * MI * 32, lane, roff);
+    float* srow = STATS ? a.stats + ((size_t)tile_p * WAVES_P + wave_p) * 2 * a.Cout_pad : nullptr;     // (conv_epilogue.h)
+    conv_epilogue<T, MI, NI, STATS>(acc, yoff, smem + wave * YOLO_EPI_WAVE_BYTES, a, co0 + wave_c * MI * 32, lane, roff, srow);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -250,11 +251,6 @@ constexpr int XSLOTS_S2 = 832;
 template <typename T, int KS, int S, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int TS>
 static int launch_cfg(ConvArgs& a, hipStream_t st, const NameOut* name) {
     constexpr int BP = WAVES_P * NI * 32, BC = WAVES_C * MI * 32;
-    if (name) {
-        snprintf(name->buf, name->len, "void conv_igemm_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d>(ConvArgs)",
-                 sizeof(T) == 2 ? "bf16_t" : "float", KS, S, WAVES_P, WAVES_C, MI, NI, XSLOTS, TS);
-        return YOLO_OK;
-    }
     if (KS == 3) {
         int best = -1, best_hs = 1 << 30;
         for (int d = 1; d <= a.Wo; ++d) {
@@ -277,6 +273,28 @@ static int launch_cfg(ConvArgs& a, hipStream_t st, const NameOut* name) {
     a.tiles_c = (a.Cout + BC - 1) / BC;
     const long long grid = (long long)a.nstrips * a.tiles_per_strip * a.tiles_c;
     if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
+    // BatchNorm forward sums in the epilogue (stats_mode 1 only here; conv_epilogue.h)
+    constexpr bool kStats = sizeof(T) == 2;
+    const bool stats_ok = kStats && a.stats_mode == 1 && !a.out_f32 && !a.d2s && !a.up2 && (a.Cout % 8) == 0 && (a.y_ps % 8) == 0 &&
+                          (a.y_bs % 8) == 0;
+    if (a.stats && !stats_ok) return YOLO_EUNSUPPORTED;
+    if (name) {
+        if (a.stats)
+            snprintf(name->buf, name->len, "void conv_igemm_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, 1>(ConvArgs)",
+                     sizeof(T) == 2 ? "bf16_t" : "float", KS, S, WAVES_P, WAVES_C, MI, NI, XSLOTS, TS);
+        else
+            snprintf(name->buf, name->len, "void conv_igemm_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d>(ConvArgs)",
+                     sizeof(T) == 2 ? "bf16_t" : "float", KS, S, WAVES_P, WAVES_C, MI, NI, XSLOTS, TS);
+        if (name->stats_rows) *name->stats_rows = a.stats ? a.nstrips * a.tiles_per_strip * WAVES_P : -1;
+        return YOLO_OK;
+    }
+    if constexpr (kStats) {
+        if (a.stats) {
+            YOLO_LAUNCH((conv_igemm_kernel<T, KS, S, WAVES_P, WAVES_C, MI, NI, XSLOTS, TS, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);
+            YOLO_LAUNCH_CHECK();
+            return YOLO_OK;
+        }
+    }
     YOLO_LAUNCH((conv_igemm_kernel<T, KS, S, WAVES_P, WAVES_C, MI, NI, XSLOTS, TS>), dim3((unsigned)grid),
                        dim3(256), 0, st, a);
     YOLO_LAUNCH_CHECK();
@@ -397,8 +415,14 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
         if (a.stats_mode == 2 && (!a.s_y || !a.s_mean || !a.s_invstd || !a.s_gamma || !a.s_beta)) return YOLO_EINVAL;
         int algo = d->algo;
         if (algo == 0) algo = conv_auto_algo(a, d->ksize, d->stride, d->dtype);
-        if (algo < 2 || algo == 13 || algo == 14) return YOLO_EUNSUPPORTED;
-        return conv_pipe_dispatch(a, d->ksize, d->stride, d->dtype, algo, st, nm);
+        if (algo == 13 || algo == 14) return YOLO_EUNSUPPORTED;                 // (the streaming kernels have none)
+        if (algo >= 2) {
+            ConvArgs b = a;
+            const int rc = conv_pipe_dispatch(b, d->ksize, d->stride, d->dtype, algo, st, nm);
+            if (rc != YOLO_EUNSUPPORTED || d->algo) return rc;
+        }
+        if (a.stats_mode != 1 || d->dtype != YOLO_BF16) return YOLO_EUNSUPPORTED;   // generic kernel: forward sums, bf16
+        return launch_dtype<bf16_t>(a, d->ksize, d->stride, st, nm);
     }
     if (d->algo == 13 || d->algo == 14) return conv_stream_dispatch(a, d->ksize, d->stride, d->dtype, d->algo, st, nm);
     if (d->algo >= 2) return conv_pipe_dispatch(a, d->ksize, d->stride, d->dtype, d->algo, st, nm);
