@@ -22,10 +22,15 @@
 #include <stdlib.h>
 #include <type_traits>
 
-__device__ __attribute__((aligned(64))) unsigned int yolo_zero_page[16];
+// The file is compiled TWICE (csrc/Makefile): YOLO_PIPE_PART 0 = the 3x3 kernels and conv_pipe_dispatch, 1 = the 2x2-window
+// and 1x1 kernels behind conv_pipe_dispatch_b -- two translation units of ~65 instantiations each build in parallel.
+#ifndef YOLO_PIPE_PART
+#define YOLO_PIPE_PART 0
+#endif
+namespace { __device__ __attribute__((aligned(64))) unsigned int yolo_zero_page[16]; }
 
-#ifdef YOLO_STAMP
-// Instrumented build only (make stamp): per-block shader-clock stamps of the phases of conv_pipe_kernel.
+#if defined(YOLO_STAMP) && YOLO_PIPE_PART == 0
+// Instrumented build only (make stamp): per-block shader-clock stamps of the phases of conv_pipe_kernel (3x3 unit).
 __device__ long long yolo_stamps[8192 * 8];
 #define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) yolo_stamps[blockIdx.x * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #define STAMP_ID() do { if (threadIdx.x == 0 && blockIdx.x < 8192) { unsigned id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); yolo_stamps[blockIdx.x * 8 + 7] = (long long)id | ((long long)(xcc & 0xf) << 32); yolo_stamps[blockIdx.x * 8 + 6] = wall_clock64(); } } while (0)
@@ -452,7 +457,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     float* srow = STATS ? a.stats + ((size_t)tile_p * WAVES_P + wave_p) * 2 * a.Cout_pad : nullptr;
     conv_epilogue<T, MI, NI, STATS>(acc, yoff, smem + wave * YOLO_EPI_WAVE_BYTES, a, co0 + wave_c * MI * 32, lane, roff, srow);
     STAMP(4);
-#ifdef YOLO_STAMP
+#if defined(YOLO_STAMP) && YOLO_PIPE_PART == 0
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(5);
 #endif
@@ -533,8 +538,11 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
 //           4-slot weight ring
 //   11: 4 waves, 64 px x 128 cout; 12 (1x1 only): 4 waves, 64 px x 256 cout -- small-M layers (13x13 maps at
 //       batch 32 have 5408 pixels: more, smaller tiles fill the chip)
+int conv_pipe_dispatch_b(ConvArgs& a, int ks, int dtype, int algo, hipStream_t st, const NameOut* nm);     // (unit 1)
+
 template <typename T>
 static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_t st, const NameOut* nm) {
+#if YOLO_PIPE_PART == 0
     if (ks == 3 && stride == 2) {
         // stride 2: the input footprint is ~4x the output tile, so tiles are 128 output pixels
         switch (algo) {
@@ -545,18 +553,6 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
             case 16: return launch_pipe<T, 3, 2, 4, 2, 2, 640, 2>(a, st, nm);
             case 17: return launch_pipe<T, 3, 2, 4, 1, 2, 640, 2>(a, st, nm);
             case 18: return launch_pipe<T, 3, 2, 4, 2, 2, 768, 2>(a, st, nm);    // (768 slots: tiles that cross image boundaries)
-        }
-        return YOLO_EUNSUPPORTED;
-    }
-    if (ks == 2) {
-        // 2x2 window (yolo_conv_dgrad_s2, bf16 only): four phases per K chunk
-        if constexpr (sizeof(T) == 2) {
-            switch (algo) {
-                case 2: return launch_pipe<T, 2, 2, 4, 2, 4, 512>(a, st, nm);    // 256 px x 256 cout
-                case 6: return launch_pipe<T, 2, 2, 4, 2, 3, 384>(a, st, nm);    // 192 px x 256 cout
-                case 10: return launch_pipe<T, 2, 2, 4, 2, 2, 384>(a, st, nm);   // 128 px x 256 cout
-                case 4: return launch_pipe<T, 2, 2, 2, 2, 2, 256>(a, st, nm);    // 128 px x 128 cout, 4 waves
-            }
         }
         return YOLO_EUNSUPPORTED;
     }
@@ -571,7 +567,23 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
             case 8: return launch_pipe<T, 3, 2, 2, 2, 3, 320>(a, st, nm);
             case 11: return launch_pipe<T, 3, 2, 2, 2, 1, 192>(a, st, nm);
         }
-    } else {
+        return YOLO_EUNSUPPORTED;
+    }
+    return conv_pipe_dispatch_b(a, ks, sizeof(T) == 2 ? YOLO_BF16 : YOLO_F32, algo, st, nm);
+#else
+    if (ks == 2) {
+        // 2x2 window (yolo_conv_dgrad_s2, bf16 only): four phases per K chunk
+        if constexpr (sizeof(T) == 2) {
+            switch (algo) {
+                case 2: return launch_pipe<T, 2, 2, 4, 2, 4, 512>(a, st, nm);    // 256 px x 256 cout
+                case 6: return launch_pipe<T, 2, 2, 4, 2, 3, 384>(a, st, nm);    // 192 px x 256 cout
+                case 10: return launch_pipe<T, 2, 2, 4, 2, 2, 384>(a, st, nm);   // 128 px x 256 cout
+                case 4: return launch_pipe<T, 2, 2, 2, 2, 2, 256>(a, st, nm);    // 128 px x 128 cout, 4 waves
+            }
+        }
+        return YOLO_EUNSUPPORTED;
+    }
+    {
         switch (algo) {
             // 1x1: the lean K loop wherever the K extent allows it (>= 4 phases), the generic loop otherwise
 #define YOLO_PIPE1(...)                                                                        \
@@ -601,8 +613,15 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
         }
     }
     return YOLO_EUNSUPPORTED;
+#endif
 }
 
+#if YOLO_PIPE_PART == 1
+int conv_pipe_dispatch_b(ConvArgs& a, int ks, int dtype, int algo, hipStream_t st, const NameOut* nm) {
+    if (dtype == YOLO_BF16) return pipe_dispatch_t<bf16_t>(a, ks, 1, algo, st, nm);
+    return pipe_dispatch_t<float>(a, ks, 1, algo, st, nm);
+}
+#else
 int conv_pipe_dispatch(ConvArgs& a, int ks, int stride, int dtype, int algo, hipStream_t st, const NameOut* nm) {
     if ((ks != 1 && ks != 2 && ks != 3) || (stride != 1 && !(ks == 3 && stride == 2))) return YOLO_EUNSUPPORTED;
     if (a.d2s && ks != 2) return YOLO_EUNSUPPORTED;
@@ -612,3 +631,4 @@ int conv_pipe_dispatch(ConvArgs& a, int ks, int stride, int dtype, int algo, hip
     if (dtype == YOLO_BF16) return pipe_dispatch_t<bf16_t>(a, ks, stride, algo, st, nm);
     return pipe_dispatch_t<float>(a, ks, stride, algo, st, nm);
 }
+#endif
