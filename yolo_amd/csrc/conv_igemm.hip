@@ -414,8 +414,14 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
         if (a.stats_mode != 1 && a.stats_mode != 2) return YOLO_EINVAL;
         if (a.stats_mode == 2 && (!a.s_y || !a.s_mean || !a.s_invstd || !a.s_gamma || !a.s_beta)) return YOLO_EINVAL;
         int algo = d->algo;
-        if (algo == 0) algo = conv_auto_algo(a, d->ksize, d->stride, d->dtype);
-        if (algo == 13 || algo == 14) return YOLO_EUNSUPPORTED;                 // (the streaming kernels have none)
+        if (algo == 13 || algo == 14) return conv_stream_dispatch(a, d->ksize, d->stride, d->dtype, algo, st, nm);
+        if (algo == 0) {
+            if (d->ksize == 3 && d->Cin <= 64 && !(d->stride == 2 && d->Cin == 64)) {          // (as in the plain path below)
+                const int rc = conv_stream_dispatch(a, d->ksize, d->stride, d->dtype, 13, st, nm);
+                if (rc != YOLO_EUNSUPPORTED) return rc;
+            }
+            algo = conv_auto_algo(a, d->ksize, d->stride, d->dtype);
+        }
         if (algo >= 2) {
             ConvArgs b = a;
             const int rc = conv_pipe_dispatch(b, d->ksize, d->stride, d->dtype, algo, st, nm);

@@ -27,9 +27,11 @@ struct StreamArgs {
     int N, H, W, Ho, Wo, Cout_pad;
     int nstrips, strip_w, rows_per_slice;
     float slope;
+    float* stats;           // STATS: partial rows [row][2][Cout_pad] of BatchNorm's forward sums (conv_epilogue.h), row =
+                            // (slice * blocks_x + block_x) * WAVES_P + pixel wave
 };
 
-template <int KS, int S, int CIN, int COUT, int NI>
+template <int KS, int S, int CIN, int COUT, int NI, int STATS = 0>
 __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
     constexpr int WAVES_C = COUT / 32, WAVES_P = 4 / WAVES_C;
     constexpr int TW = WAVES_P * NI * 32;               // output pixels per step (strip width capacity)
@@ -86,6 +88,9 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
     }
     const float slope = a.slope;
     const bool has_res = a.res != nullptr;
+    float ssum[8], qsum[8];                              // STATS: sums of the stored values of this lane's 8 channels
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ssum[e] = qsum[e] = 0.f;
 
     // ---- input staging (registers; loads run one step ahead) ----------------------------------------------------
     // (a two-step-ahead variant with two register sets was slower: it costs a wave of occupancy per SIMD, and
@@ -198,9 +203,19 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
                         v[2 * q + 1] += bf16_bits_to_f32(w[q] >> 16);
                     }
                 }
-                if (yo[ni][k] >= 0)
-                    *(uint4*)(a.y + yo[ni][k]) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
-                                                            pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+                if (yo[ni][k] >= 0) {
+                    const uint4 o = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                               pack_bf16x2(v[6], v[7]));
+                    *(uint4*)(a.y + yo[ni][k]) = o;
+                    if constexpr (STATS) {
+                        const uint32_t ow[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float t = bf16_bits_to_f32((e & 1) ? (ow[e >> 1] >> 16) : (ow[e >> 1] & 0xffffu));
+                            ssum[e] += t; qsum[e] += t * t;
+                        }
+                    }
+                }
             }
         }
 
@@ -213,15 +228,25 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
         if (slot0 >= RING) slot0 -= RING;
         __syncthreads();
     }
+    if constexpr (STATS) {
+        // the 16 lanes that share a channel octet (erow0 = 0..15) combine through the wave's scratch: one partial row
+        // (this wave's 32 channels of it) per (block, pixel wave)
+        float* sc4 = (float*)scr;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc4[lane * 16 + e] = ssum[e]; sc4[lane * 16 + 8 + e] = qsum[e]; }
+        float* prow = a.stats + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * WAVES_P + wave_p) * 2 * a.Cout_pad;
+        const int cx = lane >> 4, val = lane & 15;       // 4 octets x 16 values = 64 outputs, one per lane
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += sc4[(r * 4 + cx) * 16 + val];
+        prow[(val >> 3) * a.Cout_pad + wave_c * 32 + cx * 8 + (val & 7)] = t;
+    }
 }
 
 template <int KS, int S, int CIN, int COUT, int NI>
 static int launch_stream(const ConvArgs& c, hipStream_t st, const NameOut* nm) {
     constexpr int TW = (4 / (COUT / 32)) * NI * 32;
-    if (nm) {
-        snprintf(nm->buf, nm->len, "void conv_stream_kernel<%d, %d, %d, %d, %d>(StreamArgs)", KS, S, CIN, COUT, NI);
-        return YOLO_OK;
-    }
+    if (c.stats && (c.stats_mode != 1 || c.res)) return YOLO_EUNSUPPORTED;      // forward sums only
     StreamArgs a;
     a.x = c.x; a.wp = c.wp; a.scale = c.scale; a.bias = c.bias; a.res = c.res; a.y = c.y;
     a.N = c.N; a.H = c.H; a.W = c.W; a.Ho = c.Ho; a.Wo = c.Wo; a.Cout_pad = c.Cout_pad;
@@ -235,6 +260,18 @@ static int launch_stream(const ConvArgs& c, hipStream_t st, const NameOut* nm) {
     if (slices < 1) slices = 1;
     a.rows_per_slice = (int)((c.Ho + slices - 1) / slices);
     slices = (c.Ho + a.rows_per_slice - 1) / a.rows_per_slice;
+    a.stats = c.stats;
+    if (nm) {
+        snprintf(nm->buf, nm->len, c.stats ? "void conv_stream_kernel<%d, %d, %d, %d, %d, 1>(StreamArgs)"
+                                           : "void conv_stream_kernel<%d, %d, %d, %d, %d>(StreamArgs)", KS, S, CIN, COUT, NI);
+        if (nm->stats_rows) *nm->stats_rows = c.stats ? (int)(bx * slices * (4 / (COUT / 32))) : -1;
+        return YOLO_OK;
+    }
+    if (c.stats) {
+        YOLO_LAUNCH((conv_stream_kernel<KS, S, CIN, COUT, NI, 1>), dim3((unsigned)bx, (unsigned)slices), dim3(256), 0, st, a);
+        YOLO_LAUNCH_CHECK();
+        return YOLO_OK;
+    }
     YOLO_LAUNCH((conv_stream_kernel<KS, S, CIN, COUT, NI>), dim3((unsigned)bx, (unsigned)slices), dim3(256), 0, st, a);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;

@@ -285,10 +285,10 @@ class Trainer(object):
         return P
 
     def _pipe_kernel(self, d):
-        """True when yolo_conv_fwd serves d with a kernel that has a statistics epilogue (pipelined or generic, not streaming)."""
+        """True when yolo_conv_fwd serves d with a kernel that has a statistics epilogue (pipelined, generic and streaming ones for the forward sums)."""
         buf = C.create_string_buffer(256)
-        return self.lib.yolo_conv_kernel_name(C.byref(d), buf, 256) == 0 and (b'conv_pipe_kernel' in buf.value or
-                                                                              b'conv_igemm_kernel' in buf.value)
+        return self.lib.yolo_conv_kernel_name(C.byref(d), buf, 256) == 0 and any(
+            k in buf.value for k in (b'conv_pipe_kernel', b'conv_igemm_kernel', b'conv_stream_kernel'))
 
     def _next_ws(self):
         """(this call's BatchNorm workspace -- zero --, the one it zeroes for the next call)."""
