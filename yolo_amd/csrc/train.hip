@@ -698,7 +698,8 @@ static void wgrad_bf16_launch(const uint16_t* dy, const uint16_t* x, float* ws, 
     const int tiles_ci = (Cin + BN - 1) / BN, tiles_co = (Cout + BM - 1) / BM, taps = ksize * ksize;
     const long long chunks = ((long long)N * Ho * Wo + WG_KC - 1) / WG_KC;
     const long long tiles = (long long)tiles_ci * tiles_co * taps;
-    const long long target = 768;                                // the resident capacity: 3 blocks per CU
+    static const long long target_env = getenv("YOLO_PT_TARGET") ? atoll(getenv("YOLO_PT_TARGET")) : 0;   // (ablation knob)
+    const long long target = target_env ? target_env : 768;      // the resident capacity: 3 blocks per CU
     long long slices = target / tiles;                           // rounded DOWN: 774 blocks (one over a full round) cost 212 us where 756 take 185
     // at least 16 K-chunks per slice: every slice ends with a 128x128 atomic tile, which dominated the small 1x1 layers
     // (26x26 512->256 at batch 64: 60.7 -> 45.5 us; 8 and 32 chunks are worse)

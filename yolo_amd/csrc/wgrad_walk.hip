@@ -513,7 +513,11 @@ static int wgrad_gemm_launch(const void* dy, const void* x, float* dw, long long
     a.tiles_ci = Cin / BN;
     a.ntiles = a.tiles_ci * (Cout / BM);
     a.P = P;
-    const int resident = 256 * (163840 / (RD * SLOT) < 3 ? 163840 / (RD * SLOT) : 3);
+    // K-slices: ONE block per CU's worth (256).  Every block ends with its 64 KiB tile of atomics onto a gradient of a
+    // few MiB: at 768 blocks (what fits) the 11-GFLOP layers took 46-50 us, at 256 they take 29-32, the 45-GFLOP ones 67-72
+    // either way (YOLO_WG_SLOTS: the knob of that sweep)
+    static const int slots_env = getenv("YOLO_WG_SLOTS") ? atoi(getenv("YOLO_WG_SLOTS")) : 0;
+    const int resident = slots_env ? slots_env : 256;
     long long slices = resident / a.ntiles;
     if (slices < 1) slices = 1;
     long long Ls = (P + slices - 1) / slices;
@@ -535,13 +539,9 @@ int wgrad_gemm_dispatch(const void* dy, const void* x, float* dw, long long P, i
                         hipStream_t st) {
     if ((Cin % 128) || (Cout % 128) || (ps % 8) || P < 64) return YOLO_EUNSUPPORTED;
     if (P * Cin * 2 >= 0x7fffff00LL * 2 || P * ps * 2 >= 0x7fffff00LL * 2) return YOLO_EUNSUPPORTED;
-    if (variant == 0) {
-        // measured (bs 64): 45-GFLOP head layers 96-125 -> 70-86 us against the register-staged per-tap kernel; the 11-GFLOP
-        // backbone layers tie at ~46 us (both sit on their split-K atomics: 768 blocks x 64 KiB onto a 2 MiB gradient), and
-        // the 256 x 128 tile loses everywhere (one block per SIMD pair) -- so: the 128 x 128 tile, big layers only
-        if (2.0 * (double)P * Cin * Cout < 2.0e10) return YOLO_EUNSUPPORTED;
-        variant = 1;
-    }
+    // measured (bs 64) against the register-staged per-tap kernel: 45-GFLOP head layers 96-125 -> 64-72 us, 11-GFLOP backbone
+    // layers 46-49 -> 29-32 us; the 256 x 128 tile loses everywhere (one block per SIMD pair) -- so: the 128 x 128 tile
+    if (variant == 0) variant = 1;
     if (variant == 2 && (Cout % 256)) return YOLO_EUNSUPPORTED;
     if (variant == 1) return wgrad_gemm_launch<2, 2>(dy, x, dw, P, Cin, Cout, ps, st);
     if (variant == 2) return wgrad_gemm_launch<4, 2>(dy, x, dw, P, Cin, Cout, ps, st);
