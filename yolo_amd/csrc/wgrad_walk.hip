@@ -555,11 +555,13 @@ int wgrad_walk_dispatch(const void* dy, const void* x, float* dwt, int N, int H,
     if ((Cin % 64) || (Cout % 64) || (ps % 8) || W < 4 || H < 2) return YOLO_EUNSUPPORTED;
     if ((long long)N * H * W * Cin * 2 >= 0xffffff00LL || (long long)N * H * W * ps * 2 >= 0xffffff00LL) return YOLO_EUNSUPPORTED;
     if ((long long)N * (H + 1) >= 0x3fffffffLL) return YOLO_EUNSUPPORTED;
-    // four 4-column walkers win on every map width of the 416 / 608 families (13 ... 152): no K padding beyond W % 4, and
+    // four 4-column walkers win on the wider maps of the 416 / 608 families (19 ... 152): no K padding beyond W % 4, and
     // 40 instead of 34 staged pixels per K-step row cost less than the 16-column walker's padding
     if (variant == 0) {
-        static const int sc = getenv("YOLO_WW_SC") ? atoi(getenv("YOLO_WW_SC")) : 4;     // (A/B knob)
-        variant = sc == 16 ? 1 : 2;
+        // (maps of at most 16 columns: one 16-column walker covers a row with the same K padding as four narrow ones and a
+        //  quarter of the blocks -- 13x13, 1024 -> 2048: 439 -> 390 us, 512 -> 1024: a tie)
+        static const int sc = getenv("YOLO_WW_SC") ? atoi(getenv("YOLO_WW_SC")) : 0;     // (A/B knob)
+        variant = sc ? (sc == 16 ? 1 : 2) : (W <= 16 ? 1 : 2);
     }
     // (ablation knobs, read once: YOLO_WW_TARGET = blocks per launch, YOLO_WW_RD = ring depth, YOLO_WW_DBG see WalkArgs)
     static const int target = getenv("YOLO_WW_TARGET") ? atoi(getenv("YOLO_WW_TARGET")) : 512;    // two blocks per CU
