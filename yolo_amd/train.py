@@ -82,6 +82,7 @@ class Trainer(object):
         self._prep_s2 = {}          # conv name -> (sub-pixel dgrad weight image, ones, zeros); see _dgrad
         self._plans = {}
         self._dgrad_algo = {}
+        self._wgrad_algo = {}
         self._gb_cache = {}
         cmax = max(c.cout for c in g.convs())
         # two BatchNorm workspaces used alternately (yolo_bn_train_*_pp: a call leaves its own dirty and zeroes the next one's)
@@ -454,6 +455,37 @@ class Trainer(object):
             return 'walk'
         return 'k%ds%d' % (c.k, c.stride)
 
+    def _wgrad_algo_for(self, c, dy, xin):
+        """yolo_conv_wgrad_algo id for conv c: 0 (the library's choice) unless the net was built with tune='measure' -- then the
+        fastest of the kernels that take the shape, timed once per layer shape on a scratch gradient (the 8-wave row walk wins
+        on two D53 shapes, the 16-column walker on the 13x13 ones, ...)."""
+        if getattr(self.net, 'tune', None) != 'measure' or self.ldt != L.BF16 or os.environ.get('YOLO_TRAIN_NO_WGRAD_TUNE'):
+            return 0
+        N, Hh, Ww, Cx = xin.shape
+        key = (N, Hh, Ww, Cx, c.cout, c.k, c.stride)
+        if key not in self._wgrad_algo:
+            cands = (0, 2, 3, 4) if (c.k == 3 and c.stride == 1) else (0, 1, 5) if c.k == 1 else (0,)
+            best, best_t = 0, float('inf')
+            if len(cands) > 1:
+                lib, st = self.lib, L.stream_ptr()
+                scratch = torch.zeros((c.cout, Cx, c.k, c.k), dtype=torch.float32, device=self.dev)
+                call = lambda a: lib.yolo_conv_wgrad_algo(L.ptr(dy), L.ptr(xin.val), L.ptr(scratch), N, Hh, Ww, Cx, c.cout, c.k,
+                                                          c.stride, 0, self.ldt, L.ptr(self.wg_ws), a, st)
+                for a in cands:
+                    if call(a) != 0:
+                        continue
+                    call(a)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(6):
+                        call(a)
+                    e1.record(); e1.synchronize()
+                    t = e0.elapsed_time(e1)
+                    if t < best_t * 0.98:                       # (a later candidate must win by 2 %)
+                        best, best_t = a, t
+            self._wgrad_algo[key] = best
+        return self._wgrad_algo[key]
+
     def _wgrad(self, dy, names, launch, tag=''):
         """Run launch(stream) -- a weight-gradient call reading dy, which the current stream has just produced -- on the
         side stream (all of them, in order: they share one workspace).  The gradient buckets hear about `names` one
@@ -572,9 +604,10 @@ class Trainer(object):
                         self.gview[c.name + '.weight'].copy_(dw8[:, :3])
                     self._wgrad(dy, names, stem_wgrad, tag='stem')
                 else:
-                    self._wgrad(dy, names, lambda s_, c=c, dy=dy, xin=xin, N=N, Hh=Hh, Ww=Ww, Cx=Cx: L.check(
-                        lib.yolo_conv_wgrad(L.ptr(dy), L.ptr(xin.val), L.ptr(self.gview[c.name + '.weight']), N, Hh, Ww,
-                                            Cx, c.cout, c.k, c.stride, 0, self.ldt, L.ptr(self.wg_ws), s_), 'wgrad ' + c.name),
+                    wa = self._wgrad_algo_for(c, dy, xin)
+                    self._wgrad(dy, names, lambda s_, c=c, dy=dy, xin=xin, N=N, Hh=Hh, Ww=Ww, Cx=Cx, wa=wa: L.check(
+                        lib.yolo_conv_wgrad_algo(L.ptr(dy), L.ptr(xin.val), L.ptr(self.gview[c.name + '.weight']), N, Hh, Ww,
+                                                 Cx, c.cout, c.k, c.stride, 0, self.ldt, L.ptr(self.wg_ws), wa, s_), 'wgrad ' + c.name),
                                 tag=self._wgrad_tag(c, Cx))
                     self._dgrad(c, dy, y.shape, xin, c.cout)
         self._flush_wgrad()
