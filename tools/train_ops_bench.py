@@ -66,7 +66,7 @@ if 'bn' in a.what:
               (hw, C, tf, 3 * by / tf / 1e6, tb, 5 * by / tb / 1e6), flush=True)
 
 # (Ho=Wo, Cin, Cout, k, stride)
-WG_SHAPES = [(208, 32, 64, 3, 2), (208, 32, 64, 3, 1), (208, 64, 32, 1, 1), (104, 64, 128, 3, 1), (104, 128, 64, 1, 1),
+WG_SHAPES = [(104, 64, 128, 3, 2), (208, 32, 64, 3, 2), (208, 32, 64, 3, 1), (208, 64, 32, 1, 1), (104, 64, 128, 3, 1), (104, 128, 64, 1, 1),
              (52, 128, 256, 3, 1), (52, 256, 128, 1, 1), (26, 256, 512, 3, 1), (26, 512, 256, 1, 1),
              (13, 512, 1024, 3, 1), (13, 1024, 512, 1, 1), (416, 8, 32, 3, 1),
              # head layers, and the 608x608 family's widths

@@ -1149,7 +1149,8 @@ extern "C" int yolo_conv_wgrad_algo(const void* dy, const void* x, float* dw_oih
     } else if (algo > 1 && algo < 5) {
         return YOLO_EUNSUPPORTED;
     }
-    if (ksize == 3 && Cin <= 64) {
+    // (the 64 -> 128 stride-2 layer: the per-tap kernel measures 388 us against the strip kernel's 503 at 208^2 bs 64)
+    if (ksize == 3 && Cin <= 64 && !(stride == 2 && Cin == 64)) {
         const uint16_t* d16 = (const uint16_t*)dy;
         const uint16_t* x16 = (const uint16_t*)x;
         float* ws = (float*)workspace;
