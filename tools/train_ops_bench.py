@@ -13,6 +13,7 @@ ap.add_argument('--iters', type=int, default=20)
 ap.add_argument('--algos', default='0', help='weight-gradient kernels to time (yolo_conv_wgrad_algo ids)')
 ap.add_argument('--k3s1', action='store_true', help='weight gradient: only the 3x3 stride-1 shapes with Cin >= 64')
 ap.add_argument('--k1', action='store_true', help='weight gradient: only the 1x1 shapes')
+ap.add_argument('--s2', action='store_true', help='weight gradient: only the stride-2 shapes')
 ap.add_argument('--cold', action='store_true', help='evict L2 / MALL (1 GiB fill) before every timed launch')
 a = ap.parse_args()
 lib = L.load()
@@ -73,12 +74,16 @@ WG_SHAPES = [(104, 64, 128, 3, 2), (208, 32, 64, 3, 2), (208, 32, 64, 3, 1), (20
              (13, 1024, 2048, 3, 1), (26, 512, 1024, 3, 1), (52, 256, 512, 3, 1), (19, 512, 1024, 3, 1), (38, 256, 512, 3, 1),
              (76, 128, 256, 3, 1), (152, 64, 128, 3, 1),
              # 1x1 head layers
-             (13, 2048, 1024, 1, 1), (26, 1024, 512, 1, 1), (52, 512, 256, 1, 1)]
+             (13, 2048, 1024, 1, 1), (26, 1024, 512, 1, 1), (52, 512, 256, 1, 1),
+             # the deeper stride-2 layers
+             (52, 128, 256, 3, 2), (26, 256, 512, 3, 2), (13, 512, 1024, 3, 2)]
 if 'wgrad' in a.what:
     for ho, ci, co, k, s in WG_SHAPES:
         if a.k1 and k != 1:
             continue
         if a.k3s1 and not (k == 3 and s == 1 and ci >= 64):
+            continue
+        if a.s2 and s != 2:
             continue
         H = ho * s
         x = torch.randn((a.batch, H, H, ci), device=dev).bfloat16()

@@ -116,6 +116,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     constexpr int XL1 = X_STAGE1 / (NT * 16);
     constexpr int XL = KC * XL1;                         // LDS-DMAs per thread per X tile
     static_assert(X_STAGE1 % (NT * 16) == 0, "input stage must be whole DMAs");
+    static_assert(S != 2 || XSLOTS % 8 == 0, "stride 2: slots are permuted in groups of 8");
     // 1x1: depth of the X and W rings (loads run R1-1 phases ahead): 4 where that keeps the blocks per CU, else 3
 #ifndef YOLO_RING1
 #define YOLO_RING1 4
@@ -217,7 +218,8 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
 #pragma unroll
     for (int j = 0; j < XL1; ++j) {
         const int u = tid + j * NT;
-        const int slot = u >> 2, part = u & 3;
+        const int pos = u >> 2, part = u & 3;           // LDS position of the unit; `slot` = the halo slot it holds
+        const int slot = (S == 2) ? ((pos & ~7) | ((pos & 3) << 1) | ((pos >> 2) & 1)) : pos;
         bool valid;
         long long off;
         if constexpr (KS != 1) {
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
             valid = i < a.total_i;
             off = (long long)i * row_bytes;
         }
-        const int lp = (part ^ ((slot >> 2) & 3)) * 16;
+        const int lp = (part ^ ((S == 2 ? pos >> 3 : pos >> 2) & 3)) * 16;
         xo[j] = valid ? (unsigned)(off + lp) : 0xffffffffu;
     }
     if constexpr (KS != 1) {
@@ -303,7 +305,16 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int slot = (KS != 1) ? slot00[ni] + (q / KS) * PW + (q % KS) : slot00[ni];
-            bx[ni] = slot * 64 + ((h ^ ((slot >> 2) & 3)) << 4);
+            if constexpr (S == 2) {
+                // stride 2: the 32 pixels of a fragment are every other slot.  Inside each group of 8 slots the even ones
+                // sit in the first 256 bytes and the odd ones in the second, so that 16 lanes still cover four whole
+                // 256-byte lines (with the slots in pixel order they would touch half the banks: two-way conflicts on
+                // every input fragment read, which bound these kernels); the unit swizzle follows the group index
+                const int pos = (slot & ~7) | ((slot & 1) << 2) | ((slot >> 1) & 3);
+                bx[ni] = pos * 64 + ((h ^ ((slot >> 3) & 3)) << 4);
+            } else {
+                bx[ni] = slot * 64 + ((h ^ ((slot >> 2) & 3)) << 4);
+            }
         }
 #pragma unroll
         for (int ks = 0; ks < 2 * KC; ++ks) {

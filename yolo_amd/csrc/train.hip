@@ -726,7 +726,7 @@ template <int CO_F, int S, int TH>
 __global__ __launch_bounds__(64) void wgrad_strip_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
                                                          float* __restrict__ dwt, int N, int H, int W, int Cin, int Ho,
                                                          int Wo, int Cout, long long dy_ps, int tiles_ci, int tiles_co,
-                                                         int strips_w, int rows_per_slice) {
+                                                         int strips_w, int rows_per_slice, int pair_xcd) {
     constexpr int TW = 32;                          // output pixels per strip row = 2 MFMA K-steps
     constexpr int XW = (TW - 1) * S + 3;            // input pixels per staged row (with halo)
     constexpr int XP = 64 + 16, DP = CO_F * 64 + 16;  // LDS pitches (bytes per pixel row, padded)
@@ -738,8 +738,16 @@ __global__ __launch_bounds__(64) void wgrad_strip_kernel(const uint16_t* __restr
     char* dyl = smem + RING * XROW;
     const int lane = threadIdx.x;
     int b = blockIdx.x;
+    int tco;
+    if (pair_xcd) {
+        // the tiles_co blocks that read the same x strip sit 8 apart in launch order: same XCD, same L2, dispatched together
+        const int xcd = b & 7, q = b >> 3;
+        tco = q % tiles_co;
+        b = (q / tiles_co) * 8 + xcd;
+    } else {
+        tco = b % tiles_co; b /= tiles_co;
+    }
     const int tci = b % tiles_ci; b /= tiles_ci;
-    const int tco = b % tiles_co; b /= tiles_co;
     const int sw = b % strips_w;
     const int n = b / strips_w;
     const int ci0 = tci * 32, co0 = tco * CO_F * 32;
@@ -889,13 +897,16 @@ static void wgrad_strip_launch(const uint16_t* dy, const uint16_t* x, float* dwt
                                int Wo, int Cout, long long ps, hipStream_t st) {
     const int tiles_ci = (Cin + 31) / 32, tiles_co = (Cout + CO_F * 32 - 1) / (CO_F * 32), strips_w = (Wo + 31) / 32;
     const long long bx = (long long)tiles_ci * tiles_co * strips_w * N;
-    long long slices = (1024 + bx / 2) / bx;                  // ~4 single-wave blocks per CU resident
+    static const long long tgt = getenv("YOLO_STRIP_TARGET") ? atoll(getenv("YOLO_STRIP_TARGET")) : 1024;
+    long long slices = (tgt + bx / 2) / bx;                   // ~4 single-wave blocks per CU resident
     if (slices < 1) slices = 1;
     int rps = (int)((Ho + slices - 1) / slices);
     rps = (rps + TH - 1) / TH * TH;
     slices = (Ho + rps - 1) / rps;
+    static const int no_pair = getenv("YOLO_STRIP_NO_PAIR") ? 1 : 0;                                       // (ablation knob)
+    const int pair_xcd = (!no_pair && tiles_co > 1 && bx % (8 * tiles_co) == 0) ? 1 : 0;
     YOLO_LAUNCH((wgrad_strip_kernel<CO_F, S, TH>), dim3((unsigned)bx, (unsigned)slices), dim3(64), 0, st, dy, x, dwt, N, H,
-                W, Cin, Ho, Wo, Cout, ps, tiles_ci, tiles_co, strips_w, rps);
+                W, Cin, Ho, Wo, Cout, ps, tiles_ci, tiles_co, strips_w, rps, pair_xcd);
 }
 
 // ------------------------------------------------------------------------------------------------
