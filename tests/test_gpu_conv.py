@@ -84,11 +84,11 @@ PIPE_CASES = [
 ]
 
 
-@pytest.mark.parametrize('algo', [2, 3, 4, 5, 6, 7, 8, 11, 12, 19, 20, 21, 22, 23, 24, 25])
+@pytest.mark.parametrize('algo', [2, 3, 4, 5, 6, 7, 8, 11, 12, 19, 20, 21, 22, 23, 24, 25, 26])
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('case', PIPE_CASES)
 def test_conv_pipe(lib, cuda, case, dtype, algo):
-    if (algo in (6, 7) and case[5] != 3) or (algo in (12, 19, 20, 21, 22, 23, 24, 25) and case[5] != 1):
+    if (algo in (6, 7, 26) and case[5] != 3) or (algo in (12, 19, 20, 21, 22, 23, 24, 25) and case[5] != 1) or (algo == 26 and dtype != 'bf16'):
         pytest.skip('variant not defined for this kernel size')
     x, w, scale, bias, r = _mk(case, 4)
     y = run_conv(lib, cuda, x, w, scale, bias, case[6], 0.1, dtype, residual=r, algo=algo)
@@ -407,7 +407,7 @@ STATS_CASES = [(2, 32, 40, 70, 64, 3, 1), (3, 32, 33, 50, 64, 3, 2), (2, 64, 21,
 
 
 @pytest.mark.parametrize('mode', [1, 2])
-@pytest.mark.parametrize('algo', [0, 1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 16, 17, 18, 22, 23])
+@pytest.mark.parametrize('algo', [0, 1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 16, 17, 18, 22, 23, 26])
 @pytest.mark.parametrize('case', STATS_CASES)
 def test_conv_statistics_epilogue(lib, cuda, case, algo, mode):
     """yolo_conv_desc.stats: Gluon BatchNorm's batch sums taken in the convolution's epilogue (per pixel-tile partial rows,

@@ -16,6 +16,8 @@
 // bytes of LDS scratch one wave needs (max over MI in {1,2}): 32 rows x (64*4+16) + 2 x 32 x 8 (output offsets) + 2 x 32 x 8
 // (residual offsets, when the residual's strides differ from the output's)
 #define YOLO_EPI_WAVE_BYTES 9728
+// (wave tiles of more than 64 couts: the scratch row grows with MI)
+#define YOLO_EPI_WAVE_BYTES_MI(MI) ((MI) <= 2 ? YOLO_EPI_WAVE_BYTES : 32 * ((MI) * 128 + 16) + 4 * 32 * 8)
 
 // STATS (bf16, transposed path only; the host checks): BatchNorm batch statistics of the training step taken here instead
 // of in a pass of their own over the tensor.  After the transpose a lane owns 8 channels of one pixel row, so the column
@@ -34,7 +36,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
     constexpr int LPR = WN / CPL;               // lanes per pixel row
     constexpr int RPP = 64 / LPR;               // rows per pass
     constexpr int NPASS = 32 / RPP;
-    static_assert(32 * RS + 4 * 32 * 8 <= YOLO_EPI_WAVE_BYTES, "scratch size");
+    static_assert(32 * RS + 4 * 32 * 8 <= YOLO_EPI_WAVE_BYTES_MI(MI), "scratch size");
     const int l31 = lane & 31, h = lane >> 5;
     const float slope = a.slope;
     // scale == bias == nullptr: identity epilogue (the training step's raw convolutions and data gradients: BN and the

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
 #ifndef YOLO_RING1
 #define YOLO_RING1 4
 #endif
-    constexpr int EPI1_ = WAVES_P * WAVES_C * YOLO_EPI_WAVE_BYTES;
+    constexpr int EPI1_ = WAVES_P * WAVES_C * YOLO_EPI_WAVE_BYTES_MI(MI);
     constexpr int L13_ = 3 * KC * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) > EPI1_ ? 3 * KC * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) : EPI1_;
     constexpr int L1N_ = YOLO_RING1 * KC * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) > EPI1_ ? YOLO_RING1 * KC * (XSLOTS * 64 + WAVES_C * MI * 32 * 64) : EPI1_;
     // RD != 0 (1x1 only): an explicit ring depth.  The small-map 1x1 layers are bound by the latency of their loads (a
@@ -141,12 +141,12 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
 #ifndef YOLO_WRING
 #define YOLO_WRING 4
 #endif
-    constexpr int EPI_BYTES_ = WAVES_P * WAVES_C * YOLO_EPI_WAVE_BYTES;
+    constexpr int EPI_BYTES_ = WAVES_P * WAVES_C * YOLO_EPI_WAVE_BYTES_MI(MI);
     constexpr int LDS3 = XBUFS * X_STAGE + 3 * W_STAGE > EPI_BYTES_ ? XBUFS * X_STAGE + 3 * W_STAGE : EPI_BYTES_;
     constexpr int LDSN = XBUFS * X_STAGE + YOLO_WRING * W_STAGE > EPI_BYTES_ ? XBUFS * X_STAGE + YOLO_WRING * W_STAGE : EPI_BYTES_;
     constexpr int WR = (KS != 1) ? ((LDSN <= 163840 && 163840 / LDSN == 163840 / LDS3) ? YOLO_WRING : 3) : R1;
     constexpr int PIPE_BYTES = XBUFS * X_STAGE + WR * W_STAGE;
-    constexpr int EPI_BYTES = NW * YOLO_EPI_WAVE_BYTES;
+    constexpr int EPI_BYTES = NW * YOLO_EPI_WAVE_BYTES_MI(MI);
     __shared__ __attribute__((aligned(16))) char smem[PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)smem;
 
@@ -201,10 +201,15 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         for (int j = 0; j < WL; ++j) issue_w1(gp, j);
     };
     // input DMA j of chunk c into X buffer `buf`
+    // W1 (wave tiles of 128 couts: ONE wave per SIMD): the address of the zero page is taken once -- re-materialised per
+    // DMA it is an s_load + s_waitcnt lgkmcnt(0), which also drains the wave's LDS reads and nothing else runs on the SIMD
+    constexpr bool W1 = KS == 3 && MI == 4;
+    const char* zero_page = (const char*)yolo_zero_page;
+    if constexpr (W1) asm volatile("" : "+s"(zero_page));
     auto issue_x = [&](int j, int c, int buf) {
         const int kc = j / XL1, jj = j - kc * XL1;
         const int cc = (KS != 1) ? min(c, nchunks - 1) : min(c, nphase - 1) * KC + kc;      // (1x1: c counts phases)
-        const char* src = (xo[jj] != 0xffffffffu) ? a.x + ((size_t)xo[jj] + (size_t)cc * 64) : (const char*)yolo_zero_page;
+        const char* src = (xo[jj] != 0xffffffffu) ? a.x + ((size_t)xo[jj] + (size_t)cc * 64) : zero_page;
         glds16(src, wave_lds + buf * X_STAGE + kc * X_STAGE1 + jj * NT * 16);
     };
     static_assert(KS == 1 || XL <= PPC, "3x3: at most one input DMA per phase");
@@ -425,6 +430,76 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
             if constexpr (R1 > 3) { if (gp + 3 < nphase) lean_phase(std::integral_constant<int, 3 % R1>{}, gp + 3); }
             static_assert(R1 <= 4, "lean loop: ring depth <= 4");
         }
+    } else if constexpr (W1) {
+        // ---- one wave per SIMD (256 accumulator registers per wave): nothing covers a wave's LDS latency but the wave itself,
+        //      so the fragments are double-buffered in registers.  A phase is two K-steps of MI*NI MFMAs; the reads of step
+        //      t + 1 are issued before the MFMAs of step t.  The next phase's first fragments come from the next ring slot,
+        //      hence the counted wait + barrier sit in the MIDDLE of a phase (after its first step, by which time every DMA
+        //      of the phase has been issued) and the second step's MFMAs run over the first reads of the next phase. --------
+        static_assert(PPC == 9 && KC == 1 && S == 1, "W1: 3x3 stride 1");
+        uint4 fa[2][MI], fb[2][NI];
+        auto read_frags = [&](auto buf_c, int c, int q, int gp, int ks) {
+            constexpr int B = decltype(buf_c)::value;
+            const char* Wl = smem + W_OFF + (gp % WR) * W_STAGE;
+            const char* Xl = smem + (c & 1) * X_STAGE;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) fa[B][mi] = *(const uint4*)(Wl + mi * 2048 + (aoff0 ^ (ks * 32)));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int slot = slot00[ni] + (q / KS) * PW + (q % KS);
+                const int bxn = slot * 64 + ((h ^ ((slot >> 2) & 3)) << 4);
+                fb[B][ni] = *(const uint4*)(Xl + (bxn ^ (ks * 32)));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        read_frags(std::integral_constant<int, 0>{}, 0, 0, 0, 0);
+        for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+            for (int q = 0; q < PPC; ++q) {
+                const int gp = c * PPC + q;
+                const int nx = q < XL ? 1 : 0;
+                constexpr int NMM = MI * NI;
+                // ---- step 0: this phase's second fragments are read first; all DMAs of the phase go out between the MFMAs
+                read_frags(std::integral_constant<int, 1>{}, c, q, gp, 1);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        FragP<T>::mma(fa[0][mi], fb[0][ni], acc[mi][ni]);
+                        const int m = mi * NI + ni;
+                        constexpr int STRIDE = (NMM - 2) / (WL + 1) > 0 ? (NMM - 2) / (WL + 1) : 1;
+#pragma unroll
+                        for (int k = 0; k < WL + 1; ++k)
+                            if (m == min(1 + k * STRIDE, NMM - 1)) {
+                                if (k == 0) {
+                                    if (nx) {
+                                        __builtin_amdgcn_sched_barrier(0);
+                                        issue_x(q, c + 1, (c + 1) & 1);
+                                        __builtin_amdgcn_sched_barrier(0);
+                                    }
+                                } else {
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    issue_w1(gp + WR - 1, k - 1);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            }
+                    }
+                // ---- middle: phase gp+1's data has landed (this phase's DMAs and the previous phase's weight DMAs may still
+                //      be in flight), everyone's reads of the slots about to be overwritten are complete
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (q < XL) wait_vmcnt<2 * WL + 1>(); else wait_vmcnt<2 * WL>();
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- step 1 over the first reads of the next phase
+                if (q + 1 < PPC) read_frags(std::integral_constant<int, 0>{}, c, q + 1, gp + 1, 0);
+                else read_frags(std::integral_constant<int, 0>{}, c + 1, 0, gp + 1, 0);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) FragP<T>::mma(fa[1][mi], fb[1][ni], acc[mi][ni]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     } else {
     for (int c = 0; c < nchunks / KC; ++c) {
 #pragma unroll
@@ -466,7 +541,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     STAMP(3);
     // (STATS: one partial row of BatchNorm sums per (pixel tile, pixel wave))
     float* srow = STATS ? a.stats + ((size_t)tile_p * WAVES_P + wave_p) * 2 * a.Cout_pad : nullptr;
-    conv_epilogue<T, MI, NI, STATS>(acc, yoff, smem + wave * YOLO_EPI_WAVE_BYTES, a, co0 + wave_c * MI * 32, lane, roff, srow);
+    conv_epilogue<T, MI, NI, STATS>(acc, yoff, smem + wave * YOLO_EPI_WAVE_BYTES_MI(MI), a, co0 + wave_c * MI * 32, lane, roff, srow);
     STAMP(4);
 #if defined(YOLO_STAMP) && YOLO_PIPE_PART == 0
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -549,6 +624,11 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
 //           4-slot weight ring
 //   11: 4 waves, 64 px x 128 cout; 12 (1x1 only): 4 waves, 64 px x 256 cout -- small-M layers (13x13 maps at
 //       batch 32 have 5408 pixels: more, smaller tiles fill the chip)
+//   26: 3x3 stride 1, bf16: 4 waves, 256 px x 256 cout, wave tile 128x128 -- ONE wave per SIMD (256 accumulator registers),
+//       a third fewer LDS fragment reads per MFMA than algo 2, fragments double-buffered in registers (the W1 loop).
+//       Measured at batch 64: 1328 vs 1311 TFLOP/s on 19x19 1024->2048, 1263 vs 1276 on 38x38 512->1024, 1120 vs 1172 on
+//       76x76 256->512; a 192 px x 256 cout sibling (wave tile 128x96) ties algo 6 at batch 32 (1167 vs 1168, 1100 vs 1125)
+//       and was removed: the long-K layers are not bound by LDS traffic or by the loop structure (power / clock)
 int conv_pipe_dispatch_b(ConvArgs& a, int ks, int dtype, int algo, hipStream_t st, const NameOut* nm);     // (unit 1)
 
 template <typename T>
@@ -577,6 +657,9 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
             case 7: return launch_pipe<T, 3, 2, 4, 1, 3, 384>(a, st, nm);
             case 8: return launch_pipe<T, 3, 2, 2, 2, 3, 320>(a, st, nm);
             case 11: return launch_pipe<T, 3, 2, 2, 2, 1, 192>(a, st, nm);
+            case 26:                                                            // 4 waves, 256 px x 256 cout (wave tile 128x128)
+                if constexpr (sizeof(T) == 2) return launch_pipe<T, 3, 2, 2, 4, 4, 512>(a, st, nm);
+                break;
         }
         return YOLO_EUNSUPPORTED;
     }
