@@ -128,7 +128,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     // 64 x 128 tile has 12 KB per phase: 32 phases of K = 1024 took ~1000 cycles each with 3 phases in flight), so
     // some variants trade co-resident blocks for a deeper ring.
     constexpr int R1 = RD ? RD : ((L1N_ <= 163840 && 163840 / L1N_ == 163840 / L13_) ? YOLO_RING1 : 3);
-    static_assert(RD == 0 || KS == 1, "explicit ring depth: 1x1 only");
+    static_assert(RD == 0 || KS == 1 || (KS == 3 && RD >= 2), "explicit ring depth: 1x1, or the 3x3 weight ring");
     constexpr int XBUFS = (KS != 1) ? 2 : R1;
     static_assert(KS != 1 || XSLOTS == BP, "1x1: one slot per pixel");
     constexpr int PAD = KS / 2 - (KS == 2 ? 1 : 0);          // 3x3: 1; 2x2 (sub-pixel data gradient) and 1x1: 0
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     constexpr int EPI_BYTES_ = WAVES_P * WAVES_C * YOLO_EPI_WAVE_BYTES_MI(MI);
     constexpr int LDS3 = XBUFS * X_STAGE + 3 * W_STAGE > EPI_BYTES_ ? XBUFS * X_STAGE + 3 * W_STAGE : EPI_BYTES_;
     constexpr int LDSN = XBUFS * X_STAGE + YOLO_WRING * W_STAGE > EPI_BYTES_ ? XBUFS * X_STAGE + YOLO_WRING * W_STAGE : EPI_BYTES_;
-    constexpr int WR = (KS != 1) ? ((LDSN <= 163840 && 163840 / LDSN == 163840 / LDS3) ? YOLO_WRING : 3) : R1;
+    constexpr int WR = (KS != 1) ? ((KS == 3 && RD) ? RD : (LDSN <= 163840 && 163840 / LDSN == 163840 / LDS3) ? YOLO_WRING : 3) : R1;
     constexpr int PIPE_BYTES = XBUFS * X_STAGE + WR * W_STAGE;
     constexpr int EPI_BYTES = NW * YOLO_EPI_WAVE_BYTES_MI(MI);
     __shared__ __attribute__((aligned(16))) char smem[PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES];
@@ -657,6 +657,7 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
             case 7: return launch_pipe<T, 3, 2, 4, 1, 3, 384>(a, st, nm);
             case 8: return launch_pipe<T, 3, 2, 2, 2, 3, 320>(a, st, nm);
             case 11: return launch_pipe<T, 3, 2, 2, 2, 1, 192>(a, st, nm);
+            case 28: return launch_pipe<T, 3, 2, 2, 2, 2, 256, 1, 2>(a, st, nm);   // algo 4 with a 2-slot weight ring: 3 blocks per CU
             case 26:                                                            // 4 waves, 256 px x 256 cout (wave tile 128x128)
                 if constexpr (sizeof(T) == 2) return launch_pipe<T, 3, 2, 2, 4, 4, 512>(a, st, nm);
                 break;
