@@ -128,7 +128,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     // 64 x 128 tile has 12 KB per phase: 32 phases of K = 1024 took ~1000 cycles each with 3 phases in flight), so
     // some variants trade co-resident blocks for a deeper ring.
     constexpr int R1 = RD ? RD : ((L1N_ <= 163840 && 163840 / L1N_ == 163840 / L13_) ? YOLO_RING1 : 3);
-    static_assert(RD == 0 || KS == 1 || (KS == 3 && RD >= 2), "explicit ring depth: 1x1, or the 3x3 weight ring");
+    static_assert(RD == 0 || KS == 1, "explicit ring depth: 1x1 only");
     constexpr int XBUFS = (KS != 1) ? 2 : R1;
     static_assert(KS != 1 || XSLOTS == BP, "1x1: one slot per pixel");
     constexpr int PAD = KS / 2 - (KS == 2 ? 1 : 0);          // 3x3: 1; 2x2 (sub-pixel data gradient) and 1x1: 0
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     constexpr int EPI_BYTES_ = WAVES_P * WAVES_C * YOLO_EPI_WAVE_BYTES_MI(MI);
     constexpr int LDS3 = XBUFS * X_STAGE + 3 * W_STAGE > EPI_BYTES_ ? XBUFS * X_STAGE + 3 * W_STAGE : EPI_BYTES_;
     constexpr int LDSN = XBUFS * X_STAGE + YOLO_WRING * W_STAGE > EPI_BYTES_ ? XBUFS * X_STAGE + YOLO_WRING * W_STAGE : EPI_BYTES_;
-    constexpr int WR = (KS != 1) ? ((KS == 3 && RD) ? RD : (LDSN <= 163840 && 163840 / LDSN == 163840 / LDS3) ? YOLO_WRING : 3) : R1;
+    constexpr int WR = (KS != 1) ? ((LDSN <= 163840 && 163840 / LDSN == 163840 / LDS3) ? YOLO_WRING : 3) : R1;
     constexpr int PIPE_BYTES = XBUFS * X_STAGE + WR * W_STAGE;
     constexpr int EPI_BYTES = NW * YOLO_EPI_WAVE_BYTES_MI(MI);
     __shared__ __attribute__((aligned(16))) char smem[PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES];
@@ -629,6 +629,8 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
 //       Measured at batch 64: 1328 vs 1311 TFLOP/s on 19x19 1024->2048, 1263 vs 1276 on 38x38 512->1024, 1120 vs 1172 on
 //       76x76 256->512; a 192 px x 256 cout sibling (wave tile 128x96) ties algo 6 at batch 32 (1167 vs 1168, 1100 vs 1125)
 //       and was removed: the long-K layers are not bound by LDS traffic or by the loop structure (power / clock)
+//   (also tried: algo 4 with a 2-slot weight ring = 48 KB of LDS, three blocks per CU -- 4-10 % faster than algo 4 on the short-K
+//    layers, never faster than the 192-pixel tiles there, which fit neither three blocks of LDS nor of registers; removed)
 int conv_pipe_dispatch_b(ConvArgs& a, int ks, int dtype, int algo, hipStream_t st, const NameOut* nm);     // (unit 1)
 
 template <typename T>
@@ -657,7 +659,6 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
             case 7: return launch_pipe<T, 3, 2, 4, 1, 3, 384>(a, st, nm);
             case 8: return launch_pipe<T, 3, 2, 2, 2, 3, 320>(a, st, nm);
             case 11: return launch_pipe<T, 3, 2, 2, 2, 1, 192>(a, st, nm);
-            case 28: return launch_pipe<T, 3, 2, 2, 2, 2, 256, 1, 2>(a, st, nm);   // algo 4 with a 2-slot weight ring: 3 blocks per CU
             case 26:                                                            // 4 waves, 256 px x 256 cout (wave tile 128x128)
                 if constexpr (sizeof(T) == 2) return launch_pipe<T, 3, 2, 2, 4, 4, 512>(a, st, nm);
                 break;
