@@ -286,6 +286,33 @@ def test_d53_608_forward(cuda):
         assert e_hip < 1.5 * e_sim + 1e-3 and e_hip < 0.015, (e_hip, e_sim)
 
 
+def test_config4_608_bs64_measured_plan_replicated(cuda):
+    """The north-star shape as bench.py runs it (BASELINE configs[4] per GPU: D53 spec, 608x608, bs 64, bf16, measured kernel
+    variants).  A size-independent property at the full size: eval-mode images are independent, so a batch that repeats two
+    images must return each of them bit-identically wherever it sits in the batch (pixel tiles cross image boundaries at
+    other offsets for every copy: 32 different tile alignments per layer) -- and both against the rounding-aware oracle."""
+    from yolo_amd.net import CarNet
+    spec, size = og.spec_d53(), (608, 608)
+    g = og.build_graph(spec)
+    P = og.init_params(g, seed=0, bn='random')
+    two = np.random.default_rng(5).random((2, 3) + size, dtype=np.float32)
+    x = torch.from_numpy(two).to(cuda).repeat(32, 1, 1, 1)                 # a, b, a, b, ...
+    net = CarNet(spec, dtype='bf16', device=cuda, tune='measure').load_params(P)
+    outs = [o.clone() for o in net(x)]
+    assert len({op[1].algo for op in net._last_plan.ops if op[0] == 'conv'}) > 3
+    for o in outs:
+        assert o.shape[0] == 64 and bool(torch.isfinite(o).all())
+        assert bool((o[0::2] == o[0:1]).all()) and bool((o[1::2] == o[1:2]).all())
+        assert not bool((o[0] == o[1]).all())
+    ref = [r.numpy() for r in of.forward_torch(g, P, two)]
+    sim = [s_.numpy() for s_ in of.forward_torch_bf16sim(g, P, two)]
+    rms = lambda a: float(np.sqrt(np.mean(a * a)))
+    for o, s_, r in zip(outs, sim, ref):
+        got = o[:2].cpu().numpy()
+        e_hip, e_sim = rms(got - r) / r.std(), rms(s_ - r) / r.std()
+        assert e_hip < 1.5 * e_sim + 1e-3 and e_hip < 0.015, (e_hip, e_sim)
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_config1_bs32_measured_plan(cuda, dtype):
     """BASELINE configs[1] as bench.py runs it: D53 spec, 416x416, bs 32, per-layer kernel variants pinned by
