@@ -756,20 +756,46 @@ __global__ __launch_bounds__(64) void wgrad_strip_kernel(const uint16_t* __restr
     const int oy_end = min(oy_begin + rows_per_slice, Ho);
     if (oy_begin >= oy_end) return;
 
-    uint4 xr[XU], dr[DU];
-    auto load_x = [&](int iy0) {
+    // Staging registers: TWO sets.  A wave is alone on its SIMD (390 registers), so nothing but its own loads in flight hides
+    // the HBM latency: the rows of step k + 2 are requested at the top of step k and stored to LDS at the bottom of step k + 1
+    // (one set, i.e. a single step of ~0.25 us of MFMA work between request and use, left every step waiting ~1.5 us).
+    uint4 xr[2][XU], dr[2][DU];
+    // per-lane staging units, loop invariant: byte offset from the step's (wave-uniform) base and the row inside the step, or
+    // -1 for a unit that never loads (past the strip / the tensor's columns / the channel tail).  Loads are UNCONDITIONAL
+    // buffer loads: a unit that must read zeros gets an out-of-range offset and the hardware returns zeros.  (Predicated
+    // loads -- zero-initialise, branch, load -- cost ~20 instructions each and made the compiler wait for ALL outstanding
+    // loads before every zero-initialisation; reading a zero page instead makes 75 % of the stem's lanes hit one line: 2-6x slower.)
+    int x_off[XU], x_row[XU], d_off[DU], d_row[DU];
+#pragma unroll
+    for (int j = 0; j < XU; ++j) {
+        const int u = lane + j * 64;
+        const int r = u / (XW * 4), rem = u - r * (XW * 4), px = rem >> 2, part = rem & 3;
+        const int ix = ix0 + px;
+        x_row[j] = (r < NEW && ix >= 0 && ix < W && ci0 + part * 8 < Cin) ? r : -1;
+        x_off[j] = ((r * W + px) * Cin + part * 8) * 2;
+    }
+#pragma unroll
+    for (int j = 0; j < DU; ++j) {
+        const int u = lane + j * 64;
+        const int part = u % (CO_F * 4), px = (u / (CO_F * 4)) % TW, t = u / (CO_F * 4 * TW);
+        d_row[j] = (ox0 + px < Wo && co0 + part * 8 < Cout) ? t : -1;
+        d_off[j] = (int)(((long long)t * Wo + px) * dy_ps + part * 8) * 2;
+    }
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    auto load_x = [&](auto set_c, int iy0) {
+        constexpr int SET = decltype(set_c)::value;
+        const char* base = (const char*)x + ((((long long)n * H + iy0) * W + ix0) * Cin + ci0) * 2;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int j = 0; j < XU; ++j) {
-            const int u = lane + j * 64;
-            const int r = u / (XW * 4), rem = u - r * (XW * 4), px = rem >> 2, part = rem & 3;
-            const int iy = iy0 + r, ix = ix0 + px;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (r < NEW && iy >= 0 && iy < H && ix >= 0 && ix < W && ci0 + part * 8 < Cin)
-                v = *(const uint4*)(x + (((long long)n * H + iy) * W + ix) * Cin + ci0 + part * 8);
-            xr[j] = v;
+            const int iy = iy0 + x_row[j];
+            const bool ok = x_row[j] >= 0 && iy >= 0 && iy < H;
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? x_off[j] : -1, 0, 0);
+            xr[SET][j] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
-    auto store_x = [&](int slot0) {
+    auto store_x = [&](auto set_c, int slot0) {
+        constexpr int SET = decltype(set_c)::value;
 #pragma unroll
         for (int j = 0; j < XU; ++j) {
             const int u = lane + j * 64;
@@ -777,30 +803,32 @@ __global__ __launch_bounds__(64) void wgrad_strip_kernel(const uint16_t* __restr
             if (r < NEW) {
                 int slot = slot0 + r;
                 if (slot >= RING) slot -= RING;
-                *(uint4*)(xl + slot * XROW + px * XP + part * 16) = xr[j];
+                *(uint4*)(xl + slot * XROW + px * XP + part * 16) = xr[SET][j];
             }
         }
     };
-    auto load_dy = [&](int oy) {
+    auto load_dy = [&](auto set_c, int oy) {
+        constexpr int SET = decltype(set_c)::value;
+        const char* base = (const char*)dy + ((((long long)n * Ho + oy) * Wo + ox0) * dy_ps + co0) * 2;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < DU; ++j) {
+            const bool ok = d_row[j] >= 0 && oy + d_row[j] < oy_end;
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? d_off[j] : -1, 0, 0);
+            dr[SET][j] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+    };
+    auto store_dy = [&](auto set_c, int buf) {
+        constexpr int SET = decltype(set_c)::value;
 #pragma unroll
         for (int j = 0; j < DU; ++j) {
             const int u = lane + j * 64;
             const int part = u % (CO_F * 4), px = (u / (CO_F * 4)) % TW, t = u / (CO_F * 4 * TW);
-            const int o = oy + t, ox = ox0 + px;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (o < oy_end && ox < Wo && co0 + part * 8 < Cout)
-                v = *(const uint4*)(dy + (((long long)n * Ho + o) * Wo + ox) * dy_ps + co0 + part * 8);
-            dr[j] = v;
+            *(uint4*)(dyl + buf * DYB + (t * TW + px) * DP + part * 16) = dr[SET][j];
         }
     };
-    auto store_dy = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < DU; ++j) {
-            const int u = lane + j * 64;
-            const int part = u % (CO_F * 4), px = (u / (CO_F * 4)) % TW, t = u / (CO_F * 4 * TW);
-            *(uint4*)(dyl + buf * DYB + (t * TW + px) * DP + part * 16) = dr[j];
-        }
-    };
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
 
     f32x16 acc[CO_F][9];
 #pragma unroll
@@ -810,15 +838,19 @@ __global__ __launch_bounds__(64) void wgrad_strip_kernel(const uint16_t* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[cf][tp][r] = 0.f;
 
-    // prologue: the input rows the first TH output rows need, and their dy
+    // prologue: the input rows the first TH output rows need, and their dy; then the request for step 1 (set 1)
     const int iyb0 = oy_begin * S - 1;
 #pragma unroll
     for (int r0 = 0; r0 < INUSE; r0 += NEW) {
-        load_x(iyb0 + r0);
-        store_x(r0);
+        load_x(Set0{}, iyb0 + r0);
+        store_x(Set0{}, r0);
     }
-    load_dy(oy_begin);
-    store_dy(0);
+    load_dy(Set0{}, oy_begin);
+    store_dy(Set0{}, 0);
+    if (oy_begin + TH < oy_end) {
+        load_x(Set1{}, oy_begin * S - 1 + INUSE);
+        load_dy(Set1{}, oy_begin + TH);
+    }
     __syncthreads();
 
     const int g = lane >> 4, j16 = lane & 15;
@@ -826,11 +858,15 @@ __global__ __launch_bounds__(64) void wgrad_strip_kernel(const uint16_t* __restr
     const int a_off = frag_row * DP + frag_col2;
     const int b_off = frag_row * S * XP + frag_col2;
     int slot0 = 0, buf = 0;
-    for (int oy = oy_begin; oy < oy_end; oy += TH) {
-        const bool more = oy + TH < oy_end;
-        if (more) {
-            load_x(oy * S - 1 + INUSE);
-            load_dy(oy + TH);
+    // step k = output rows [oy, oy + TH); its parity selects the register set that is FREE at its top (step k's own rows were
+    // stored at the bottom of step k - 1) and receives step k + 2; the other set holds step k + 1 and is stored at the bottom
+    auto step = [&](auto par_c, int oy) {
+        constexpr int PAR = decltype(par_c)::value;
+        using Mine = std::integral_constant<int, PAR>;
+        using Other = std::integral_constant<int, PAR ^ 1>;
+        if (oy + 2 * TH < oy_end) {
+            load_x(Mine{}, (oy + TH) * S - 1 + INUSE);
+            load_dy(Mine{}, oy + 2 * TH);
         }
 #pragma unroll
         for (int t = 0; t < TH; ++t) {
@@ -866,16 +902,20 @@ __global__ __launch_bounds__(64) void wgrad_strip_kernel(const uint16_t* __restr
                     }
             }
         }
-        if (more) {
+        if (oy + TH < oy_end) {
             int ns = slot0 + INUSE;
             if (ns >= RING) ns -= RING;
-            store_x(ns);
-            store_dy(buf ^ 1);
+            store_x(Other{}, ns);
+            store_dy(Other{}, buf ^ 1);
         }
         slot0 += NEW;
         if (slot0 >= RING) slot0 -= RING;
         buf ^= 1;
         __syncthreads();
+    };
+    for (int oy = oy_begin; oy < oy_end; oy += 2 * TH) {
+        step(Set0{}, oy);
+        if (oy + TH < oy_end) step(Set1{}, oy + TH);
     }
 
     const int l31 = lane & 31, h = lane >> 5;
