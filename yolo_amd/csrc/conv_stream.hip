@@ -96,16 +96,29 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
     // (a two-step-ahead variant with two register sets was slower: it costs a wave of occupancy per SIMD, and
     // co-resident blocks hide more latency than the extra step does)
     uint4 xr[XU];
+    // per-thread staging units, loop invariant: byte offset from the step's (block-uniform) base and the row inside the step,
+    // or -1 for a unit that never loads.  The loads are unconditional range-checked buffer loads -- a unit that must read
+    // zeros gets an out-of-range offset -- instead of predicated ones (zero-initialise, exec branch, load: ~20 instructions
+    // each, and the compiler waits for every outstanding load before each zero-initialisation)
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    int x_off[XU], x_row[XU];
+#pragma unroll
+    for (int j = 0; j < XU; ++j) {
+        const int u = tid + j * 256;
+        const int r = u / (XW * PARTS), rem = u - r * (XW * PARTS), px = rem / PARTS, part = rem % PARTS;
+        const int ix = ix0 + px;
+        x_row[j] = (r < NEW && ix >= 0 && ix < W) ? r : -1;
+        x_off[j] = (r * W + px) * ROWB + part * 16;
+    }
     auto load_x = [&](int iy_first) {
+        const char* base = a.x + (((long long)n * H + iy_first) * W + ix0) * ROWB;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int j = 0; j < XU; ++j) {
-            const int u = tid + j * 256;
-            const int r = u / (XW * PARTS), rem = u - r * (XW * PARTS), px = rem / PARTS, part = rem % PARTS;
-            const int iy = iy_first + r, ix = ix0 + px;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (r < NEW && iy >= 0 && iy < H && ix >= 0 && ix < W)
-                v = *(const uint4*)(a.x + (((long long)n * H + iy) * W + ix) * ROWB + part * 16);
-            xr[j] = v;
+            const int iy = iy_first + x_row[j];
+            const bool ok = x_row[j] >= 0 && iy >= 0 && iy < H;
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? x_off[j] : -1, 0, 0);
+            xr[j] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
     auto store_x = [&](int slot_first) {

@@ -607,32 +607,44 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const uint16_t* __restr
     const long long c_first = (long long)blockIdx.z * chunks_per_slice;
     const long long c_last = min(c_first + chunks_per_slice, (P + WG_KC - 1) / WG_KC);
     uint4 dr[UA], xr[UB];
+    // Unconditional range-checked buffer loads: a unit that must read zeros (past the pixel range, channel tail, padding)
+    // gets an out-of-range offset.  (Predicated loads -- zero-initialise, exec branch, load -- cost the branch and make the
+    // compiler wait for every outstanding load before each zero-initialisation.)  dy: a per-chunk base + loop-invariant lane
+    // offsets; x: offsets from the tensor start (the host checks that it is < 4 GiB).
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    int d_off[UA];
+#pragma unroll
+    for (int j = 0; j < UA; ++j) {
+        const int u = tid + j * 256;
+        const int px = u / (BM / 8), part = u % (BM / 8);
+        d_off[j] = (co0 + part * 8 < Cout) ? (int)((px * dy_ps + part * 8) * 2) : -1;
+    }
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)0xffffffffu, 0x00020000);
     auto load_chunk = [&](long long c) {
+        const long long p0 = c * WG_KC;
+        const int left = (int)min((long long)WG_KC, P - p0);                 // live pixels of this chunk
+        const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + p0 * dy_ps + co0), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int j = 0; j < UA; ++j) {
             const int u = tid + j * 256;
-            const int px = u / (BM / 8), part = u % (BM / 8);
-            const long long p = c * WG_KC + px;
-            uint4 a = make_uint4(0, 0, 0, 0);
-            if (p < P && co0 + part * 8 < Cout) a = *(const uint4*)(dy + p * dy_ps + co0 + part * 8);
-            dr[j] = a;
+            const int px = u / (BM / 8);
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_d, px < left ? d_off[j] : -1, 0, 0);
+            dr[j] = make_uint4(v.x, v.y, v.z, v.w);
         }
 #pragma unroll
         for (int j = 0; j < UB; ++j) {
             const int u = tid + j * 256;
             const int px = u / (BN / 8), part = u % (BN / 8);
-            const long long p = c * WG_KC + px;
-            uint4 b = make_uint4(0, 0, 0, 0);
-            if (p < P && ci0 + part * 8 < Cin) {
-                // pixel -> (image, row, column) by multiply-shift (a 64-bit division here cost more than the MFMAs)
-                const int n = fdiv((int)p, d_howo);
-                const int rem = (int)p - n * Ho * Wo;
-                const int oy = fdiv(rem, d_wo), ox = rem - oy * Wo;
-                const int iy = oy * stride + kh - pad, ix = ox * stride + kw - pad;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-                    b = *(const uint4*)(x + (((long long)n * H + iy) * W + ix) * Cin + ci0 + part * 8);
-            }
-            xr[j] = b;
+            const int p = (int)p0 + px;
+            // pixel -> (image, row, column) by multiply-shift (a 64-bit division here cost more than the MFMAs)
+            const int n = fdiv(p, d_howo);
+            const int rem = p - n * Ho * Wo;
+            const int oy = fdiv(rem, d_wo), ox = rem - oy * Wo;
+            const int iy = oy * stride + kh - pad, ix = ox * stride + kw - pad;
+            const bool ok = px < left && ci0 + part * 8 < Cin && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const unsigned off = ((unsigned)((n * H + iy) * W + ix) * (unsigned)Cin + (unsigned)(ci0 + part * 8)) * 2u;
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (int)off : -1, 0, 0);
+            xr[j] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
     f32x16 acc[MI][NI];
@@ -1228,6 +1240,8 @@ extern "C" int yolo_conv_wgrad_algo(const void* dy, const void* x, float* dw_oih
         const uint16_t* x16 = (const uint16_t*)x;
         float* ws = (float*)workspace;
         // (256x128 / 128x256 / 256x256 tiles were measured 10-40 % slower: one wave per SIMD)
+        if ((long long)N * H * W * Cin * 2 >= 0xffffff00LL || (long long)N * Ho * Wo >= 0x7fffffffLL)
+            return YOLO_EUNSUPPORTED;                        // (32-bit buffer offsets into x)
         wgrad_bf16_launch<2, 2>(d16, x16, ws, N, H, W, Cin, Ho, Wo, Cout, ksize, stride, ps, st);
     }
     YOLO_LAUNCH(wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (float*)workspace,
