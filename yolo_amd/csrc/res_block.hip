@@ -125,16 +125,26 @@ __global__ __launch_bounds__(256) void res_block_kernel(ResArgs a) {
 
     // ---- input rows: registers -> ring slot (row mod 3) ------------------------------------------------------------
     uint4 xr[D][XU];                                        // register sets: rows oy+2 .. oy+D in flight (static indices only)
+    // unconditional range-checked buffer loads (a unit outside the image gets an out-of-range offset and reads zeros): a
+    // predicated load is a zero-initialisation + an exec branch, and the compiler waits for EVERY load in flight before each
+    // zero-initialisation -- which serialised the D register sets this kernel keeps in flight
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    int x_off[XU];
+#pragma unroll
+    for (int j = 0; j < XU; ++j) {
+        const int u = tid + j * 256;
+        const int px = u / (C * 2 / 16), part = u % (C * 2 / 16);
+        const int ix = mx0 + px;
+        x_off[j] = (ix >= 0 && ix < W) ? px * (C * 2) + part * 16 : -1;
+    }
     auto load_x = [&](uint4 (&r)[XU], int iy) {
+        const char* base = a.x + (((long long)n * H + iy) * W + mx0) * (C * 2);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+        const bool row_ok = iy >= 0 && iy < H;
 #pragma unroll
         for (int j = 0; j < XU; ++j) {
-            const int u = tid + j * 256;
-            const int px = u / (C * 2 / 16), part = u % (C * 2 / 16);
-            const int ix = mx0 + px;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-                v = *(const uint4*)(a.x + (((long long)n * H + iy) * W + ix) * (C * 2) + part * 16);
-            r[j] = v;
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, row_ok ? x_off[j] : -1, 0, 0);
+            r[j] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
     auto store_x = [&](const uint4 (&r)[XU], int slot) {
