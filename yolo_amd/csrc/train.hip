@@ -806,17 +806,22 @@ __global__ __launch_bounds__(64) void wgrad_strip_kernel(const uint16_t* __restr
             xr[SET][j] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
+    int s_row[XU], s_off[XU];                           // (row inside the step, byte offset inside the LDS row)
+#pragma unroll
+    for (int j = 0; j < XU; ++j) {
+        const int u = lane + j * 64;
+        const int r = u / (XW * 4), rem = u - r * (XW * 4);
+        s_row[j] = r;
+        s_off[j] = (rem >> 2) * XP + (rem & 3) * 16;
+    }
     auto store_x = [&](auto set_c, int slot0) {
         constexpr int SET = decltype(set_c)::value;
 #pragma unroll
         for (int j = 0; j < XU; ++j) {
-            const int u = lane + j * 64;
-            const int r = u / (XW * 4), rem = u - r * (XW * 4), px = rem >> 2, part = rem & 3;
-            if (r < NEW) {
-                int slot = slot0 + r;
-                if (slot >= RING) slot -= RING;
-                *(uint4*)(xl + slot * XROW + px * XP + part * 16) = xr[SET][j];
-            }
+            int slot = slot0 + s_row[j];
+            if (slot >= RING) slot -= RING;
+            // (only the last pass has lanes past the NEW rows: the others store without an exec branch)
+            if ((j + 1) * 64 <= NEW * XW * 4 || s_row[j] < NEW) *(uint4*)(xl + slot * XROW + s_off[j]) = xr[SET][j];
         }
     };
     auto load_dy = [&](auto set_c, int oy) {
