@@ -191,8 +191,7 @@ __global__ __launch_bounds__(256) void res_block_kernel(ResArgs a) {
     // rows oy0+2 .. oy0+D go into sets 0 .. D-2 (set of row r = (r - oy0 - 2) % D); step oy stores set (oy - oy0) % D and
     // re-loads the set the previous step stored
 #pragma unroll
-    for (int k = 0; k < D - 1; ++k)
-        if (oy0 + 2 + k <= oy1) load_x(xr[k], oy0 + 2 + k);
+    for (int k = 0; k < D - 1; ++k) load_x(xr[k], oy0 + 2 + k);   // (unconditional: see the step loop)
     __syncthreads();
     mid_row(oy0 - 1);
     mid_row(oy0);
@@ -205,7 +204,10 @@ __global__ __launch_bounds__(256) void res_block_kernel(ResArgs a) {
         const int oy = oyb + u;
         if (oy >= oy1) break;
         const bool more = oy + 1 < oy1;
-        if (oy + D + 1 <= oy1) load_x(xr[(u + D - 1) % D], oy + D + 1);     // D - 1 rows ahead of the row stored below
+        // D - 1 rows ahead of the row stored below.  UNCONDITIONAL (rows past the slice are read and dropped, rows past the
+        // image get out-of-range offsets): behind a uniform branch the compiler's s_waitcnt for the stores of the other sets
+        // must assume the no-load path, i.e. wait for every load in flight -- D sets then behave like one
+        load_x(xr[(u + D - 1) % D], oy + D + 1);
         mid_row(oy + 1);
         __syncthreads();
 

@@ -864,10 +864,11 @@ __global__ __launch_bounds__(64) void wgrad_strip_kernel(const uint16_t* __restr
     }
     load_dy(Set0{}, oy_begin);
     store_dy(Set0{}, 0);
-    if (oy_begin + TH < oy_end) {
-        load_x(Set1{}, oy_begin * S - 1 + INUSE);
-        load_dy(Set1{}, oy_begin + TH);
-    }
+    // (the requests are UNCONDITIONAL -- past the slice end dy gets out-of-range offsets, x rows that exist are read and
+    //  dropped: a uniform branch around them makes the compiler's s_waitcnt for the OTHER set's stores assume the no-load
+    //  path, i.e. wait for everything in flight, which turns two sets into one)
+    load_x(Set1{}, oy_begin * S - 1 + INUSE);
+    load_dy(Set1{}, oy_begin + TH);
     __syncthreads();
 
     const int g = lane >> 4, j16 = lane & 15;
@@ -881,10 +882,8 @@ __global__ __launch_bounds__(64) void wgrad_strip_kernel(const uint16_t* __restr
         constexpr int PAR = decltype(par_c)::value;
         using Mine = std::integral_constant<int, PAR>;
         using Other = std::integral_constant<int, PAR ^ 1>;
-        if (oy + 2 * TH < oy_end) {
-            load_x(Mine{}, (oy + TH) * S - 1 + INUSE);
-            load_dy(Mine{}, oy + 2 * TH);
-        }
+        load_x(Mine{}, (oy + TH) * S - 1 + INUSE);
+        load_dy(Mine{}, oy + 2 * TH);
 #pragma unroll
         for (int t = 0; t < TH; ++t) {
             int slot[3];
