@@ -15,6 +15,7 @@
 // Same operand order, accumulation order and rounding points as the two separate kernels: results are bit-identical.
 #include "common.h"
 #include <stdio.h>
+#include <type_traits>
 
 namespace {
 constexpr int C1 = 32, C2 = 64;
@@ -178,11 +179,18 @@ __global__ __launch_bounds__(256) void stem_down_kernel(Args a) {
 
     const int b_off = (wave_p * 32 + l31) * 2 * PITCH + h * 16;
     int slot0 = 0;
-    for (int oy = oy0; oy < oy1; ++oy) {
+    // image rows 2oy+5, 2oy+6 are used by step oy+1's stem rows and stored at the bottom of step oy; they are requested TWO
+    // steps ahead (top of step oy-1) into one of two register sets, unconditionally (clamped addresses: always readable) --
+    // a uniform branch around the request would make the compiler wait for every load in flight before the other set's store
+    float cimg[2][3];
+    bool okimg[2] = {false, false};
+    load_img(2 * oy0 + 5, 0, cimg[0], okimg[0]);
+    auto step = [&](auto par_c, int oy) {
+        constexpr int PAR = decltype(par_c)::value;
         const bool more = oy + 1 < oy1;
-        float c[3];
-        bool ok = false;
-        if (more) load_img(2 * oy + 5, 0, c, ok);          // image rows 2oy+5, 2oy+6: used by the NEXT step's stem rows
+        load_img(2 * oy + 7, 0, cimg[PAR ^ 1], okimg[PAR ^ 1]);
+        float (&c)[3] = cimg[PAR];
+        const bool ok = okimg[PAR];
         long long yo[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -241,6 +249,10 @@ __global__ __launch_bounds__(256) void stem_down_kernel(Args a) {
         slot0 += 2;
         if (slot0 >= RING) slot0 -= RING;
         __syncthreads();
+    };
+    for (int oy = oy0; oy < oy1; oy += 2) {
+        step(std::integral_constant<int, 0>{}, oy);
+        if (oy + 1 < oy1) step(std::integral_constant<int, 1>{}, oy + 1);
     }
 }
 
