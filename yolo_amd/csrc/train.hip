@@ -741,7 +741,12 @@ __global__ __launch_bounds__(64) void wgrad_strip_kernel(const uint16_t* __restr
                                                          int strips_w, int rows_per_slice, int pair_xcd) {
     constexpr int TW = 32;                          // output pixels per strip row = 2 MFMA K-steps
     constexpr int XW = (TW - 1) * S + 3;            // input pixels per staged row (with halo)
-    constexpr int XP = 64 + 16, DP = CO_F * 64 + 16;  // LDS pitches (bytes per pixel row, padded)
+    // LDS pitches (bytes per pixel row).  The fragments come from ds_read_b64_tr_b16: a 16-lane group reads 4 consecutive
+    // K rows x 32 bytes and the four groups rows r..r+3 / r+8..r+11 x two 32-byte halves, so a row stride of 64 bytes puts the
+    // 512 bytes of a read on every bank exactly twice (the minimum); the 80 the kernel started with made three rows share banks
+    // (PMC: a quarter of the wave cycles were LDS bank-conflict cycles).  Stride 2 reads every other pixel: 2 * 80 = 160 = 32 mod
+    // 128 spreads almost as well and keeps four blocks per CU.
+    constexpr int XP = (S == 1) ? 64 : 80, DP = CO_F * 64;
     constexpr int INUSE = (TH - 1) * S + 3, NEW = S * TH, RING = INUSE + NEW;
     constexpr int XROW = XW * XP, DYB = TH * TW * DP;
     constexpr int XU = (NEW * XW * 4 + 63) / 64, DU = TH * TW * CO_F * 4 / 64;
