@@ -315,7 +315,8 @@ int yolo_bn_train_bwd_partials(const float* partials, int rows, int cout_pad, co
  * dy (N,Ho,Wo,[dy_pixel_stride]) x (N,H,W,Cin), NHWC `dtype`.  The caller zero-fills dw once per step.
  * YOLO_F32: MFMA 32x32x2 f32.  YOLO_BF16: MFMA 32x32x16 bf16 fed by transposing LDS reads
  * (ds_read_b64_tr_b16), fp32 accumulation; needs `workspace` of yolo_conv_wgrad_workspace_bytes(), ZERO-FILLED by
- * the caller before its first use; every call leaves it zeroed again. */
+ * the caller before its first use; every call leaves it zeroed again.  bf16: x must be smaller than 4 GiB (32-bit
+ * buffer offsets; YOLO_EUNSUPPORTED otherwise). */
 long long yolo_conv_wgrad_workspace_bytes(int Cin, int Cout, int ksize, int dtype);
 int yolo_conv_wgrad(const void* dy, const void* x, float* dw_oihw, int N, int H, int W, int Cin, int Cout,
                     int ksize, int stride, long long dy_pixel_stride, int dtype, void* workspace,
