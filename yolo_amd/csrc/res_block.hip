@@ -25,6 +25,7 @@
 // Same packed weight images, operand rounding points (mid is rounded to bf16 once; the residual is added in fp32 before
 // the output's one rounding) and K order ((kh, kw, channel)) as conv_stream_kernel.
 #include "common.h"
+#include <stdlib.h>
 #include <stdio.h>
 
 namespace {
@@ -310,5 +311,10 @@ extern "C" int yolo_res_block_fwd(const void* x, const void* w1_packed, const fl
     a.wp2 = (const char*)w2_packed; a.scale2 = scale2; a.bias2 = bias2; a.y = (char*)y;
     a.N = N; a.H = H; a.W = W; a.slope = slope;
     a.Cpad1 = round_up(C / 2, YOLO_COUT_PAD); a.Cpad2 = round_up(C, YOLO_COUT_PAD);
-    return C == 64 ? launch_res_block<64, 3>(a, (hipStream_t)stream) : launch_res_block<128, 3>(a, (hipStream_t)stream);
+    static const int dknob = getenv("YOLO_RB_D") ? atoi(getenv("YOLO_RB_D")) : 0;          // (ablation knob: rows in flight)
+    hipStream_t st = (hipStream_t)stream;
+    if (dknob == 2) return C == 64 ? launch_res_block<64, 2>(a, st) : launch_res_block<128, 2>(a, st);
+    if (dknob == 4) return C == 64 ? launch_res_block<64, 4>(a, st) : launch_res_block<128, 4>(a, st);
+    if (dknob == 6) return C == 64 ? launch_res_block<64, 6>(a, st) : launch_res_block<128, 6>(a, st);
+    return C == 64 ? launch_res_block<64, 3>(a, st) : launch_res_block<128, 3>(a, st);
 }
