@@ -93,9 +93,10 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
     for (int e = 0; e < 8; ++e) ssum[e] = qsum[e] = 0.f;
 
     // ---- input staging (registers; loads run one step ahead) ----------------------------------------------------
-    // (a two-step-ahead variant with two register sets was slower: it costs a wave of occupancy per SIMD, and
-    // co-resident blocks hide more latency than the extra step does)
-    uint4 xr[XU];
+    // (two register sets, requested UNCONDITIONALLY two steps ahead: behind a uniform branch the compiler's s_waitcnt for the
+    // other set's stores covers the no-load path and waits for every load in flight -- which is what made the first
+    // two-set attempt of round 1 look slower than one set)
+    uint4 xr[2][XU];                                    // two sets: the rows of step k + 2 are requested at the top of step k
     // per-thread staging units, loop invariant: byte offset from the step's (block-uniform) base and the row inside the step,
     // or -1 for a unit that never loads.  The loads are unconditional range-checked buffer loads -- a unit that must read
     // zeros gets an out-of-range offset -- instead of predicated ones (zero-initialise, exec branch, load: ~20 instructions
@@ -110,7 +111,8 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
         x_row[j] = (r < NEW && ix >= 0 && ix < W) ? r : -1;
         x_off[j] = (r * W + px) * ROWB + part * 16;
     }
-    auto load_x = [&](int iy_first) {
+    auto load_x = [&](auto set_c, int iy_first) {
+        constexpr int SET = decltype(set_c)::value;
         const char* base = a.x + (((long long)n * H + iy_first) * W + ix0) * ROWB;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
@@ -118,10 +120,11 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
             const int iy = iy_first + x_row[j];
             const bool ok = x_row[j] >= 0 && iy >= 0 && iy < H;
             const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? x_off[j] : -1, 0, 0);
-            xr[j] = make_uint4(v.x, v.y, v.z, v.w);
+            xr[SET][j] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
-    auto store_x = [&](int slot_first) {
+    auto store_x = [&](auto set_c, int slot_first) {
+        constexpr int SET = decltype(set_c)::value;
 #pragma unroll
         for (int j = 0; j < XU; ++j) {
             const int u = tid + j * 256;
@@ -129,25 +132,33 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
             if (r < NEW) {
                 int slot = slot_first + r;
                 if (slot >= RING) slot -= RING;
-                *(uint4*)(xl + slot * XROW + px * PITCH + part * 16) = xr[j];
+                *(uint4*)(xl + slot * XROW + px * PITCH + part * 16) = xr[SET][j];
             }
         }
     };
 
     // prologue: the KS input rows of the first output row
     const int iyb0 = oy0 * S - PAD;
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
 #pragma unroll
     for (int r0 = 0; r0 < INUSE; r0 += NEW) {
-        load_x(iyb0 + r0);
-        store_x(r0);
+        load_x(Set0{}, iyb0 + r0);
+        store_x(Set0{}, r0);
     }
+    load_x(Set1{}, oy0 * S - PAD + INUSE);              // the rows step oy0 stores at its bottom
     __syncthreads();
 
     const int b_off = (wave_p * NI * 32 + l31) * S * PITCH + h * 16;
     int slot0 = 0;
-    for (int oy = oy0; oy < oy1; ++oy) {
+    // step k = output row oy; its parity names the set that is free at its top (it receives the rows of step k + 2); the
+    // other set holds the rows step k stores at its bottom
+    auto step = [&](auto par_c, int oy) {
+        constexpr int PAR = decltype(par_c)::value;
+        using Mine = std::integral_constant<int, PAR>;
+        using Other = std::integral_constant<int, PAR ^ 1>;
         const bool more = oy + 1 < oy1;
-        if (more) load_x(oy * S - PAD + INUSE);
+        load_x(Mine{}, (oy + 1) * S - PAD + INUSE);
         // residual prefetch (same addresses as this lane's stores)
         long long yo[NI][2];
         uint4 rv[NI][2];
@@ -235,11 +246,15 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
         if (more) {
             int ns = slot0 + INUSE;
             if (ns >= RING) ns -= RING;
-            store_x(ns);
+            store_x(Other{}, ns);
         }
         slot0 += NEW;
         if (slot0 >= RING) slot0 -= RING;
         __syncthreads();
+    };
+    for (int oy = oy0; oy < oy1; oy += 2) {
+        step(Set0{}, oy);
+        if (oy + 1 < oy1) step(Set1{}, oy + 1);
     }
     if constexpr (STATS) {
         // the 16 lanes that share a channel octet (erow0 = 0..15) combine through the wave's scratch: one partial row
