@@ -372,6 +372,12 @@ int yolo_loss_lp_fwd_bwd(const float* logits, const float* records, float* dlogi
  * (trainer.step(batch_size), car/YOLO.py:396). */
 int yolo_adam_step(float* w, const float* grad, float* m, float* v, long long n, int t, float lr,
                    float beta1, float beta2, float eps, float rescale, void* stream);
+/* The same update with rescale = 1 / *global_batch_dev read ON THE DEVICE: the batch_size of trainer.step(batch_size)
+ * (car/YOLO.py:396) as the SUM of the ranks' shard sizes, which the caller's gradient all-reduce delivers in a slot
+ * of the last bucket (yolo_amd/train.py) -- uneven shards (split_render_data, yolo_gluon.py:100-124) need no
+ * collective of their own and no host synchronisation. */
+int yolo_adam_step_dev(float* w, const float* grad, float* m, float* v, long long n, int t, float lr,
+                       float beta1, float beta2, float eps, const float* global_batch_dev, void* stream);
 
 #ifdef __cplusplus
 }

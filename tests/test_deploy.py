@@ -30,6 +30,7 @@ def test_symbol_json_round_trip_and_rejections(tmp_path):
     import json
     from oracle import graph as og
     from yolo_amd.spec import NetGraph, darknet53_spec
+    from yolo_amd import mxparams
     for spec in (darknet53_spec(), og.spec_micro(), og.spec_car_v1()):
         g = NetGraph(spec)
         sym = deploy.symbol_json(g)
@@ -46,6 +47,19 @@ def test_symbol_json_round_trip_and_rejections(tmp_path):
         # fine -> coarse: the first head's output conv sees the largest map (the fewest stride-2 convs upstream... the
         # deepest head is built first, so its reshape node comes first in the file and LAST in `heads`)
         assert sym['heads'][-1][0] < sym['heads'][0][0]
+    # CarLPNet (car_and_LP/YOLO.py:62-95, exported at :386): the LP branch is one more head -- transposed, not reshaped --
+    # and comes back as LP_slice_point
+    lp = dict(og.spec_micro(), LP_slice_point=[1, 3, 4, 7, 10])
+    g = NetGraph(lp)
+    sym = deploy.symbol_json(g)
+    assert len(sym['heads']) == 4 and sym['nodes'][sym['heads'][-1][0]]['op'] == 'transpose'
+    got = deploy.spec_from_symbol(sym)
+    assert got['LP_slice_point'] == [10] and got['layers'] == list(lp['layers']) and got['channels'] == list(lp['channels'])
+    assert sum(1 for n in sym['nodes'] if n['op'] == 'Convolution') == len(g.convs()) == len(NetGraph(og.spec_micro()).convs()) + 31
+    assert {n['name'] for n in sym['nodes'] if n['op'] == 'null'} - {'data'} == set(mxparams.gluon_param_names(g).values())
+    # the branch reads the INPUT of the finest detection block (the concat), not its output
+    lp_first = next(n for n in sym['nodes'] if n['op'] == 'Convolution' and 'yolodetectionblockv33_' in n['name'])
+    assert sym['nodes'][lp_first['inputs'][0][0]]['op'] == 'Concat'
     spec = og.spec_micro()
     sym = deploy.symbol_json(NetGraph(spec))
     old = copy.deepcopy(sym)
@@ -90,3 +104,41 @@ def test_export_and_init_executor(cuda, tmp_path):
         deploy.init_executor(str(tmp_path), other, size, device=cuda, step=3)
     with pytest.raises(ValueError):
         ex.forward(is_train=True, data=x)
+    # ... and against the ORACLE, not only against the net that wrote the files: the executor built from the two exported
+    # files alone evaluates the oracle's graph on the oracle's parameters (bf16: as good as the rounding-aware oracle)
+    from oracle import forward as of
+    g = og.build_graph(spec)
+    xs = x.cpu().numpy()
+    f32 = [r.numpy() for r in of.forward_torch(g, P, xs)]
+    sim = [r.numpy() for r in of.forward_torch_bf16sim(g, P, xs)]
+    rms = lambda a: float(np.sqrt(np.mean(a * a)))
+    for o, s_, r in zip(out2, sim, f32):
+        e_hip, e_sim = rms(o.cpu().numpy() - r) / r.std(), rms(s_ - r) / r.std()
+        assert e_hip < 1.5 * e_sim + 1e-3 and e_hip < 0.015, (e_hip, e_sim)
+    ex32 = deploy.init_executor(str(tmp_path), None, size, device=cuda, step=3, dtype='f32')
+    for o, r in zip(ex32.forward(is_train=False, data=x), f32):
+        np.testing.assert_allclose(o.cpu().numpy(), r, rtol=0, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_export_and_init_executor_carlpnet(cuda, tmp_path):
+    """car_and_LP/YOLO.py:386 exports CarLPNet; the executor built from export-symbol.json + .params ALONE must recover the
+    LP branch and return all_output[::-1] + [LP_output] -- against the oracle's CarLPNet forward."""
+    import torch
+    from oracle import graph as og, forward as of
+    from yolo_amd.net import CarLPNet
+    spec, size = dict(og.spec_micro(), LP_slice_point=[1, 3, 4, 7, 10]), (64, 96)
+    g = og.build_graph(spec)
+    P = og.init_params(g, seed=11, bn='random')
+    net = CarLPNet(spec, dtype='f32', device=cuda).load_params(P)
+    deploy.export(net, str(tmp_path), epoch=0)
+    ex = deploy.init_executor(str(tmp_path), None, size, device=cuda, dtype='f32')
+    assert type(ex.net).__name__ == 'CarLPNet'
+    x = np.random.default_rng(12).random((2, 3) + size, dtype=np.float32)
+    out = ex.forward(is_train=False, data=torch.from_numpy(x).to(cuda))
+    routs, rlp = of.forward_torch(g, P, x)
+    assert len(out) == 4 and tuple(out[3].shape) == tuple(rlp[0].shape) == (2, 8, 12, 10)
+    for o, r in zip(out, list(routs) + list(rlp)):
+        np.testing.assert_allclose(o.cpu().numpy(), r.numpy(), rtol=0, atol=1e-3)
+    with pytest.raises(ValueError):
+        deploy.init_executor(str(tmp_path), og.spec_micro(), size, device=cuda, dtype='f32')      # a spec without the branch

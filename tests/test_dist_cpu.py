@@ -77,9 +77,14 @@ def _bucket_worker(rank, world, port, q):
     offs, o = [], 0
     for s in sizes:
         offs.append(o); o += (s + 3) // 4 * 4
-    flat = torch.zeros(o)
+    # + the 16-byte slot behind the last parameter that carries the rank's shard size (yolo_amd/train.py): uneven shards of
+    # a global batch of 7 (3 + 4, yolo_gluon.py:118-119) must come back as 7 on every rank with the LAST bucket, no
+    # collective of their own
+    flat = torch.zeros(o + 4)
     for n, of, s in zip(names, offs, sizes):
         flat[of:of + s] = float(rank + 1) * (1 + names.index(n))
+    lo, hi = P.shard_bounds(7, rank, world)
+    flat[o] = float(hi - lo)
     b = P.GradBuckets(flat, names, offs, sizes, nbuckets=3)
     b.reset()
     # the backward reports parameters roughly from the end of the buffer to its start, not exactly in order
@@ -105,8 +110,8 @@ def test_bucketed_gradient_allreduce_two_ranks():
     for i, s in enumerate(sizes):
         pad = (s + 3) // 4 * 4
         expect += [3.0 * (1 + i)] * s + [0.0] * (pad - s)          # (1 + 2) * value: SUM over the two ranks
-    assert ranges[-1][1] == len(expect)
-    assert out[0][2] == out[1][2] == expect
+    assert ranges[-1][1] == len(expect) + 4                      # the last bucket owns the shard-size slot
+    assert out[0][2] == out[1][2] == expect + [7.0, 0.0, 0.0, 0.0]
 
 
 def test_bucket_ranges_cover_the_buffer():
@@ -150,3 +155,40 @@ def test_bench_refuses_fewer_gpus_than_asked():
 def test_bench_rejects_world_size_mismatch():
     r = _run_bench(['--gpus', '4', '--launch-check'], {'YOLO_BENCH_BACKEND': 'gloo', 'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
     assert r.returncode != 0 and 'WORLD_SIZE 1 != --gpus 4' in r.stderr
+
+
+def _save_worker(rank, world, port, q, path):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from yolo_amd.net import CarNet
+    import numpy as np
+
+    class FakeNet(object):                                       # (CarNet's own methods on a parameter dict: no GPU here)
+        params = {'c.weight': torch.full((2,), 5.0), 'c.running_mean': torch.full((3,), float(rank + 1))}
+    net = FakeNet()
+    avg = CarNet.averaged_params(net)                            # the collective: every rank
+    if rank == 0:
+        CarNet.save_state(net, path, avg)                        # rank 0 alone writes -- must not communicate
+        CarNet.save_state(net, path + '.local.npz')
+    dist.barrier()
+    q.put((rank, avg['c.running_mean'].tolist()))
+    dist.destroy_process_group()
+
+
+def test_rank0_only_save_does_not_deadlock(tmp_path):
+    """`if rank == 0: net.save_state(...)` is the common pattern: the file write must not hide a collective (the averaging of
+    the running statistics is the explicit, all-rank averaged_params())."""
+    import numpy as np
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    path = str(tmp_path / 'ck.npz')
+    ps = [ctx.Process(target=_save_worker, args=(r, world, port, q, path)) for r in range(world)]
+    [p.start() for p in ps]
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(timeout=60) for p in ps]
+    assert out[0][1] == out[1][1] == [1.5] * 3
+    with np.load(path) as z:
+        assert z['c.running_mean'].tolist() == [1.5] * 3 and z['c.weight'].tolist() == [5.0, 5.0]
+    with np.load(path + '.local.npz') as z:
+        assert z['c.running_mean'].tolist() == [1.0] * 3

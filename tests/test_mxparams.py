@@ -238,3 +238,27 @@ def test_gluon_order_with_lp_branch():
     P = _random_params(g, 2)
     back = mp.from_gluon(g, mp.to_gluon(g, P))
     assert all(np.array_equal(back[k], P[k]) for k in P)
+
+
+def test_legacy_flat_names_fall_back_to_forward_order():
+    """Files this package's first exporter wrote: `arg:conv%d_weight` / `aux:batchnorm%d_running_mean`, ONE counter over all
+    layers in forward order, no detection-block scopes.  They match the gluon name pattern but not a gluon CarNet's
+    structure: from_gluon(order='auto') must map them by position (forward order) instead of rejecting them."""
+    g = NetGraph(MICRO)
+    P = _random_params(g, 3)
+    legacy, ci, bi = {}, 0, 0
+    for c in mp.gluon_conv_order(g, 'forward'):
+        legacy['arg:conv%d_weight' % ci] = P[c.name + '.weight']
+        if c.bn:
+            legacy['arg:batchnorm%d_gamma' % bi] = P[c.name + '.gamma']
+            legacy['arg:batchnorm%d_beta' % bi] = P[c.name + '.beta']
+            legacy['aux:batchnorm%d_running_mean' % bi] = P[c.name + '.running_mean']
+            legacy['aux:batchnorm%d_running_var' % bi] = P[c.name + '.running_var']
+            bi += 1
+        else:
+            legacy['arg:conv%d_bias' % ci] = P[c.name + '.bias']
+        ci += 1
+    back = mp.from_gluon(g, legacy)
+    assert set(back) == set(P)
+    for k in P:
+        np.testing.assert_array_equal(back[k], P[k], err_msg=k)

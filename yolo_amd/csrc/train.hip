@@ -1438,6 +1438,33 @@ __global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g, 
     w[i] = w[i] - lr_t * mi / (sqrtf(vi) + eps);
 }
 
+// The same update with the rescale taken on the device: rescale = 1 / *global_batch_dev, a float the caller's gradient
+// exchange has just SUM-reduced over the ranks (each rank contributes its shard size in a slot of the last gradient
+// bucket) -- no collective of its own, no host read, and no per-rank decision whether to issue one.
+__global__ void adam_dev_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, long long n, float lr_t, float b1, float b2, float eps,
+                                const float* __restrict__ gb) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float rescale = 1.f / gb[0];
+    const float gr = g[i] * rescale;
+    const float mi = b1 * m[i] + (1.f - b1) * gr;
+    const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mi;
+    v[i] = vi;
+    w[i] = w[i] - lr_t * mi / (sqrtf(vi) + eps);
+}
+
+extern "C" int yolo_adam_step_dev(float* w, const float* grad, float* m, float* v, long long n, int t, float lr,
+                                  float beta1, float beta2, float eps, const float* global_batch_dev, void* stream) {
+    if (!w || !grad || !m || !v || !global_batch_dev || n <= 0 || t < 1) return YOLO_EINVAL;
+    const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
+    YOLO_LAUNCH(adam_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, grad, m, v, n,
+                lr_t, beta1, beta2, eps, global_batch_dev);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}
+
 extern "C" int yolo_adam_step(float* w, const float* grad, float* m, float* v, long long n, int t, float lr,
                               float beta1, float beta2, float eps, float rescale, void* stream) {
     if (!w || !grad || !m || !v || n <= 0 || t < 1) return YOLO_EINVAL;

@@ -75,9 +75,10 @@ def _conv2d_nodes(nodes, c, names, src):
 
 
 def symbol_json(graph, prefix='carnet0_'):
-    """The symbol graph HybridBlock.export writes for CarNet.hybrid_forward (car/utils.py:68-95), as a dict."""
-    if getattr(graph, 'lp_out', None) is not None:
-        raise NotImplementedError('symbol export of CarLPNet')
+    """The symbol graph HybridBlock.export writes for CarNet.hybrid_forward (car/utils.py:68-95) -- or, for a graph with
+    the licence-plate branch, CarLPNet.hybrid_forward (car_and_LP/YOLO.py:62-95; exported at car_and_LP/YOLO.py:386):
+    five detection blocks chained through their tips on the input of the finest car block, a biased 1x1 and a transpose
+    to NHWC, listed as one more head behind all_output[::-1] -- as a dict."""
     names = mxparams.gluon_param_names(graph, prefix)
     nodes = [{'op': 'null', 'name': 'data', 'inputs': []}]
     x = _conv2d_nodes(nodes, graph.stem, names, 0)
@@ -91,8 +92,17 @@ def symbol_json(graph, prefix='carnet0_'):
             x = len(nodes) - 1
         routes.append(x)
     routes = routes[-graph.num_pyramid:][::-1]
-    heads = []
+    heads, lp_head = [], None
     for i, (body, tip, outc, nA) in enumerate(graph.heads):
+        if getattr(graph, 'lp_out', None) is not None and i >= len(graph.heads) - 1:
+            t = x
+            for lbody, ltip in graph.lp_blocks:                   # `_, LP_output = self.LP_branch[k](...)`: the tip output
+                for c in list(lbody) + [ltip]:
+                    t = _conv2d_nodes(nodes, c, names, t)
+            t = _conv2d_nodes(nodes, graph.lp_out, names, t)
+            nodes.append({'op': 'transpose', 'name': 'transpose%d' % len(graph.heads), 'attrs': {'axes': '(0, 2, 3, 1)'},
+                          'inputs': [[t, 0, 0]]})
+            lp_head = len(nodes) - 1
         for c in body:
             x = _conv2d_nodes(nodes, c, names, x)
         route = x
@@ -111,7 +121,8 @@ def symbol_json(graph, prefix='carnet0_'):
                           'inputs': [[x, 0, 0], [routes[i + 1], 0, 0]]})
             x = len(nodes) - 1
     return {'nodes': nodes, 'arg_nodes': [i for i, n in enumerate(nodes) if n['op'] == 'null'],
-            'node_row_ptr': list(range(len(nodes) + 1)), 'heads': [[h, 0, 0] for h in heads[::-1]],     # all_output[::-1]
+            'node_row_ptr': list(range(len(nodes) + 1)),
+            'heads': [[h, 0, 0] for h in heads[::-1] + ([lp_head] if lp_head is not None else [])],     # all_output[::-1] (+ [LP_output])
             'attrs': {'mxnet_version': ['int', 10301]}}
 
 
@@ -127,7 +138,8 @@ def spec_from_symbol(sym):
     """Network structure from an exported symbol graph (a dict, or the path of export-symbol.json): the `layers` /
     `channels` of the spec, the number of pyramid scales, anchors per scale and values per anchor.  Anchor SIZES and the
     inner slice points are not part of the graph (the drivers read them from spec.yaml for the decode): `all_anchors`
-    comes back as ones and `slice_point` as [per_anchor].  The recovered graph is re-built and compared conv by conv
+    comes back as ones and `slice_point` as [per_anchor]; a head that is transposed but not reshaped is CarLPNet's
+    LP_output (car_and_LP/YOLO.py:79) and gives `LP_slice_point` = [its channels].  The recovered graph is re-built and compared conv by conv
     with the file; anything that is not the CarNet topology raises ValueError."""
     if not isinstance(sym, dict):
         with open(sym) as f:
@@ -180,14 +192,18 @@ def spec_from_symbol(sym):
     downs = [c for c in convs if c['stride'] == 2]
     channels = [convs[0]['cout']] + [c['cout'] for c in downs]
     layers = [adds.get(l + 1, 0) for l in range(len(downs))]
-    per_scale = []
+    per_scale, lp_c = [], None
     for h in sym['heads']:
         j = h[0]
-        shape = None
+        shape, transposed = None, False
         while nodes[j]['op'] != 'Convolution':
             if nodes[j]['op'] in ('Reshape', 'reshape'):
                 shape = _tuple(_attrs(nodes[j])['shape'].replace('-1', '0'))
+            transposed = transposed or nodes[j]['op'] == 'transpose'
             j = nodes[j]['inputs'][0][0]
+        if shape is None and transposed and lp_c is None and h is sym['heads'][-1]:
+            lp_c = chan[j]                                        # CarLPNet's [LP_output]: NHWC, no anchor axis
+            continue
         if shape is None or len(shape) != 4:
             raise ValueError('output %s is not reshaped to (B, HW, A, C)' % nodes[h[0]]['name'])
         per_scale.append((shape[2], shape[3]))
@@ -195,6 +211,8 @@ def spec_from_symbol(sym):
         raise ValueError('the scales disagree on the values per anchor')
     spec = {'layers': layers, 'channels': channels, 'slice_point': [per_scale[0][1]],
             'all_anchors': [[[1.0, 1.0]] * a for a, _ in per_scale]}
+    if lp_c is not None:
+        spec['LP_slice_point'] = [lp_c]
     from .spec import NetGraph
     g = NetGraph(spec)
     want = [(c.cin, c.cout, c.k, c.stride, bool(c.bn)) for c in mxparams.gluon_conv_order(g, 'forward')]
@@ -222,10 +240,11 @@ def init_executor(export_folder, spec, size, device='cuda:0', step=0, dtype='bf1
     sym_path = os.path.join(export_folder, 'export-symbol.json')
     if spec is None:
         spec = spec_from_symbol(sym_path)
-    elif os.path.exists(sym_path) and 'LP_slice_point' not in spec:
+    elif os.path.exists(sym_path):
         got = spec_from_symbol(sym_path)
-        if (list(got['layers']), list(got['channels']), got['slice_point'][-1], [len(a) for a in got['all_anchors']]) != \
-                (list(spec['layers']), list(spec['channels']), spec['slice_point'][-1], [len(a) for a in spec['all_anchors']]):
+        key = lambda sp: (list(sp['layers']), list(sp['channels']), sp['slice_point'][-1], [len(a) for a in sp['all_anchors']],
+                          sp['LP_slice_point'][-1] if 'LP_slice_point' in sp else None)
+        if key(got) != key(spec):
             raise ValueError('export-symbol.json describes another network than the spec: %s' % got)
     cls = CarLPNet if 'LP_slice_point' in spec else CarNet
     net = cls(spec, dtype=dtype, device=device, tune=tune)

@@ -96,6 +96,7 @@ SIGNATURES = {
     'yolo_assign_targets_lp': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
     'yolo_loss_lp_fwd_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(C.c_float), _f, _f, _vp]),
     'yolo_adam_step': (_i, [_vp, _vp, _vp, _vp, _ll, _i, _f, _f, _f, _f, _f, _vp]),
+    'yolo_adam_step_dev': (_i, [_vp, _vp, _vp, _vp, _ll, _i, _f, _f, _f, _f, _vp, _vp]),
 }
 
 _lib = None

@@ -274,6 +274,10 @@ def _from_gluon_by_name(graph, loaded):
         else:
             other.append(sc)
     block_scopes.sort()
+    if not block_scopes and graph.heads:
+        # flat conv%d / batchnorm%d names without a single detection-block scope: not a gluon CarNet's names (files this
+        # package's first exporter wrote: one counter over all layers in forward order) -> positional mapping
+        return None
     plain, biased = [], []
     # non-block scopes, the one with the most layers (the net's own: the backbone) first
     for sc in sorted(other, key=lambda sc_: (-len(scopes[sc_]['conv']), sc_)):
@@ -329,7 +333,8 @@ def from_gluon(graph, loaded, order='auto'):
         byname = _from_gluon_by_name(graph, loaded)
         if byname is not None:
             return byname
-        order = 'registration'
+        # flat gluon-looking names (no block scopes) are the legacy export of this package: forward order
+        order = 'forward' if loaded and all(_NAME_RE.match(n) for n in loaded) else 'registration'
     names = list(loaded.keys())
     convs = gluon_conv_order(graph, order)
     by_kind = {s: [] for s in _SUFFIX}

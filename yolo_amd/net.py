@@ -123,10 +123,18 @@ class CarNet(object):
     def collect_params(self):
         return self.params
 
-    def save_state(self, path):
+    def averaged_params(self):
+        """COLLECTIVE (every rank calls it): the parameter dict with `.running_mean` / `.running_var` averaged over the
+        ranks -- what gluon's Parameter._reduce() hands collect_params().save() (car/YOLO.py:549); the live statistics
+        stay local to a GPU (no SyncBN).  Hand the result to save_state / save_gluon_params, which never communicate:
+            params = net.averaged_params()            # all ranks
+            if rank == 0: net.save_state(path, params)"""
         from . import parallel
-        # (under torch.distributed every rank must call this: the running statistics are averaged over the ranks)
-        np.savez(path, **{k: v.detach().cpu().numpy() for k, v in parallel.checkpoint_params(self.params).items()})
+        return parallel.checkpoint_params(self.params)
+
+    def save_state(self, path, params=None):
+        """Writes `params` (averaged_params(), see there) or, by default, this rank's own parameters.  No collective."""
+        np.savez(path, **{k: v.detach().cpu().numpy() for k, v in (self.params if params is None else params).items()})
 
     def load_state(self, path):
         with np.load(path) as z:
@@ -139,9 +147,10 @@ class CarNet(object):
         from . import mxparams
         return self.load_params(mxparams.from_gluon(self.graph, mxparams.read_params(path), order))
 
-    def save_gluon_params(self, path, prefix='carnet0_'):
-        from . import mxparams, parallel
-        mxparams.write_params(path, mxparams.to_gluon(self.graph, parallel.checkpoint_params(self.params), prefix))
+    def save_gluon_params(self, path, prefix='carnet0_', params=None):
+        """`collect_params().save(path)` (car/YOLO.py:549).  params: averaged_params() under N > 1 (see there)."""
+        from . import mxparams
+        mxparams.write_params(path, mxparams.to_gluon(self.graph, self.params if params is None else params, prefix))
 
     # ---- one-off preparation: BN folding + weight packing (all on device, HIP kernels) ------------
     def prepare(self):
@@ -423,7 +432,11 @@ class CarNet(object):
     # ---- forward ------------------------------------------------------------------------------------
     def forward(self, x, training=False):
         if training:
-            raise NotImplementedError('training-mode forward is not built yet')
+            # `self.net(bx)` under autograd.record (car/YOLO.py:381): batch-statistics BatchNorm, everything backward()
+            # needs is kept.  Runs through the Trainer that owns the flat parameter buffers (built on first use with the
+            # reference's defaults; `Trainer(net, size, ...)` beforehand to choose the hyper-parameters).
+            tr = self.trainer((int(x.shape[2]), int(x.shape[3])))
+            return tr.forward(x)
         self._ensure_prepared()
         if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or not x.is_cuda:
             raise ValueError('expected a (B,3,H,W) float32 CUDA tensor')
@@ -455,6 +468,27 @@ class CarNet(object):
         return outs
 
     __call__ = forward
+
+    def trainer(self, size=None):
+        """The Trainer attached to this net (gluon.Trainer(net.collect_params(), 'adam', ...), car/YOLO.py:106); built with
+        the reference's defaults when none exists yet (or when the image size -- the anchor grid -- changed)."""
+        tr = getattr(self, '_trainer', None)
+        if tr is None or (size is not None and tuple(size) != tr.size):
+            if size is None:
+                raise L.YoloError('no Trainer is attached to this net yet: pass the image size')
+            from .train import Trainer
+            tr = Trainer(self, size)
+        return tr
+
+    def backward(self, grads, lp_grads=None):
+        """`.backward()` of a loss the caller computed on the training-mode logits (car/YOLO.py:392-394): grads = list of 3
+        d(loss)/d(logits) shaped like forward(x, training=True)'s outputs.  Gradients land in `self.grads()`; the update is
+        `self.trainer().step(batch_size)` (car/YOLO.py:396)."""
+        self.trainer().backward(grads, lp_grads=lp_grads)
+
+    def grads(self):
+        """name -> gradient tensor (views of the flat fp32 gradient buffer) after backward()."""
+        return self.trainer().grads()
 
     def _run_two_streams(self, plan, x, dt):
         """The launch list with the ops of plan.side on the side stream.  A run of side ops starts after everything

@@ -62,7 +62,10 @@ class Trainer(object):
         for s in sizes:
             offs.append(o)
             o += (s + 3) // 4 * 4
-        self.wflat = torch.zeros(o, dtype=torch.float32, device=self.dev)
+        # + one 16-byte slot behind the last parameter: the rank's shard size, SUM-reduced with the last gradient bucket
+        # (the batch_size of trainer.step(batch_size), car/YOLO.py:396, when the shards are uneven: yolo_gluon.py:100-124)
+        self.nparam = o
+        self.wflat = torch.zeros(o + 4, dtype=torch.float32, device=self.dev)
         self.gflat = torch.zeros_like(self.wflat)
         self.mflat = torch.zeros_like(self.wflat)
         self.vflat = torch.zeros_like(self.wflat)
@@ -73,7 +76,9 @@ class Trainer(object):
             net.params[n] = self.wflat[of:of + s].view(shp)
             self.pview[n] = net.params[n]
             self.gview[n] = self.gflat[of:of + s].view(shp)
+        self._gb_slot = self.gflat[o:o + 1]
         self.buckets = parallel.GradBuckets(self.gflat, names, offs, sizes, nbuckets=4)
+        net._trainer = self                     # CarNet.forward(x, training=True) / CarNet.backward(grads) run through it
         # the parameters moved into the flat buffer: the net's launch plans hold pointers to the old tensors (stem
         # weights), and its folded / packed images are re-made on the next inference forward (net._version)
         net._plans = {}
@@ -83,7 +88,7 @@ class Trainer(object):
         self._plans = {}
         self._dgrad_algo = {}
         self._wgrad_algo = {}
-        self._gb_cache = {}
+        self._fwd_B = None
         cmax = max(c.cout for c in g.convs())
         # two BatchNorm workspaces used alternately (yolo_bn_train_*_pp: a call leaves its own dirty and zeroes the next one's)
         self.ws2 = [torch.zeros(2 * cmax, dtype=torch.float64, device=self.dev) for _ in range(2)]
@@ -468,6 +473,10 @@ class Trainer(object):
             best, best_t = 0, float('inf')
             if len(cands) > 1:
                 lib, st = self.lib, L.stream_ptr()
+                # the candidates run on THIS stream with the workspace the side stream's weight gradients share (their
+                # finishing passes accumulate into it and zero it): nothing of the side stream may be in flight
+                main = torch.cuda.current_stream()
+                main.wait_stream(self._side)
                 scratch = torch.zeros((c.cout, Cx, c.k, c.k), dtype=torch.float32, device=self.dev)
                 call = lambda a: lib.yolo_conv_wgrad_algo(L.ptr(dy), L.ptr(xin.val), L.ptr(scratch), N, Hh, Ww, Cx, c.cout, c.k,
                                                           c.stride, 0, self.ldt, L.ptr(self.wg_ws), a, st)
@@ -483,6 +492,7 @@ class Trainer(object):
                     t = e0.elapsed_time(e1)
                     if t < best_t * 0.98:                       # (a later candidate must win by 2 %)
                         best, best_t = a, t
+                self._side.wait_stream(main)
             self._wgrad_algo[key] = best
         return self._wgrad_algo[key]
 
@@ -494,6 +504,11 @@ class Trainer(object):
         flt = os.environ.get('YOLO_SIDE_FILTER')                  # (diagnostics: exactly these classes go to the side stream)
         side = (tag in flt.split(',')) if flt is not None else True
         if not self._overlap or not side:
+            if self._overlap:
+                # (mixed main / side launches: earlier side-stream weight gradients use the same workspace, and a bucket
+                #  these names complete may hold gradients the side stream is still writing)
+                self._flush_wgrad()
+                main.wait_stream(self._side)
             launch(main.cuda_stream)
             self.buckets.done(names)
             return
@@ -525,6 +540,7 @@ class Trainer(object):
         lib, st = self.lib, L.stream_ptr()
         g = self.net.graph
         self.gflat.zero_()
+        self._gb_slot.fill_(float(P.merged.shape[0]))               # this rank's shard size (see __init__)
         self.buckets.reset(enabled=exchange)
         self._pending_wgrad = None
         self._P = P
@@ -614,12 +630,14 @@ class Trainer(object):
         if self._overlap:
             torch.cuda.current_stream().wait_stream(self._side)
 
-    # ---- one training step -----------------------------------------------------------------------------------
-    def train_step(self, images, labels, global_batch=None, update=True, lp_labels=None, capture=None):
-        """images (B,3,H,W) float32 CUDA; labels (B,nobj,6+ncls) float32 CUDA [cls,y,x,h,w,rot,dist...],
-        cls < 0 = no object.  Returns losses (5,B) [score, box_yx, box_hw, rotate, class] (device)."""
-        lib, st = self.lib, L.stream_ptr()
-        images, labels = images.contiguous(), labels.to(self.dev, torch.float32).contiguous()
+    # ---- the reference's three calls: net(x) under autograd.record / loss.backward() / trainer.step(batch_size) -----
+    def forward(self, images):
+        """`self.net(bx)` in train mode (car/YOLO.py:381): (B,3,H,W) float32 NCHW -> list of 3 fp32 (B, HiWi, A, C) logits
+        fine -> coarse with batch-statistics BatchNorm (running statistics updated); CarLPNet: (outs, [LP_output]).  The
+        tensors are views of one buffer that the next forward of the same batch size overwrites."""
+        if images.dim() != 4 or images.shape[1] != 3 or images.dtype != torch.float32 or not images.is_cuda:
+            raise ValueError('expected a (B,3,H,W) float32 CUDA tensor')
+        images = images.contiguous()
         B, _, H, W = images.shape
         if (H, W) != self.size:
             raise ValueError('image size differs from the anchor grid the trainer was built for')
@@ -632,6 +650,83 @@ class Trainer(object):
                 raise L.YoloError('a parameter tensor of the net was replaced after the Trainer was built')
             self._repack()
         self._forward(P, images)
+        self._fwd_B = B
+        self._last = (P,)
+        # the running statistics moved: an inference forward of the same net (the reference's _valid_iou every
+        # valid_step, car/YOLO.py:501-534) must re-fold
+        self.net._version += 1
+        self._packed_version = self.net._version
+        return self._outs(P)
+
+    def _outs(self, P):
+        g = self.net.graph
+        hw = [op['hw'] for op in P.fwd if op['kind'] == 'out' and op['c'] is not g.lp_out][::-1]
+        outs, o = [], 0
+        for n in hw:
+            outs.append(P.merged[:, o:o + n].view(P.merged.shape[0], n, P.A, g.per_anchor))
+            o += n
+        if g.lp_out is not None:
+            return outs, [P.lp.view(P.lp.shape[0], P.lp_hw[0], P.lp_hw[1], g.lp_out.cout)]
+        return outs
+
+    def backward(self, grads, lp_grads=None, exchange=True, capture=None):
+        """`sum(losses).backward()` (car/YOLO.py:394) for a loss the CALLER computed on forward()'s logits: grads = the list
+        of 3 d(loss)/d(logits) tensors, shaped like forward()'s outputs (or ONE merged (B, sum HiWi, A, C) tensor);
+        CarLPNet: lp_grads = d(loss)/d(LP_output).  Fills grads() and -- with a process group -- starts the bucketed
+        SUM all-reduce of the gradient buffer (exchange=False: local gradients only)."""
+        if self._fwd_B is None:
+            raise L.YoloError('backward() without a training-mode forward()')
+        P = self._plans[self._fwd_B]
+        B = P.merged.shape[0]
+        if isinstance(grads, torch.Tensor):
+            P.dmerged.copy_(grads.reshape(B, P.tot, P.AC))
+        else:
+            o = 0
+            for gr in grads:
+                n = gr.shape[1]
+                P.dmerged[:, o:o + n].copy_(gr.reshape(B, n, P.AC))
+                o += n
+            if o != P.tot:
+                raise ValueError('the gradients do not cover the %d cells of the three scales' % P.tot)
+        if P.dlp is not None:
+            if lp_grads is None:
+                raise ValueError('a CarLPNet backward needs lp_grads')
+            lg = lp_grads[0] if isinstance(lp_grads, (list, tuple)) else lp_grads
+            P.dlp.copy_(lg.reshape(P.dlp.shape))
+        self._backward(P, exchange=exchange, capture=capture)
+
+    def step(self, batch_size=None):
+        """`trainer.step(batch_size)` (car/YOLO.py:396): joins the gradient exchange, rescales by 1/batch_size and applies
+        the MXNet Adam update on every rank.  batch_size=None: the SUM of the ranks' shard sizes of the last backward,
+        taken from the slot the exchange itself reduced (no collective of its own, no host read)."""
+        lib, st = self.lib, L.stream_ptr()
+        self.buckets.wait()                                    # KVStore sum-reduce of trainer.step (RCCL), bucketed
+        self.t += 1
+        n = self.nparam
+        if batch_size is None:
+            if self.buckets.active():
+                L.check(lib.yolo_adam_step_dev(L.ptr(self.wflat), L.ptr(self.gflat), L.ptr(self.mflat), L.ptr(self.vflat), n,
+                                               self.t, self.lr, self.b1, self.b2, self.eps, L.ptr(self._gb_slot), st), 'adam')
+                batch_size = 0
+            else:
+                batch_size = self._fwd_B
+        if batch_size:
+            L.check(lib.yolo_adam_step(L.ptr(self.wflat), L.ptr(self.gflat), L.ptr(self.mflat), L.ptr(self.vflat), n,
+                                       self.t, self.lr, self.b1, self.b2, self.eps, 1.0 / batch_size, st), 'adam')
+        self._repack()
+        self.net._version += 1
+        self._packed_version = self.net._version
+
+    # ---- one training step -----------------------------------------------------------------------------------
+    def train_step(self, images, labels, global_batch=None, update=True, lp_labels=None, capture=None):
+        """_train_batch (car/YOLO.py:350-399) with the reference's own targets and losses on the device.
+        images (B,3,H,W) float32 CUDA; labels (B,nobj,6+ncls) float32 CUDA [cls,y,x,h,w,rot,dist...],
+        cls < 0 = no object.  Returns losses (5,B) [score, box_yx, box_hw, rotate, class] (device)."""
+        lib, st = self.lib, L.stream_ptr()
+        labels = labels.to(self.dev, torch.float32).contiguous()
+        self.forward(images)
+        P = self._plans[self._fwd_B]
+        B, _, H, W = images.shape
         nobj, ncls = labels.shape[1], labels.shape[2] - 6
         C_ = self.net.graph.per_anchor
         rec = torch.empty((B, nobj, 7 + ncls), dtype=torch.float32, device=self.dev)
@@ -665,22 +760,7 @@ class Trainer(object):
             self._last = (P, rec, lrec)
         self._backward(P, exchange=update, capture=capture)
         if update:
-            self.buckets.wait()                                    # KVStore sum-reduce of trainer.step (RCCL), bucketed
-            if global_batch is None:
-                # trainer.step(batch_size): the SUM of the ranks' shard sizes (uneven shards allowed); the shards of a
-                # run are static, so the all-reduce + host read happens once per local batch size
-                if B not in self._gb_cache:
-                    self._gb_cache[B] = parallel.global_batch_size(B, self.dev)
-                global_batch = self._gb_cache[B]
-            gb = global_batch
-            self.t += 1
-            L.check(lib.yolo_adam_step(L.ptr(self.wflat), L.ptr(self.gflat), L.ptr(self.mflat), L.ptr(self.vflat),
-                                       self.wflat.numel(), self.t, self.lr, self.b1, self.b2, self.eps, 1.0 / gb, st), 'adam')
-            self._repack()
-        # the running statistics moved in every step (and the weights when update): an inference forward of the same net
-        # (the reference's _valid_iou every valid_step, car/YOLO.py:501-534) must re-fold and re-pack
-        self.net._version += 1
-        self._packed_version = self.net._version
+            self.step(global_batch)
         return losses
 
     def grads(self):
