@@ -203,7 +203,7 @@ def bench_train(args, spec, size, B, rank, world, dev, dist):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 def _free_port():
@@ -245,7 +245,18 @@ def launch_check(backend, rank, world, local):
     else:
         out = {'launch_check': True, 'n_gpus': 1, 'world': 1, 'max': 1.0, 'ranks': [0], 'backend': None}
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
+
+
+def emit(out):
+    """The ONE JSON line, as the LAST line of stdout: RCCL writes its version banner through C stdio, which sits in libc's
+    buffer until exit when stdout is a pipe or a file -- flush it out first."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
 
 
 def timed_pass(net, det, x, post, steps, warmup, fence):
@@ -461,7 +472,7 @@ def main():
             if rank == 0:
                 out['train_416_bs64'] = {'error': 'the training pass did not finish within %.0f s (watchdog)' % args.train_timeout,
                                          'n_gpus': world}
-                print(json.dumps(out), flush=True)
+                emit(out)
             os._exit(0)
 
         dog = threading.Timer(args.train_timeout, give_up) if world > 1 else None
@@ -478,7 +489,7 @@ def main():
             out['train_416_bs64'] = {'error': '%s: %s' % (type(e).__name__, e), 'n_gpus': world}
             if world > 1:
                 if rank == 0:
-                    print(json.dumps(out), flush=True)
+                    emit(out)
                 os._exit(0)
         finally:
             if dog is not None:
@@ -489,7 +500,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 if __name__ == '__main__':
