@@ -204,8 +204,8 @@ def test_d53_train_step_bf16_one_hop(cuda):
 def test_d53_train_bs64_bf16_replicated_batch(cuda):
     """BASELINE configs[2] at its own size (bs 64, bf16, measured kernel variants).  The oracle cannot run 64 images
     (70 GB of autograd state), so the batch is 32 copies of a 2-image batch: batch statistics over the copies equal the
-    2-image statistics, hence every copy's losses must equal the oracle's B=2 losses, all copies must agree, and the
-    summed gradient is 32x the 2-image one.  Then the loss must fall over 10 updates."""
+    2-image statistics, hence every copy's losses must equal the oracle's B=2 losses and all copies must agree.  Then the
+    loss must fall over 10 updates."""
     spec, g, P, x2, lab2, net, tr = _d53(cuda, 'bf16', 2, tune='measure')
     x = torch.from_numpy(np.tile(x2, (32, 1, 1, 1))).to(cuda)
     lab = torch.from_numpy(np.tile(lab2, (32, 1, 1))).to(cuda)
@@ -217,37 +217,143 @@ def test_d53_train_bs64_bf16_replicated_batch(cuda):
     np.testing.assert_allclose(L[:, :2], np.stack(rl), rtol=5e-2, atol=5e-3)
     for k in range(1, 32):
         np.testing.assert_allclose(L[:, 2 * k:2 * k + 2], L[:, :2], rtol=1e-5, atol=1e-7)
-    g64 = {n: v.clone() for n, v in tr.grads().items()}
-    # 32x the gradient of the plain 2-image step of the same trainer.  The two runs use different tile variants (fp32
-    # accumulation order), so a few stored bf16 activations differ by one ulp; BatchNorm's backward projects the
-    # dominant, spatially constant part of the loss gradient out (the objectness term pushes every box the same way),
-    # which makes what is left ill-conditioned: measured (tools/rep_batch_diag.py) the output layers agree to
-    # cos 0.985-1.0 and everything behind the first BatchNorm backward decorrelates to cos ~0.6 -- in fp32 the same comparison
-    # gives cos 0.9999 everywhere, and the one-hop tests above hold every operator to its bar.  So: tight where the
-    # gradient has not passed a BatchNorm yet, direction and size elsewhere.
-    tr.train_step(x[:2], lab[:2], update=False)
-    cos, ratio = {}, {}
-    for n, a in g64.items():
-        b = tr.grads()[n].double().flatten() * 32
-        a = a.double().flatten()
-        cos[n] = float(a @ b / (a.norm() * b.norm() + 1e-30))
-        ratio[n] = float(a.norm() / (b.norm() + 1e-30))
-    # (the bars are per tuner outcome, i.e. per box: tools/rep_batch_diag.py measured heads.1.out.weight -- the scale that owns
-    #  the labelled cells, whose class-loss gradient follows the one logit row that differs most between the two runs: 0.66
-    #  of a 4.9 range after 75 bf16 layers -- at cos 0.990 / ratio 0.89 with one set of measured variants, 0.968 / 0.87 with
-    #  another and 0.951 / 1.35 with the heuristic ones, the other two scales at cos > 0.998 / ratio 1.00 every time.  A lost
-    #  half batch or a wrong 1/B would show as ratio 0.5 or 32.)
-    near = [n for n in cos if '.out.' in n]
-    bad = {n: (round(cos[n], 4), round(ratio[n], 4)) for n in near if not (cos[n] > 0.92 and 0.7 < ratio[n] < 1.45)}
-    assert not bad, bad
-    tight = [n for n in near if cos[n] > 0.995 and 0.97 < ratio[n] < 1.03]
-    assert len(tight) >= len(near) // 2, {n: (round(cos[n], 4), round(ratio[n], 4)) for n in near}
-    assert np.median(list(cos.values())) > 0.5 and min(cos.values()) > 0.2, (np.median(list(cos.values())), min(cos.values()))
-    assert 0.55 < np.median(list(ratio.values())) < 1.8          # (0.91 with measured variants, 1.49 with the heuristic ones)
+    # (the gradients of this configuration are held one hop at a time, on the device, by
+    #  test_d53_train_bs64_bf16_device_one_hop below -- the loose whole-step cosine bars this test used to carry are gone)
     first = float(tr.train_step(x, lab).sum())
     for _ in range(9):
         last = float(tr.train_step(x, lab).sum())
     assert np.isfinite(last) and last < first, (first, last)
+
+
+def _taps_conv(x, w, stride):
+    """Raw convolution (pad k//2) of NHWC fp32 x (N,H,W,Cin) with OIHW fp32 w as one fp32 matmul per tap (rocBLAS; no MIOpen)."""
+    N, H, W, Cin = x.shape
+    Cout, _, k, _ = w.shape
+    p = k // 2
+    Ho, Wo = (H + 2 * p - k) // stride + 1, (W + 2 * p - k) // stride + 1
+    xp = torch.nn.functional.pad(x, (0, 0, p, p, p, p))
+    y = torch.zeros((N * Ho * Wo, Cout), dtype=torch.float32, device=x.device)
+    for kh in range(k):
+        for kw in range(k):
+            xs = xp[:, kh:kh + (Ho - 1) * stride + 1:stride, kw:kw + (Wo - 1) * stride + 1:stride, :].reshape(-1, Cin)
+            y += xs @ w[:, :, kh, kw].t()
+    return y.view(N, Ho, Wo, Cout)
+
+
+def _taps_dgrad(dy, w, stride, H, W):
+    """d/dx of the same convolution: scatter of dy @ w[:, :, kh, kw] per tap into the padded input grid."""
+    N, Ho, Wo, Cout = dy.shape
+    _, Cin, k, _ = w.shape
+    p = k // 2
+    dxp = torch.zeros((N, H + 2 * p, W + 2 * p, Cin), dtype=torch.float32, device=dy.device)
+    d2 = dy.reshape(-1, Cout)
+    for kh in range(k):
+        for kw in range(k):
+            dxp[:, kh:kh + (Ho - 1) * stride + 1:stride, kw:kw + (Wo - 1) * stride + 1:stride, :] += (d2 @ w[:, :, kh, kw]).view(N, Ho, Wo, Cin)
+    return dxp[:, p:p + H, p:p + W, :]
+
+
+def _taps_wgrad(x, dy, k, stride):
+    N, H, W, Cin = x.shape
+    _, Ho, Wo, Cout = dy.shape
+    p = k // 2
+    xp = torch.nn.functional.pad(x, (0, 0, p, p, p, p))
+    dw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=x.device)
+    d2 = dy.reshape(-1, Cout)
+    for kh in range(k):
+        for kw in range(k):
+            xs = xp[:, kh:kh + (Ho - 1) * stride + 1:stride, kw:kw + (Wo - 1) * stride + 1:stride, :].reshape(-1, Cin)
+            dw[:, :, kh, kw] = d2.t() @ xs
+    return dw
+
+
+def test_d53_train_bs64_bf16_device_one_hop(cuda):
+    """BASELINE configs[2] at its own size and arithmetic -- bs 64, bf16, measured kernel variants, 64 DIFFERENT images, half
+    of them without an object -- held one hop at a time ON THE DEVICE (the CPU oracle cannot hold 64 images): for a spread of
+    layers that covers every kernel family at its full-size launch (the fused-statistics forward convolutions, the split-pixel
+    atomics of the strip / row-walk / per-tap / GEMM weight gradients, the sub-pixel stride-2 data gradient, the channel-group
+    BatchNorm reductions) the raw convolution, BatchNorm forward + backward, the weight gradient and the data gradient are
+    re-derived with plain fp32 torch-ROCm matmuls from the operands the kernels themselves read.  Same bars as the B=4
+    one-hop test: 2.5 bf16 ulps of the largest element for stored activations, 2e-3 for fp32 weight gradients."""
+    from yolo_amd.spec import LEAKY_SLOPE
+    spec, g, P, _, _, net, tr = _d53(cuda, 'bf16', 2, tune='measure')
+    B = 64
+    x = torch.rand((B, 3) + SIZE, generator=torch.Generator().manual_seed(11)).to(cuda)
+    lab = torch.from_numpy(ot.synthetic_labels(B, seed=5, render_rate=0.5, num_class=24)).to(cuda)
+    tr.train_step(x, lab, update=False)                                        # (measures the variants at this batch size)
+    net.load_params(P)
+    cap = {}
+    losses = tr.train_step(x, lab, update=False, capture=cap)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(losses).all())
+    plan = tr._last[0]
+    ops = {op['c'].name: op for op in plan.fwd if op['kind'] == 'conv_bn'}
+    rb = lambda t: t.to(torch.bfloat16).float()
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+    tol, tol_w = 2e-2, 2e-3
+    layers = ['stem', 'stages.0.down', 'stages.0.res.0.c1', 'stages.0.res.0.c2', 'stages.1.down', 'stages.1.res.1.c2',
+              'stages.2.down', 'stages.2.res.0.c1', 'stages.2.res.0.c2', 'stages.3.res.7.c2', 'stages.4.res.3.c2',
+              'heads.0.b1', 'heads.0.b2', 'heads.1.b3', 'heads.2.b0', 'heads.2.tip', 'transitions.1']
+    worst = {}
+
+    def note(kind, name, err, bar):
+        worst[kind] = max(worst.get(kind, (0, '')), (err, name))
+        assert err < bar, '%s %s: relative error %.3g (bar %.1g)' % (kind, name, err, bar)
+
+    grads = tr.grads()
+    for name in layers:
+        op = ops[name]
+        c = op['c']
+        w = rb(net.params[name + '.weight'].detach().float())
+        xin = op['x'].val.float()[..., :c.cin]
+        yraw = op['yraw'].val.float()
+        # forward: raw convolution of the saved input; BatchNorm + LeakyReLU (+ residual) of the saved raw output
+        note('conv fwd', name, rel(yraw, rb(_taps_conv(xin, w, c.stride))), tol)
+        gam, bet = net.params[name + '.gamma'].float(), net.params[name + '.beta'].float()
+        n = yraw.shape[0] * yraw.shape[1] * yraw.shape[2]
+        mean = yraw.double().mean(dim=(0, 1, 2))
+        var = (yraw.double() - mean).pow(2).mean(dim=(0, 1, 2))
+        assert rel(op['mean'], mean.float()) < 1e-4 and rel(op['invstd'], (1.0 / torch.sqrt(var + 1e-5)).float()) < 1e-4
+        xh = (yraw - op['mean']) * op['invstd']
+        a = gam * xh + bet
+        z = torch.where(a > 0, a, a * LEAKY_SLOPE)
+        if op['res'] is not None:
+            z = z + op['res'].val.float()
+        note('bn fwd', name, rel(op['z'].val.float(), rb(z)), tol)
+        # backward: dy, dgamma, dbeta from the captured dz
+        dz, dy = cap[name]['dz'].float(), cap[name]['dy'].float()
+        assert bool(torch.isfinite(dy).all())
+        da = dz * torch.where(a > 0, 1.0, LEAKY_SLOPE)
+        s1, s2 = da.double().sum(dim=(0, 1, 2)), (da * xh).double().sum(dim=(0, 1, 2))
+        ref = gam * op['invstd'] * (da - (s1 / n).float() - xh * (s2 / n).float())
+        off = ((dy - rb(ref)).abs() > tol * ref.abs().max()) & (a.abs() > 1e-3)          # (near the kink either branch is right)
+        assert not bool(off.any()), 'bn bwd dy %s: %d elements off, %d of them exact zeros' % (name, int(off.sum()), int((dy[off] == 0).sum()))
+        note('dgamma', name, rel(grads[name + '.gamma'], s2.float()), tol_w)
+        note('dbeta', name, rel(grads[name + '.beta'], s1.float()), tol_w)
+        # weight gradient of the convolution from the dy the kernel read (fp32 accumulation of the bf16 operands)
+        note('wgrad', name, rel(grads[name + '.weight'], _taps_wgrad(xin, dy, c.k, c.stride)), tol_w)
+        del xin, yraw, xh, a, z, dz, dy, da, ref, off
+    # data gradients: a producer whose ONLY consumer is one convolution receives exactly that convolution's data gradient
+    pairs = [('stem', 'stages.0.down'), ('stages.0.res.0.c2', 'stages.1.down'), ('stages.0.res.0.c1', 'stages.0.res.0.c2'),
+             ('stages.1.res.1.c1', 'stages.1.res.1.c2'), ('stages.2.res.0.c1', 'stages.2.res.0.c2'),
+             ('stages.3.res.7.c1', 'stages.3.res.7.c2'), ('stages.4.res.3.c1', 'stages.4.res.3.c2'),
+             ('heads.0.b1', 'heads.0.b2'), ('heads.1.b0', 'heads.1.b1'), ('heads.2.b3', 'heads.2.b4')]
+    nuse = {}
+    for op in plan.fwd:
+        for k_ in ('x', 'res', 'up', 'route'):
+            t = op.get(k_)
+            if t is not None:
+                nuse[id(t)] = nuse.get(id(t), 0) + 1
+    for prod, cons in pairs:
+        po, co = ops[prod], ops[cons]
+        assert co['x'] is po['z'] and nuse[id(po['z'])] == 1, (prod, cons)
+        c = co['c']
+        w = rb(net.params[cons + '.weight'].detach().float())
+        N_, H_, W_, _ = po['z'].shape
+        ref = _taps_dgrad(cap[cons]['dy'].float(), w, c.stride, H_, W_)
+        note('dgrad s%d k%d' % (c.stride, c.k), cons, rel(cap[prod]['dz'].float(), rb(ref)), tol)
+        del ref
+    print('bs-64 device one-hop worst:', worst)
 
 
 def test_d53_608_forward(cuda):

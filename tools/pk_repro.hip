@@ -1,0 +1,199 @@
+// Stand-alone probe for the "packed fp32 operations store wrong values beside MFMA kernels" finding (csrc/Makefile NOPK,
+// DESIGN 4.2): ONE VALU kernel whose arithmetic is v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 (the shape of the BatchNorm
+// backward's apply pass: 16-byte bf16 loads of two tensors, per-channel constants, 16-byte bf16 store) on stream 1, ONE
+// MFMA spinner on stream 2 sharing its CUs, no library code.  The packed kernel's output is compared bit for bit with a
+// scalar-arithmetic kernel run alone.  Build + run: tools/pk_repro.sh (hipcc --offload-arch=gfx950).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <vector>
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+__device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {                       // round to nearest even
+    unsigned u = __float_as_uint(f);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ f2 pk_mul(f2 a, f2 b) { f2 r; asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f2 pk_add(f2 a, f2 b) { f2 r; asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// the form hipcc emits for a wave-uniform factor: the first source is an SGPR PAIR
+__device__ __forceinline__ f2 pk_mul_s(f2 s_pair, f2 b) { f2 r; asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "s"(s_pair), "v"(b)); return r; }
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { f2 r; asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// dy = k0[c] * (dz * (a > 0 ? 1 : 0.1) - k1[c] - xhat * k2[c]),  xhat = (y - mean[c]) * invstd[c],  a = g[c] * xhat + b[c]
+// PACKED: 0 scalar arithmetic; 1 packed, VGPR sources only; 2 packed, the final factor (u0, u1) from an SGPR pair
+template <int PACKED>
+__global__ __launch_bounds__(256) void apply_kernel(const uint4* __restrict__ dz, const uint4* __restrict__ y, uint4* __restrict__ dy,
+                                                    const float* __restrict__ kc, int C, long long n_oct, float u0, float u1) {
+    const int oct_per_px = C / 8;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n_oct; i += (long long)gridDim.x * 256) {
+        const int c0 = (int)(i % oct_per_px) * 8;
+        const uint4 a4 = dz[i], b4 = y[i];
+        const unsigned aw[4] = {a4.x, a4.y, a4.z, a4.w}, bw[4] = {b4.x, b4.y, b4.z, b4.w};
+        unsigned ow[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = c0 + 2 * q;
+            f2 d = {bf2f(aw[q] & 0xffff), bf2f(aw[q] >> 16)}, v = {bf2f(bw[q] & 0xffff), bf2f(bw[q] >> 16)};
+            const f2 mean = {kc[c], kc[c + 1]}, inv = {kc[C + c], kc[C + c + 1]}, g = {kc[2 * C + c], kc[2 * C + c + 1]};
+            const f2 be = {kc[3 * C + c], kc[3 * C + c + 1]}, k0 = {kc[4 * C + c], kc[4 * C + c + 1]};
+            const f2 k1 = {kc[5 * C + c], kc[5 * C + c + 1]}, k2 = {kc[6 * C + c], kc[6 * C + c + 1]};
+            f2 r;
+            if (PACKED) {
+                const f2 xh = pk_mul(pk_add(v, -mean), inv);
+                const f2 a = pk_fma(g, xh, be);
+                const f2 sl = {a.x > 0.f ? 1.f : 0.1f, a.y > 0.f ? 1.f : 0.1f};
+                const f2 da = pk_mul(d, sl);
+                r = pk_mul(k0, pk_add(pk_add(da, -k1), -pk_mul(xh, k2)));
+                const f2 u = {u0, u1};
+                r = PACKED == 2 ? pk_mul_s(u, r) : pk_mul(u, r);
+            } else {
+                float rr[2];
+                const float dd[2] = {d.x, d.y}, vv[2] = {v.x, v.y};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float xh = (vv[e] - kc[c + e]) * kc[C + c + e];
+                    const float a = fmaf(kc[2 * C + c + e], xh, kc[3 * C + c + e]);
+                    const float da = dd[e] * (a > 0.f ? 1.f : 0.1f);
+                    rr[e] = kc[4 * C + c + e] * ((da - kc[5 * C + c + e]) - xh * kc[6 * C + c + e]);
+                    rr[e] = (e ? u1 : u0) * rr[e];
+                }
+                r.x = rr[0]; r.y = rr[1];
+            }
+            ow[q] = (unsigned)f2bf(r.x) | ((unsigned)f2bf(r.y) << 16);
+        }
+        dy[i] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    }
+}
+
+// MFMA spinner: `iters` x 8 independent 32x32x16 bf16 MFMAs per wave on register operands, a few global loads per
+// iteration (the weight-gradient kernels of the training step read two tensors), AGPR-heavy like them
+__global__ __launch_bounds__(256) void mfma_spin(const uint4* __restrict__ src, float* __restrict__ out, int iters, long long n16) {
+    f16v acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    long long p = (blockIdx.x * 256LL + threadIdx.x) % n16;
+    for (int it = 0; it < iters; ++it) {
+        const uint4 a = src[p], b = src[(p + 4099) % n16];
+        p = (p + 256LL * gridDim.x) % n16;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), acc[k], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += acc[k][threadIdx.x & 15];
+    if (s == 12345.678f) out[0] = s;                                            // (keeps the loop alive)
+}
+
+// LDS spinners: `iters` x 8 LDS reads per lane, summed.  TR = 1: ds_read_b64_tr_b16 (gfx950's transposing read -- what
+// both weight-gradient kernel families of the training step feed their MFMAs with); TR = 0: plain ds_read_b64 (control)
+template <int TR>
+__global__ __launch_bounds__(256) void lds_spin(float* __restrict__ out, int iters) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[16384];
+    for (int i = threadIdx.x; i < 16384; i += 256) lds[i] = (unsigned short)(i * 7);
+    __syncthreads();
+    typedef __attribute__((address_space(3))) unsigned short lds_t;
+    unsigned base = (unsigned)(uintptr_t)(lds_t*)lds + (threadIdx.x & 63) * 8 + (threadIdx.x >> 6) * 4096;
+    unsigned acc = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint2 v;
+            const unsigned a = base + k * 512;
+            if (TR) asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+            else asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+            acc += v.x ^ v.y;
+        }
+    }
+    if (acc == 0x12345678u) out[0] = 1.f;
+}
+
+// LDS-DMA spinner: global_load_lds_dwordx4 (global -> LDS without VGPRs; the LDS base travels in M0) -- what this library's
+// pipelined convolutions and LDS-DMA weight gradients stage their operands with (csrc/conv_pipe.hip glds16)
+__global__ __launch_bounds__(256) void dma_spin(const char* __restrict__ src, float* __restrict__ out, int iters, long long nbytes) {
+    __shared__ __attribute__((aligned(16))) char lds[32768];
+    typedef __attribute__((address_space(3))) char lds_c;
+    const unsigned base = (unsigned)(uintptr_t)(lds_c*)lds;
+    const unsigned wave_lds = __builtin_amdgcn_readfirstlane(base + (threadIdx.x >> 6) * 1024);
+    long long p = ((blockIdx.x * 256LL + threadIdx.x) * 16) % nbytes;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned dst = wave_lds + k * 4096;
+            const char* g = src + p;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(dst) : "memory");
+            p = (p + 256LL * 16 * gridDim.x) % nbytes;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (lds[threadIdx.x] == 0x7f && lds[threadIdx.x + 4096] == 0x55) out[0] = 1.f;
+}
+
+int main(int argc, char** argv) {
+    const int rounds = argc > 1 ? atoi(argv[1]) : 200;
+    const int C = 64;
+    const long long npix = 4LL * 208 * 208, n_oct = npix * C / 8;                // the 64-channel 208x208 map at batch 4
+    std::vector<unsigned short> h(n_oct * 8);
+    srand(1);
+    for (auto& v : h) { float f = (rand() % 2001 - 1000) / 500.0f; unsigned u; memcpy(&u, &f, 4); v = (unsigned short)(u >> 16); }
+    std::vector<float> kc(7 * C);
+    for (int i = 0; i < 7 * C; ++i) kc[i] = 0.25f + (rand() % 1000) / 800.0f;
+    uint4 *dz, *y, *out, *ref, *spin_src; float *kd, *spin_out;
+    CK(hipMalloc(&dz, n_oct * 16)); CK(hipMalloc(&y, n_oct * 16)); CK(hipMalloc(&out, n_oct * 16)); CK(hipMalloc(&ref, n_oct * 16));
+    CK(hipMalloc(&kd, kc.size() * 4)); CK(hipMalloc(&spin_src, 64 << 20)); CK(hipMalloc(&spin_out, 4));
+    CK(hipMemcpy(dz, h.data(), n_oct * 16, hipMemcpyHostToDevice));
+    for (auto& v : h) v = (unsigned short)(v * 3 + 7);
+    CK(hipMemcpy(y, h.data(), n_oct * 16, hipMemcpyHostToDevice));
+    CK(hipMemcpy(kd, kc.data(), kc.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(spin_src, 0x3c, 64 << 20));
+    hipStream_t s1, s2;
+    CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+    const float u0 = 1.375f, u1 = 0.8125f;
+    apply_kernel<0><<<1024, 256, 0, s1>>>(dz, y, ref, kd, C, n_oct, u0, u1);     // scalar arithmetic, alone on the chip
+    CK(hipStreamSynchronize(s1));
+    std::vector<uint4> hr(n_oct), ho(n_oct);
+    CK(hipMemcpy(hr.data(), ref, n_oct * 16, hipMemcpyDeviceToHost));
+    const char* vict[2] = {"packed, VGPR sources", "packed, one SGPR-pair source"};
+    const char* aggr[5] = {"alone", "beside the MFMA spinner", "beside the ds_read_b64 spinner", "beside the ds_read_b64_tr_b16 spinner",
+                           "beside the LDS-DMA spinner (m0 + global_load_lds_dwordx4)"};
+    long long bad[2][5] = {}, zeros[2][5] = {}, lanes48[2][5] = {};
+    for (int v = 0; v < 2; ++v)
+        for (int mode = 0; mode < 5; ++mode)
+            for (int r = 0; r < rounds; ++r) {
+                CK(hipMemsetAsync(out, 0xff, n_oct * 16, s1));                    // NaN poison: an unwritten element shows
+                if (mode == 1) mfma_spin<<<1024, 256, 0, s2>>>(spin_src, spin_out, 3000, (64 << 20) / 16);
+                if (mode == 2) lds_spin<0><<<1024, 256, 0, s2>>>(spin_out, 4000);
+                if (mode == 3) lds_spin<1><<<1024, 256, 0, s2>>>(spin_out, 4000);
+                if (mode == 4) dma_spin<<<1024, 256, 0, s2>>>((const char*)spin_src, spin_out, 1500, 64 << 20);
+                if (v == 0) apply_kernel<1><<<1024, 256, 0, s1>>>(dz, y, out, kd, C, n_oct, u0, u1);
+                else apply_kernel<2><<<1024, 256, 0, s1>>>(dz, y, out, kd, C, n_oct, u0, u1);
+                CK(hipStreamSynchronize(s1));
+                CK(hipMemcpy(ho.data(), out, n_oct * 16, hipMemcpyDeviceToHost));
+                CK(hipStreamSynchronize(s2));
+                const unsigned short* a = (const unsigned short*)ho.data(); const unsigned short* b = (const unsigned short*)hr.data();
+                for (long long i = 0; i < n_oct * 8; ++i)
+                    if (a[i] != b[i]) {
+                        if (bad[v][mode] < 4) printf("%s, %s, round %d: element %lld (thread-lane %lld, element %lld of its 8): got %04x want %04x\n", vict[v], aggr[mode], r, i, (i / 8) % 64, i % 8, a[i], b[i]);
+                        ++bad[v][mode]; zeros[v][mode] += (a[i] & 0x7fff) == 0; lanes48[v][mode] += ((i / 8) % 64) >= 48;
+                    }
+            }
+    printf("pk_repro: %d rounds x %lld bf16 elements per cell; mismatches against scalar arithmetic run alone (exact zeros / in lanes 48-63):\n", rounds, n_oct * 8);
+    bool only = true, any = false;
+    for (int v = 0; v < 2; ++v)
+        for (int m = 0; m < 5; ++m) {
+            printf("  %-30s %-58s %9lld (%lld / %lld)\n", vict[v], aggr[m], bad[v][m], zeros[v][m], lanes48[v][m]);
+            if (bad[v][m]) { any = true; if (!(v == 1 && m == 4)) only = false; }
+        }
+    printf(!any ? "NOT REPRODUCED\n" : only ? "REPRODUCED: v_pk_mul_f32 with an SGPR-pair source beside LDS-DMA only\n" : "REPRODUCED (see the table)\n");
+    return 0;
+}
