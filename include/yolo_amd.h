@@ -152,6 +152,9 @@ int yolo_stem_down_fwd(const float* x_nchw, const float* w1_oihw, const float* s
 /* Synthetic-target compositing of RenderCar.render (car/render_car.py:135-137): out = clip((bg / 255) * (1 - mask) +
  * fg * mask, 0, 1) over n float32 elements (n % 4 == 0; (B,3,H,W) tensors: bg 0..255, fg and mask 0..1). */
 int yolo_composite(const float* bg, const float* fg, const float* mask, float* out, long long n, void* stream);
+/* The blend of LPGenerator.add (yolo_modules/licence_plate_render/__init__.py:163-164), which pastes the projected plate
+ * onto images that are ALREADY 0..1: out = clip(bg * (1 - mask) + fg * mask, 0, 1). */
+int yolo_composite_unit(const float* bg, const float* fg, const float* mask, float* out, long long n, void* stream);
 
 /* 2x nearest up-sample of `up` (N,H/2,W/2,C1) + channel concat with `route` (N,H,W,C2) ->
  * (N,H,W,C1+C2), up-sampled channels first: gluoncv _upsample + F.concat, car/utils.py:92-93. */

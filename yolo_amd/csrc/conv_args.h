@@ -73,5 +73,7 @@ static inline int conv_halo_slots(int BP, int d, int Ho, int H, int S, long long
 
 // conv_pipe.hip: pipelined variants (algo >= 2); YOLO_EUNSUPPORTED if the shape is not eligible.
 int conv_pipe_dispatch(ConvArgs& a, int ks, int stride, int dtype, int algo, hipStream_t st, const NameOut* nm);
+// conv_sk.hip: 1x1 with the K range split over the waves of one block (algo 30-35); YOLO_EUNSUPPORTED if not eligible.
+int conv_sk_dispatch(ConvArgs& a, int ks, int stride, int dtype, int algo, hipStream_t st, const NameOut* nm);
 // conv_stream.hip: weights-stationary streaming kernel for the small-channel layers (algo 13 / 14).
 int conv_stream_dispatch(const ConvArgs& a, int ks, int stride, int dtype, int algo, hipStream_t st, const NameOut* nm);

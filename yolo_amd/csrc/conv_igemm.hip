@@ -431,6 +431,7 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
         return launch_dtype<bf16_t>(a, d->ksize, d->stride, st, nm);
     }
     if (d->algo == 13 || d->algo == 14) return conv_stream_dispatch(a, d->ksize, d->stride, d->dtype, d->algo, st, nm);
+    if (d->algo >= 30 && d->algo <= 35) return conv_sk_dispatch(a, d->ksize, d->stride, d->dtype, d->algo, st, nm);
     if (d->algo >= 2) return conv_pipe_dispatch(a, d->ksize, d->stride, d->dtype, d->algo, st, nm);
     if (d->algo == 0) {
         // small-channel 3x3 layers: the streaming kernel (measured 1.2-1.45x the generic one; the 1x1s and the

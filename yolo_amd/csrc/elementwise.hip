@@ -170,6 +170,8 @@ extern "C" int yolo_upsample2x_concat(const void* up, const void* route, void* y
 
 // ---- synthetic-target compositing (RenderCar.render, car/render_car.py:135-137) -------------------------------
 // out = clip((bg / 255) * (1 - mask) + fg * mask, 0, 1), all (B,3,H,W) float32; 4 elements per thread.
+// UNIT: bg is already 0..1 (LPGenerator.add pastes onto RenderCar's output, licence_plate_render/__init__.py:163).
+template <bool UNIT>
 __global__ void composite_kernel(const f32x4* __restrict__ bg, const f32x4* __restrict__ fg, const f32x4* __restrict__ mask,
                                  f32x4* __restrict__ out, long long n4) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -178,7 +180,7 @@ __global__ void composite_kernel(const f32x4* __restrict__ bg, const f32x4* __re
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float v = (b[e] / 255.f) * (1.f - m[e]) + f[e] * m[e];
+        const float v = (UNIT ? b[e] : b[e] / 255.f) * (1.f - m[e]) + f[e] * m[e];
         o[e] = fminf(fmaxf(v, 0.f), 1.f);
     }
     out[i] = o;
@@ -188,7 +190,17 @@ extern "C" int yolo_composite(const float* bg, const float* fg, const float* mas
     if (!bg || !fg || !mask || !out || n <= 0) return YOLO_EINVAL;
     if (n % 4) return YOLO_EUNSUPPORTED;
     const long long n4 = n / 4;
-    YOLO_LAUNCH(composite_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)bg,
+    YOLO_LAUNCH(composite_kernel<false>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)bg,
+                (const f32x4*)fg, (const f32x4*)mask, (f32x4*)out, n4);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+}
+
+extern "C" int yolo_composite_unit(const float* bg, const float* fg, const float* mask, float* out, long long n, void* stream) {
+    if (!bg || !fg || !mask || !out || n <= 0) return YOLO_EINVAL;
+    if (n % 4) return YOLO_EUNSUPPORTED;
+    const long long n4 = n / 4;
+    YOLO_LAUNCH(composite_kernel<true>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)bg,
                 (const f32x4*)fg, (const f32x4*)mask, (f32x4*)out, n4);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;

@@ -57,6 +57,7 @@ SIGNATURES = {
     'yolo_stem_down_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'yolo_res_block_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'yolo_composite': (_i, [_vp, _vp, _vp, _vp, _ll, _vp]),
+    'yolo_composite_unit': (_i, [_vp, _vp, _vp, _vp, _ll, _vp]),
     'yolo_upsample2x_concat': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'yolo_decode': (_i, [_vp, _vp, _i, _i, C.POINTER(GridDesc), _vp]),
     'yolo_decode_scores': (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(GridDesc), _i, _vp]),
