@@ -84,11 +84,11 @@ PIPE_CASES = [
 ]
 
 
-@pytest.mark.parametrize('algo', [2, 3, 4, 5, 6, 7, 8, 11, 12, 19, 20, 21, 22, 23, 24, 25, 26, 30, 31, 32, 33, 35])
+@pytest.mark.parametrize('algo', [2, 3, 4, 5, 6, 7, 8, 11, 12, 19, 20, 21, 22, 23, 24, 25, 26, 30, 31, 32, 33, 35, 36, 37, 38, 39])
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('case', PIPE_CASES)
 def test_conv_pipe(lib, cuda, case, dtype, algo):
-    if (algo in (6, 7, 26) and case[5] != 3) or (algo in (12, 19, 20, 21, 22, 23, 24, 25) and case[5] != 1) or (algo == 26 and dtype != 'bf16'):
+    if (algo in (6, 7, 26) and case[5] != 3) or (algo in (12, 19, 20, 21, 22, 23, 24, 25, 36, 37, 38, 39) and case[5] != 1) or (algo == 26 and dtype != 'bf16'):
         pytest.skip('variant not defined for this kernel size')
     if algo >= 30 and case[5] != 1:
         pytest.skip('split-K-in-block variants (conv_sk.hip): 1x1 only')

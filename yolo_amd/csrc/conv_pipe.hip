@@ -701,6 +701,12 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
             case 19: return launch_pipe<T, 1, 1, 4, 2, 2, 64, 1, 7>(a, st, nm);      // 64 px x 256 cout
             case 20: return launch_pipe<T, 1, 2, 2, 2, 1, 64, 1, 8>(a, st, nm);      // 64 px x 128 cout
             case 21: return launch_pipe<T, 1, 2, 2, 2, 2, 128, 1, 6>(a, st, nm);     // 128 px x 128 cout
+            // 3-slot rings (round 3): LESS LDS per block so that one more block fits a CU -- the large-map 1x1 layers are
+            // HBM-bound and a block runs load -> compute -> store in sequence; a third (fourth) co-resident block overlaps them
+            case 36: return launch_pipe<T, 1, 2, 2, 2, 2, 128, 1, 3, 1, 1>(a, st, nm);     // 128 px x 128 cout, 48 KB: 3 blocks per CU
+            case 37: return launch_pipe<T, 1, 2, 2, 2, 1, 64, 1, 3, 1, 1>(a, st, nm);      // 64 px x 128 cout, 39 KB: 4 blocks per CU
+            case 38: return launch_pipe<T, 1, 1, 8, 1, 4, 128, 1, 3, 1, 1>(a, st, nm);     // 128 px x 256 cout (8 waves), 78 KB: 2 blocks per CU
+            case 39: return launch_pipe<T, 1, 2, 2, 2, 3, 192, 1, 3, 1, 1>(a, st, nm);     // 192 px x 128 cout, 60 KB: 2 blocks per CU
             // two K chunks per phase (half the barriers), lean loop
             case 22: return launch_pipe<T, 1, 2, 2, 2, 1, 64, 1, 0, 2, 1>(a, st, nm);   // 64 px x 128 cout
             case 23: return launch_pipe<T, 1, 2, 2, 2, 2, 128, 1, 0, 2, 1>(a, st, nm);  // 128 px x 128 cout
