@@ -557,7 +557,7 @@ class CarNet(object):
                 continue
             if kind == 'res_block':
                 N_, H_, W_, C_ = payload[8:12]
-                out.append((name, 'res_block_kernel<%d>' % C_, 2 * N_ * H_ * W_ * (C_ * (C_ // 2) + 9 * (C_ // 2) * C_)))
+                out.append((name, ('res_block2_kernel<%d>' if C_ == 128 else 'res_block_kernel<%d>') % C_, 2 * N_ * H_ * W_ * (C_ * (C_ // 2) + 9 * (C_ // 2) * C_)))
                 continue
             if kind != 'conv':
                 out.append((name, kind, 0))
