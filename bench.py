@@ -174,7 +174,7 @@ def train_pass(args, spec, size, B, rank, world, dev, dist, steps, warmup):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el_off = float(t.item())
         nbytes = tr.gflat.numel() * 4
-        exch = {'rccl_world': dist.get_world_size(), 'buckets': len(tr.buckets.ranges), 'bytes': nbytes,
+        exch = {'rccl_world': dist.get_world_size(), 'backend': dist.get_backend(), 'buckets': len(tr.buckets.ranges), 'bytes': nbytes,
                 'allreduce_ms_per_step_standalone': round(ar_ms, 3),
                 'allreduce_busbw_GBps': round(2.0 * (world - 1) / max(world, 1) * nbytes / (ar_ms * 1e-3) / 1e9, 1),
                 'ms_per_step_without_exchange': round(el_off / steps * 1e3, 4),
@@ -318,7 +318,12 @@ def main():
         raise SystemExit('--gpus must be >= 1')
     if need_gpu and not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
-    if need_gpu and torch.cuda.device_count() < args.gpus:
+    # TEST-ONLY (tests/test_gpu_seam_dist.py): YOLO_BENCH_SHARED_GPU=1 with YOLO_BENCH_BACKEND=gloo lets the N ranks share the
+    # GPUs that exist, so that the whole N > 1 path -- rendezvous, sharded passes, the Trainer's bucketed exchange between real
+    # processes, the watchdog, the one JSON line -- runs on a one-GPU box.  The line is marked `shared_gpu_test`; it is not an
+    # N-GPU measurement.
+    shared = bool(os.environ.get('YOLO_BENCH_SHARED_GPU')) and backend == 'gloo'
+    if need_gpu and torch.cuda.device_count() < args.gpus and not shared:
         raise SystemExit('--gpus %d but only %d GPU(s) are visible: refusing to report a %d-GPU number from fewer ranks'
                          % (args.gpus, torch.cuda.device_count(), args.gpus))
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -330,13 +335,18 @@ def main():
         raise SystemExit('WORLD_SIZE %d != --gpus %d: n_gpus must be the number of ranks that ran' % (world, args.gpus))
     if args.launch_check:
         return launch_check(backend, rank, world, local)
+    if shared:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
     if world > 1 or os.environ.get('YOLO_BENCH_FORCE_DIST'):      # (the env knob exercises the N>1 code path on one GPU)
         import torch.distributed as dist
         import datetime
-        dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=max(60.0, args.train_timeout)))
+        if shared:
+            dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=max(60.0, args.train_timeout)))
+        else:
+            dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=max(60.0, args.train_timeout)))
 
     from yolo_amd.net import CarNet
     from yolo_amd.detect import Detector
@@ -391,6 +401,8 @@ def main():
     }
     out['value_median'] = round(float(np.median(reps)), 2)
     out['value_repeats'] = [round(v, 1) for v in reps]
+    if shared:
+        out['shared_gpu_test'] = 'TEST ONLY: %d ranks share %d GPU(s) over gloo -- not an N-GPU measurement' % (world, torch.cuda.device_count())
     out['net_tflops'] = round(net.graph.flops(*size) * value / 1e12 / world, 1)          # per GPU
     out['net_frac'] = round(out['net_tflops'] / MFMA_PEAK_TFLOPS[args.dtype], 4)           # whole pass vs the dense MFMA peak
 

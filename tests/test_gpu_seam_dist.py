@@ -306,3 +306,97 @@ def test_rccl_world_of_one_exchange_is_the_identity(cuda):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+# ---- two REAL ranks (two processes, torch.distributed) on the one GPU of a test box --------------------------------------
+def _two_rank_worker(rank, world, port, q):
+    """One rank of a 2-rank job on cuda:0 (gloo carries CUDA tensors through the host: slow, but a real cross-process
+    SUM all-reduce with the stream semantics of an asynchronous collective)."""
+    import torch.distributed as dist
+    from yolo_amd.net import CarNet
+    from yolo_amd.train import Trainer
+    from yolo_amd import parallel
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        cuda = torch.device('cuda:0')
+        spec, size = og.spec_micro(), (64, 96)
+        P = og.init_params(og.build_graph(spec), seed=0, bn='random')
+        # a global batch of 5 over 2 ranks: UNEVEN shards 2 + 3 (yolo_gluon.py:118-119)
+        x = np.random.default_rng(2).random((5, 3) + size, dtype=np.float32)
+        lab = ot.synthetic_labels(5, seed=7, render_rate=0.0, num_class=4)
+        a, b = parallel.shard_bounds(5, rank, world)
+        net = CarNet(spec, dtype='f32', device=cuda).load_params(P)
+        tr = Trainer(net, size)
+        assert tr.buckets.active()
+        losses = tr.train_step(torch.from_numpy(x[a:b]).to(cuda), torch.from_numpy(lab[a:b]).to(cuda))     # exchange + Adam
+        torch.cuda.synchronize()
+        q.put((rank, b - a, float(tr.gflat[tr.nparam]), losses.cpu().numpy(), tr.gflat.cpu().numpy(), tr.wflat.cpu().numpy()))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_real_ranks_exchange_on_one_gpu(cuda):
+    """configs[3] with two PROCESSES: each rank runs its uneven shard (2 + 3 images) with its own batch statistics, the
+    Trainer's bucketed asynchronous all-reduce sums the gradient buffers between the processes, the global batch (5) arrives
+    in the buffer's slot, every rank applies the same Adam step.  Against the single-process emulation of the same thing:
+    the two shards run one after the other on one Trainer, the buffers added by hand, step(5)."""
+    import torch.multiprocessing as mp
+    import socket
+    from yolo_amd.net import CarNet
+    from yolo_amd.train import Trainer
+    so = socket.socket(); so.bind(('127.0.0.1', 0)); port = so.getsockname()[1]; so.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    out = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    [p.join(timeout=120) for p in ps]
+    assert [o[1] for o in out] == [2, 3] and out[0][2] == out[1][2] == 5.0          # the slot: SUM of the shard sizes
+    np.testing.assert_array_equal(out[0][4], out[1][4])                                # the same reduced gradient buffer ...
+    np.testing.assert_array_equal(out[0][5], out[1][5])                                # ... and the same weights on both ranks
+    # single-process emulation
+    spec, size = og.spec_micro(), (64, 96)
+    P = og.init_params(og.build_graph(spec), seed=0, bn='random')
+    x = np.random.default_rng(2).random((5, 3) + size, dtype=np.float32)
+    lab = ot.synthetic_labels(5, seed=7, render_rate=0.0, num_class=4)
+    net = CarNet(spec, dtype='f32', device=cuda).load_params(P)
+    tr = Trainer(net, size)
+    gsum, ls = None, []
+    for a, b in ((0, 2), (2, 5)):
+        net.load_params(P)
+        ls.append(tr.train_step(torch.from_numpy(x[a:b]).to(cuda), torch.from_numpy(lab[a:b]).to(cuda), update=False).cpu().numpy())
+        gsum = tr.gflat.clone() if gsum is None else gsum + tr.gflat
+    net.load_params(P)
+    tr.gflat.copy_(gsum)
+    tr.step(5)
+    np.testing.assert_allclose(np.concatenate([out[0][3], out[1][3]], axis=1), np.concatenate(ls, axis=1), rtol=1e-5, atol=1e-8)
+    g_ref, g_got = gsum.cpu().numpy(), out[0][4]
+    assert np.abs(g_got - g_ref).max() <= 1e-5 * np.abs(g_ref).max() + 1e-9         # (atomics: summation order inside a shard)
+    w_ref, w_got = tr.wflat.cpu().numpy()[:tr.nparam], out[0][5][:tr.nparam]
+    # Adam's first step is lr * g / (|g| + eps): weights agree wherever the two gradients do
+    assert np.mean(np.abs(w_got - w_ref) > 1e-6) < 1e-3, float(np.mean(np.abs(w_got - w_ref) > 1e-6))
+
+
+def test_bench_two_ranks_sharing_the_gpu():
+    """`bench.py --gpus 2` end to end on a one-GPU box (TEST-ONLY switch YOLO_BENCH_SHARED_GPU + gloo): the launcher starts two
+    ranks, both run the sharded inference passes and the training pass with the real exchange, rank 0 prints ONE JSON line
+    last on stdout with n_gpus = 2, the training key with its exchange block, and the test-only marker."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(YOLO_BENCH_BACKEND='gloo', YOLO_BENCH_SHARED_GPU='1')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--no-northstar',
+                        '--no-roofline', '--no-repeats', '--train-timeout', '900'], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    d = json.loads(lines[-1])                                                          # the JSON line is the LAST line
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 64 and 'shared_gpu_test' in d
+    t = d['train_416_bs64']
+    assert 'error' not in t, t
+    assert t['n_gpus'] == 2 and t['global_batch'] == 128 and t['exchange']['rccl_world'] == 2 and t['exchange']['buckets'] >= 2
+    assert t['exchange']['allreduce_ms_per_step_standalone'] > 0 and all(np.isfinite(t['final_losses']))
+    assert 'cpu_baseline' not in d and 'f32_path' not in d                              # rank-0-only extras of the N = 1 line
