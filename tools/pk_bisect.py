@@ -2,7 +2,7 @@
 """Where does the packed-fp32 corruption of the BatchNorm backward come from?  (csrc/Makefile NOPK, DESIGN 4.2, round-2
 verdict item 7.)  tools/pk_repro.hip -- a synthetic packed-VALU kernel beside a synthetic MFMA spinner -- does NOT
 reproduce it, so this script isolates the REAL kernel outside the Trainer: yolo_bn_train_bwd_pp from a library whose
-train.hip was built WITH the packed operations (yolo_amd/csrc/_ab/libyolo_pk.so: `hipcc ... train.hip` without NOPK) runs
+train.hip was built WITH the packed operations (`make -C yolo_amd/csrc pk` -> yolo_amd/csrc/_ab/libyolo_pk.so) runs
 on stream 1 on one fixed input while stream 2 runs, in turn: nothing; a bf16 torch.matmul (hipBLASLt's MFMA kernel: not
 this repository's code, its own buffers only); synthetic one-feature spinners (tools/pk_spin.hip: MFMA, plain and
 transposing LDS reads, fp32 atomics, LDS-DMA); this library's forward convolution (generic register-staged kernel and
