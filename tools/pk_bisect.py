@@ -21,7 +21,7 @@ import torch
 
 from yolo_amd import lib as L
 
-PK = os.path.join(L.CSRC, '_ab', 'libyolo_pk.so')
+PK = os.environ.get('PK_LIB') or os.path.join(L.CSRC, '_ab', 'libyolo_pk.so')        # (PK_LIB: a variant build of the victim)
 
 
 def load(path):
@@ -113,6 +113,10 @@ def main():
                ('beside a synthetic ds_read_b64_tr_b16 spinner', lambda: spin.spin_lds(vp(spin_out.data_ptr()), 4000, 1, vp(side.cuda_stream))),
                ('beside a synthetic fp32-atomics spinner', lambda: spin.spin_atomic(vp(spin_out.data_ptr()), 300, spin_out.numel(), vp(side.cuda_stream))),
                ('beside a synthetic LDS-DMA spinner (m0 + global_load_lds_dwordx4)', lambda: spin.spin_dma(vp(spin_src.data_ptr()), vp(spin_out.data_ptr()), 1500, C.c_longlong(spin_src.numel() * 2), vp(side.cuda_stream))),
+               ('beside a synthetic turnover spinner: short MFMA blocks (1 wave)', lambda: spin.spin_turnover(vp(spin_src.data_ptr()), vp(spin_out.data_ptr()), 0, 400000, 6, C.c_longlong(spin_src.numel() // 8), vp(side.cuda_stream))),
+               ('beside a synthetic turnover spinner: short MFMA blocks (4 waves)', lambda: spin.spin_turnover(vp(spin_src.data_ptr()), vp(spin_out.data_ptr()), 3, 100000, 6, C.c_longlong(spin_src.numel() // 8), vp(side.cuda_stream))),
+               ('beside a synthetic turnover spinner: short MFMA blocks + 64 KB LDS + barrier', lambda: spin.spin_turnover(vp(spin_src.data_ptr()), vp(spin_out.data_ptr()), 1, 60000, 6, C.c_longlong(spin_src.numel() // 8), vp(side.cuda_stream))),
+               ('beside a synthetic turnover spinner: short VALU-only blocks (200 zeroed registers)', lambda: spin.spin_turnover(vp(spin_src.data_ptr()), vp(spin_out.data_ptr()), 2, 800000, 0, C.c_longlong(spin_src.numel() // 8), vp(side.cuda_stream))),
                ('beside yolo_conv_fwd 3x3, generic kernel (register-staged MFMA)', lambda: co_conv(1)),
                ('beside yolo_conv_fwd 3x3, pipelined kernel (LDS-DMA + MFMA)', lambda: co_conv(4)),
                ('beside yolo_conv_wgrad 1x1 (GEMM / per-tap kernel)', lambda: wg(wx, wdw1, 128, 1)),
@@ -122,25 +126,28 @@ def main():
             for co_name, co in cos:
                 bad = zeros = events = 0
                 lanes = {}
+                pix_lo, pix_hi = 1 << 60, -1
                 for r in range(rounds):
                     out = torch.full_like(y, float('nan'))
                     torch.cuda.synchronize()
                     co()
                     bn(lib, out, torch.cuda.current_stream().cuda_stream, r)
                     torch.cuda.synchronize()
-                    ne = out.view(torch.int16) != ref.view(torch.int16)
+                    ne = out.view(torch.int16) != (ref2 if lib is pk else ref).view(torch.int16)      # (each library against itself, alone)
                     k = int(ne.sum())
                     if k:
                         events += 1
                         bad += k
                         zeros += int((out[ne] == 0).sum())
-                        idx = ne.reshape(-1).nonzero().flatten()[:64].cpu().tolist()
+                        allidx = ne.reshape(-1).nonzero().flatten()
+                        pix_lo, pix_hi = min(pix_lo, int(allidx.min()) // Cc), max(pix_hi, int(allidx.max()) // Cc)
+                        idx = allidx[:64].cpu().tolist()
                         for i in idx:
                             lanes[(i // 8) % 64] = lanes.get((i // 8) % 64, 0) + 1
                 key = '%dx%dx%dx%d %s BatchNorm backward %s' % (N, H, W, Cc, lib_name, co_name)
                 results[key] = (events, bad, zeros)
                 print('%-104s rounds with a mismatch %3d / %d, elements %6d (exact zeros %6d)%s' % (
-                    key, events, rounds, bad, zeros, ('  octet-lanes ' + str(sorted(lanes.items())[:8])) if lanes else ''), flush=True)
+                    key, events, rounds, bad, zeros, ('  pixels %d..%d of %d' % (pix_lo, pix_hi, npix)) if lanes else ''), flush=True)
         print('   (packed library alone == shipped library alone: %s)' % same_alone, flush=True)
     return results
 
