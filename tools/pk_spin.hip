@@ -97,6 +97,38 @@ __global__ __launch_bounds__(256) void k_pkform(const f2v* __restrict__ a, const
             else asm volatile("v_pk_mul_f32 %0, %2, %1\n\ts_nop 7\n\tv_mov_b64 %1, %3" : "=&v"(r), "+v"(vb2) : "v"(va), "v"(vc));
             if (__float_as_uint(vb2.x) != (unsigned)i) r.x = -12345.f;   // (the move itself must have happened)
         }
+        // forms 5 / 6: the half-swap hipcc emits to re-pair packed results -- BOTH sources the same register pair:
+        // v_pk_mov_b32 vdst, v[n:n+1], v[n:n+1] op_sel:[1,0] -> (hi, lo); form 6 feeds it straight from a packed multiply
+        if (FORM == 5) asm volatile("v_pk_mov_b32 %0, %1, %1 op_sel:[1,0]" : "=v"(r) : "v"(va));
+        if (FORM == 6) {
+            f2v t;
+            asm volatile("v_pk_mul_f32 %0, %2, %3\n\tv_pk_mov_b32 %1, %0, %0 op_sel:[1,0]" : "=&v"(t), "=v"(r) : "v"(va), "v"(vb));
+        }
+        // form 7: the half-swap while vector-memory loads of the same wave are still in flight (the kernel's re-pairing moves sit
+        // between s_waitcnt vmcnt(2) and vmcnt(0)): 8 x { issue a load ; v_pk_mul_f32 ; v_pk_mov_b32 d, t, t op_sel:[1,0] }, the
+        // loads waited for only at the end; every swap is checked on the device, the first failing one marks the output
+        if (FORM == 7) {
+            const f2v* q = a + ((i * 7919 + 13) % (n - 1024));
+            uint2 ld[8];
+            f2v t[8], d[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const f2v vk = {va.x + (float)k, va.y - (float)k};
+                asm volatile("global_load_dwordx2 %0, %4, off\n\tv_pk_mul_f32 %1, %3, %5\n\tv_pk_mov_b32 %2, %1, %1 op_sel:[1,0]"
+                             : "=&v"(ld[k]), "=&v"(t[k]), "=&v"(d[k]) : "v"(vk), "v"(q + 64 * k), "v"(vb));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            r = va * vb;
+            unsigned chk = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const f2v vk = {va.x + (float)k, va.y - (float)k};
+                const f2v w = vk * vb;
+                if (d[k].x != w.y || d[k].y != w.x) r.x = -777.f - (float)k;
+                chk += ld[k].x ^ ld[k].y;
+            }
+            if (chk == 0x12345678u) r.y = 0.f;
+        }
         out[i] = r;
     }
 }
@@ -106,7 +138,10 @@ extern "C" int victim_pkform(const void* a, const void* b, void* out, long long 
     else if (form == 1) k_pkform<1><<<1024, 256, 0, s>>>((const f2v*)a, (const f2v*)b, (f2v*)out, n);
     else if (form == 2) k_pkform<2><<<1024, 256, 0, s>>>((const f2v*)a, (const f2v*)b, (f2v*)out, n);
     else if (form == 3) k_pkform<3><<<1024, 256, 0, s>>>((const f2v*)a, (const f2v*)b, (f2v*)out, n);
-    else k_pkform<4><<<1024, 256, 0, s>>>((const f2v*)a, (const f2v*)b, (f2v*)out, n);
+    else if (form == 4) k_pkform<4><<<1024, 256, 0, s>>>((const f2v*)a, (const f2v*)b, (f2v*)out, n);
+    else if (form == 5) k_pkform<5><<<1024, 256, 0, s>>>((const f2v*)a, (const f2v*)b, (f2v*)out, n);
+    else if (form == 6) k_pkform<6><<<1024, 256, 0, s>>>((const f2v*)a, (const f2v*)b, (f2v*)out, n);
+    else k_pkform<7><<<1024, 256, 0, s>>>((const f2v*)a, (const f2v*)b, (f2v*)out, n);
     return (int)hipGetLastError();
 }
 // Register-file poison: every wave writes `bits` into v1..v255 and a0..a255 of its SIMD's register file and exits; VGPRs are not

@@ -5,6 +5,8 @@
 #   v3  the two multiplies kept scalar (values pinned in single registers)          -> measured CLEAN beside every co-runner
 #   v4  conversions, 32 wait states, then the (packed) multiplies                    -> still corrupted
 #   v5  the factor in a VGPR instead of the SGPR pair                                -> still corrupted
+#   v6  k1 and k2 in loops of their own: the 8 packed multiplies stay, but hipcc no longer needs its 8 re-pairing moves
+#       v_pk_mov_b32 v[n:n+1], v[n:n+1] op_sel:[1,0] behind them                         -> measured CLEAN
 set -e
 cd "$(dirname "$0")/../yolo_amd/csrc"
 make -s pk >/dev/null 2>&1
@@ -30,11 +32,19 @@ v4 = s.replace(a, "                if (FUSED) { k1[e] = (float)f.sums[c]; k2[e] 
         }
 ''' + b)
 v5 = s.replace(a, '                if (FUSED) { float iv = inv_n; asm volatile("" : "+v"(iv)); k1[e] = (float)f.sums[c] * iv; k2[e] = (float)f.sums[C + c] * iv; }')
-for n, t in (('v3', v3), ('v4', v4), ('v5', v5)):
+v6 = s.replace(a, "                if (FUSED) { k1[e] = 0.f; k2[e] = 0.f; }").replace(b, '''        if (MODE == 1 && FUSED) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) k1[e] = (float)f.sums[oct * 8 + e] * inv_n;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) k2[e] = (float)f.sums[C + oct * 8 + e] * inv_n;
+        }
+''' + b)
+for n, t in (('v3', v3), ('v4', v4), ('v5', v5), ('v6', v6)):
     open('_ab_train_%s.hip' % n, 'w').write(t)
 PY
 OBJS="conv_igemm.o conv_pipe.o conv_pipe_b.o conv_sk.o conv_stream.o stem.o stem_down.o res_block.o elementwise.o detect.o wgrad_walk.o loss.o"
-for v in v3 v4 v5; do
+for v in v3 v4 v5 v6; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -ffp-contract=off -c _ab_train_$v.hip -o _ab/train_$v.o
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o _ab/libyolo_pk_$v.so $OBJS _ab/train_$v.o
     rm -f _ab_train_$v.hip
