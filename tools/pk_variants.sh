@@ -13,7 +13,7 @@ make -s pk >/dev/null 2>&1
 python - <<'PY'
 s = open('train.hip').read()
 a = "                if (FUSED) { k1[e] = (float)f.sums[c] * inv_n; k2[e] = (float)f.sums[C + c] * inv_n; }"
-assert s.count(a) == 1
+assert s.count(a) == 1                                        # (the YOLO_BN_PAIRED_FACTORS form: the variants build with that macro)
 v3 = s.replace(a, '''                if (FUSED) {
                     float t1 = (float)f.sums[c], t2 = (float)f.sums[C + c];
                     asm volatile("" : "+v"(t1)); asm volatile("" : "+v"(t2));
@@ -45,7 +45,7 @@ for n, t in (('v3', v3), ('v4', v4), ('v5', v5), ('v6', v6)):
 PY
 OBJS="conv_igemm.o conv_pipe.o conv_pipe_b.o conv_sk.o conv_stream.o stem.o stem_down.o res_block.o elementwise.o detect.o wgrad_walk.o loss.o"
 for v in v3 v4 v5 v6; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -ffp-contract=off -c _ab_train_$v.hip -o _ab/train_$v.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -ffp-contract=off -DYOLO_BN_PAIRED_FACTORS -c _ab_train_$v.hip -o _ab/train_$v.o
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o _ab/libyolo_pk_$v.so $OBJS _ab/train_$v.o
     rm -f _ab_train_$v.hip
 done

@@ -244,10 +244,26 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
             }
             sc[e] = gamma[c]; sh[e] = beta[c];
             if (MODE == 1) {
+#ifdef YOLO_BN_PAIRED_FACTORS
+                // (the form this kernel shipped with until round 3, kept for `make pk`: built WITH the packed fp32 operations hipcc
+                //  pairs (k1[e], k2[e]) for one v_pk_mul_f32 and re-pairs the products with v_pk_mov_b32 v[n:n+1], v[n:n+1]
+                //  op_sel:[1,0] -- the instruction that comes out wrong beside this library's MFMA kernels)
                 if (FUSED) { k1[e] = (float)f.sums[c] * inv_n; k2[e] = (float)f.sums[C + c] * inv_n; }
+#else
+                if (FUSED) { k1[e] = 0.f; k2[e] = 0.f; }                       // (set below, k1 and k2 in loops of their own)
+#endif
                 else { k1[e] = dbeta[c] * inv_n; k2[e] = dgamma[c] * inv_n; }
             }
         }
+#ifndef YOLO_BN_PAIRED_FACTORS
+        if (MODE == 1 && FUSED) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) k1[e] = (float)f.sums[oct * 8 + e] * inv_n;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) k2[e] = (float)f.sums[C + oct * 8 + e] * inv_n;
+        }
+#endif
         auto apply = [&](const float (&v)[8], const float (&o)[8], float (&r)[8]) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
