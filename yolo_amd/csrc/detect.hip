@@ -238,7 +238,7 @@ extern "C" int yolo_nms_scores(const float* rows, float* scores, int B, int nbox
     if (!rows || !scores || B <= 0 || nbox <= 0 || C < 6) return YOLO_EINVAL;
     if (mode == 1 && C <= 6) return YOLO_EINVAL;
     const long long nboxes = (long long)B * nbox;
-    if (C > 96) return YOLO_EUNSUPPORTED;                      // LDS staging: 256 boxes x (C + ncls) floats
+    if (C > 96) return YOLO_EUNSUPPORTED;                      // LDS staging: kDecBoxes boxes x (C + ncls) floats
     YOLO_LAUNCH(nms_scores_kernel, dim3((unsigned)((nboxes + 255) / 256)), dim3(256),
                 (size_t)256 * (C + (C - 6)) * sizeof(float), (hipStream_t)stream, rows, scores, C, C - 6, mode, nboxes);
     YOLO_LAUNCH_CHECK();
@@ -247,54 +247,140 @@ extern "C" int yolo_nms_scores(const float* rows, float* scores, int B, int nbox
 
 // ---- decode + NMS scores in one pass over the logits ------------------------------------------------
 // yolo_decode followed by yolo_nms_scores reads the logits, writes the rows, reads the rows again and writes the
-// scores (665 MB at 608x608 bs 64, 380 us); here a block stages 256 boxes through LDS once (coalesced both ways), one
+// scores (665 MB at 608x608 bs 64, 380 us); here a block stages 128 boxes through LDS once (coalesced both ways), one
 // thread per box decodes its row IN the staged copy (box constants computed once per box, not once per coordinate)
 // and derives its class scores from it.  Same functions, same operation order: bit-identical to the two calls.
-__global__ __launch_bounds__(256) void decode_scores_kernel(const float* __restrict__ out, float* __restrict__ rows,
-                                                            float* __restrict__ scores, int C, int ncls, int mode,
-                                                            int nbox, long long nboxes, GridDev g) {
-    extern __shared__ float sm[];                        // 256*C floats of rows, then 256*ncls of scores
-    const long long k0 = blockIdx.x * 256LL;
-    const int nb = (int)min(256LL, nboxes - k0);
-    for (int i = threadIdx.x; i < nb * C; i += 256) sm[i] = out[k0 * C + i];
-    __syncthreads();
-    float* so = sm + 256 * C;
-    if ((int)threadIdx.x < nb) {
-        float* p = sm + threadIdx.x * C;
-        const int k = (int)((k0 + threadIdx.x) % nbox);
-        float s, y, x, h, w, l, r, t, b;
-        box_consts(g, k, s, y, x, h, w);
-        decode_axis(p[2], p[4], s, x, (float)g.img_w, w, l, r);
-        decode_axis(p[1], p[3], s, y, (float)g.img_h, h, t, b);
-        const float obj = sigmoidf_ref(p[0]);
-        p[0] = obj; p[1] = l; p[2] = t; p[3] = r; p[4] = b;
-        if (mode == 1) {
-            float m = -FLT_MAX;
-            for (int c = 0; c < ncls; ++c) m = fmaxf(m, p[6 + c]);
-            float sum = 0.f;
-            for (int c = 0; c < ncls; ++c) sum += expf(p[6 + c] - m);
-            for (int c = 0; c < ncls; ++c) so[threadIdx.x * ncls + c] = obj * (expf(p[6 + c] - m) / sum);
-        } else {
-            so[threadIdx.x] = obj;
+// (round 3) The copies are what the kernel is made of -- 490 MB at 608^2 batch 64 -- and a block that loads, computes and
+// stores in turn keeps its loads in flight a third of the time (2.0 TB/s, 243-263 us, with LDS leaving room for ten waves per
+// CU).  So the blocks are persistent and PIPELINED: a tile of 128 boxes is fetched into registers by 16-byte loads, all issued
+// at once, while the tile before it is decoded in LDS and written out.  The score rows have an ODD pitch: a lane owns a box, and
+// 24-float rows put every fourth lane on the same bank; the exponentials are kept there between the sum and the division.
+constexpr int kDecBoxes = 128;
+
+template <int NV>                                          // 16-byte loads per thread and tile: kDecBoxes * C / 4 / kDecBoxes
+__global__ __launch_bounds__(kDecBoxes) void decode_scores_kernel(const float* __restrict__ out, float* __restrict__ rows,
+                                                                  float* __restrict__ scores, int C, int ncls, int mode,
+                                                                  int nbox, long long nboxes, GridDev g) {
+    extern __shared__ float4 sm4[];                      // kDecBoxes rows of C floats, then the score rows of SP floats
+    float* sm = reinterpret_cast<float*>(sm4);
+    float* so = sm + ((kDecBoxes * C + 3) & ~3);
+    const int per = mode == 1 ? ncls : 1, SP = per | 1;
+    const long long ntiles = (nboxes + kDecBoxes - 1) / kDecBoxes;
+    float4 v[NV];
+    float vt = 0.f;                                        // (tile floats % 4: only a last, ragged tile has them)
+    auto fetch = [&](long long tile) {
+        const long long k0 = tile * kDecBoxes;
+        const int n = (int)min((long long)kDecBoxes, nboxes - k0) * C, n4 = n >> 2;
+        const float* src = out + k0 * C;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = (int)threadIdx.x + kDecBoxes * j;
+            if (i < n4) v[j] = reinterpret_cast<const float4*>(src)[i];
         }
+        if ((n4 << 2) + (int)threadIdx.x < n) vt = src[(n4 << 2) + threadIdx.x];
+    };
+    long long tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const long long k0 = tile * kDecBoxes;
+        const int nb = (int)min((long long)kDecBoxes, nboxes - k0), n = nb * C, n4 = n >> 2;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = (int)threadIdx.x + kDecBoxes * j;
+            if (i < n4) sm4[i] = v[j];
+        }
+        if ((n4 << 2) + (int)threadIdx.x < n) sm[(n4 << 2) + threadIdx.x] = vt;
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);      // in flight until the top of the next trip
+        __syncthreads();
+        if ((int)threadIdx.x < nb) {
+            float* p = sm + threadIdx.x * C;
+            const int k = (int)((k0 + threadIdx.x) % nbox);
+            float s, y, x, h, w, l, r, t, b;
+            box_consts(g, k, s, y, x, h, w);
+            decode_axis(p[2], p[4], s, x, (float)g.img_w, w, l, r);
+            decode_axis(p[1], p[3], s, y, (float)g.img_h, h, t, b);
+            const float obj = sigmoidf_ref(p[0]);
+            p[0] = obj; p[1] = l; p[2] = t; p[3] = r; p[4] = b;
+            if (mode == 1) {
+                // eight classes at a time: their LDS reads, exponentials and divisions are independent instructions of one
+                // wave (two or three waves share a SIMD here, so a chain of dependent LDS round trips is not hidden); the
+                // maximum, the sum and every quotient are still taken in class order, value by value
+                const float* cl = p + 6;
+                float* e = so + threadIdx.x * SP;           // the exponentials are kept, not taken twice (same values)
+                float m = -FLT_MAX, sum = 0.f, q[8];
+                for (int c0 = 0; c0 < ncls; c0 += 8) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) q[i] = c0 + i < ncls ? cl[c0 + i] : -FLT_MAX;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) m = fmaxf(m, q[i]);
+                }
+                for (int c0 = 0; c0 < ncls; c0 += 8) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) q[i] = c0 + i < ncls ? cl[c0 + i] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) q[i] = expf(q[i] - m);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (c0 + i < ncls) { e[c0 + i] = q[i]; sum += q[i]; }
+                }
+                for (int c0 = 0; c0 < ncls; c0 += 8) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) q[i] = c0 + i < ncls ? e[c0 + i] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) q[i] = obj * (q[i] / sum);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (c0 + i < ncls) e[c0 + i] = q[i];
+                }
+            } else {
+                so[threadIdx.x * SP] = obj;
+            }
+        }
+        __syncthreads();
+        {
+            float4* dst = reinterpret_cast<float4*>(rows + k0 * C);
+            for (int i = threadIdx.x; i < n4; i += kDecBoxes) dst[i] = sm4[i];
+            if ((n4 << 2) + (int)threadIdx.x < n) rows[k0 * C + (n4 << 2) + threadIdx.x] = sm[(n4 << 2) + threadIdx.x];
+            // flat element i = threadIdx.x + kDecBoxes j of the nb x per scores <-> (row, col), advanced without divisions
+            const int er = kDecBoxes / per, ec = kDecBoxes % per;
+            int row = (int)threadIdx.x / per, col = (int)threadIdx.x % per;
+            for (int i = threadIdx.x; i < nb * per; i += kDecBoxes) {
+                scores[k0 * per + i] = so[row * SP + col];
+                row += er; col += ec;
+                if (col >= per) { col -= per; ++row; }
+            }
+        }
+        __syncthreads();                                   // the next trip overwrites the staged tile
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nb * C; i += 256) rows[k0 * C + i] = sm[i];
-    const int per = mode == 1 ? ncls : 1;
-    for (int i = threadIdx.x; i < nb * per; i += 256) scores[k0 * per + i] = so[i];
 }
 
 extern "C" int yolo_decode_scores(const float* out, float* rows, float* scores, int B, int C, const yolo_grid_desc* g,
                                   int mode, void* stream) {
     if (!out || !rows || !scores || B <= 0 || C < 6 || (mode != 0 && mode != 1)) return YOLO_EINVAL;
     if (mode == 1 && C <= 6) return YOLO_EINVAL;
-    if (C > 96) return YOLO_EUNSUPPORTED;                      // LDS staging: 256 boxes x (C + ncls) floats
+    if (C > 96) return YOLO_EUNSUPPORTED;                      // LDS staging: kDecBoxes boxes x (C + ncls) floats
     GridDev d; int nbox;
     int rc = make_grid(g, d, &nbox);
     if (rc) return rc;
     const long long nboxes = (long long)B * nbox;
-    YOLO_LAUNCH(decode_scores_kernel, dim3((unsigned)((nboxes + 255) / 256)), dim3(256),
-                (size_t)256 * (C + (C - 6 > 1 ? C - 6 : 1)) * sizeof(float), (hipStream_t)stream, out, rows, scores, C,
+    if ((C * kDecBoxes) % 4) return YOLO_EUNSUPPORTED;         // 16-byte copies: a tile's rows start on a 16-byte boundary
+    const size_t lds = (size_t)(((kDecBoxes * C + 3) & ~3) + kDecBoxes * ((mode == 1 ? C - 6 : 1) | 1)) * sizeof(float);
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess
+            || n <= 0) n = 256;
+        cus = n;
+    }
+    long long per_cu = (long long)(160 * 1024 / lds);          // persistent blocks: as many as a CU's LDS holds
+    if (per_cu > 8) per_cu = 8;
+    const long long ntiles = (nboxes + kDecBoxes - 1) / kDecBoxes;
+    const dim3 grid((unsigned)(ntiles < cus * per_cu ? ntiles : cus * per_cu));
+    if (C <= 32)
+        YOLO_LAUNCH(decode_scores_kernel<8>, grid, dim3(kDecBoxes), lds, (hipStream_t)stream, out, rows, scores, C,
+                    C - 6, mode, nbox, nboxes, d);
+    else
+        YOLO_LAUNCH(decode_scores_kernel<24>, grid, dim3(kDecBoxes), lds, (hipStream_t)stream, out, rows, scores, C,
                 C - 6, mode, nbox, nboxes, d);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
@@ -320,6 +406,25 @@ constexpr int NMS_THREADS = 1024;
 constexpr int NMS_CAP = 4096;
 constexpr int NMS_WS_PER_IMAGE = (2 * 2048 + 16) * 4 + NMS_CAP * 8;     // hist x2, sel[8] + cnt + pad, list
 
+// (round 3) The grid-wide selection passes read sixteen scores per thread and trip -- four 16-byte loads in flight -- instead
+// of one dword (4096 waves with one load each in flight took a memory latency per 256 scores: 73-78 us per pass over 140 MB).
+// Element e of load q of the thread's batch is candidate base + 1024 q + e; slots past the end read as -0 (never valid).
+__device__ __forceinline__ void load_score_batch(const float* __restrict__ sc, long long base, long long i1, bool vec,
+                                                 unsigned (&u)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long long i = base + 1024 * q;
+        if (vec && i + 3 < i1) {
+            const float4 v = *reinterpret_cast<const float4*>(sc + i);
+            u[4 * q] = __float_as_uint(v.x); u[4 * q + 1] = __float_as_uint(v.y);
+            u[4 * q + 2] = __float_as_uint(v.z); u[4 * q + 3] = __float_as_uint(v.w);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[4 * q + e] = i + e < i1 ? __float_as_uint(sc[i + e]) : 0x80000000u;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void nms_hist_kernel(const float* __restrict__ scores, long long ncand,
                                                        unsigned vbits, int pass, unsigned* __restrict__ hist,
                                                        const unsigned* __restrict__ sel, long long per_block) {
@@ -335,18 +440,24 @@ __global__ __launch_bounds__(256) void nms_hist_kernel(const float* __restrict__
     // a thread counts runs of equal bins privately: scores of neighbouring candidates often share their top bits
     // (every candidate of a random-weight net lands in two or three bins), and LDS atomics on one address serialise
     unsigned cur = 0xffffffffu, run = 0;
-    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
-        const unsigned u = __float_as_uint(sc[i]);
-        if (u >= vbits && !(u & 0x80000000u)) {
-            unsigned bin = 0xffffffffu;
-            if (pass == 0) bin = u >> 21;
-            else if ((u >> 21) == q1) bin = (u >> 10) & 2047u;
-            if (bin != cur) {
-                if (run) atomicAdd(&h[cur], run);
-                cur = bin;
-                run = 0;
+    const bool vec = (reinterpret_cast<unsigned long long>(sc) & 15ull) == 0;
+    for (long long base = i0 + 4 * threadIdx.x; base < i1; base += 4096) {
+        unsigned ub[16];
+        load_score_batch(sc, base, i1, vec, ub);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const unsigned u = ub[e];
+            if (u >= vbits && !(u & 0x80000000u)) {
+                unsigned bin = 0xffffffffu;
+                if (pass == 0) bin = u >> 21;
+                else if ((u >> 21) == q1) bin = (u >> 10) & 2047u;
+                if (bin != cur) {
+                    if (run) atomicAdd(&h[cur], run);
+                    cur = bin;
+                    run = 0;
+                }
+                if (bin != 0xffffffffu) ++run;
             }
-            if (bin != 0xffffffffu) ++run;
         }
     }
     if (run) atomicAdd(&h[cur], run);
@@ -400,22 +511,30 @@ __global__ __launch_bounds__(256) void nms_collect_kernel(const float* __restric
     const float* sc = scores + (long long)b * ncand;
     unsigned long long* out = list + (long long)b * NMS_CAP;
     const long long i0 = blockIdx.x * per_block, i1 = min(i0 + per_block, ncand);
-    for (long long base = i0; base < i1; base += 256) {
-        const long long i = base + threadIdx.x;
-        unsigned u = 0;
-        bool take = false;
-        if (i < i1) {
-            u = __float_as_uint(sc[i]);
-            take = u >= thr && !(u & 0x80000000u);
-        }
-        const unsigned long long bal = __ballot(take);
-        if (bal) {
-            unsigned basepos = 0;
-            const int leader = __ffsll((long long)bal) - 1;
-            if (lane == leader) basepos = atomicAdd(cnt, (unsigned)__popcll(bal));
-            basepos = __shfl(basepos, leader, 64);
-            const unsigned pos = basepos + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-            if (take && pos < NMS_CAP) out[pos] = ((unsigned long long)u << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+    const bool vec = (reinterpret_cast<unsigned long long>(sc) & 15ull) == 0;
+    // (every wave of the block runs the same number of trips: the ballots below are wave-wide)
+    for (long long base0 = i0; base0 < i1; base0 += 4096) {
+        const long long base = base0 + 4 * threadIdx.x;
+        unsigned ub[16];
+        load_score_batch(sc, base, i1, vec, ub);
+        unsigned mine = 0;                                 // bit e: element e of the batch is taken
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mine |= (ub[e] >= thr && !(ub[e] & 0x80000000u)) ? 1u << e : 0u;
+        if (!__ballot(mine != 0)) continue;                // the common case: nothing at or above the threshold in 4096 scores
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const bool take = (mine >> e) & 1u;
+            const unsigned long long bal = __ballot(take);
+            if (bal) {
+                unsigned basepos = 0;
+                const int leader = __ffsll((long long)bal) - 1;
+                if (lane == leader) basepos = atomicAdd(cnt, (unsigned)__popcll(bal));
+                basepos = __shfl(basepos, leader, 64);
+                const unsigned pos = basepos + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+                const long long i = base + 1024 * (e >> 2) + (e & 3);
+                if (take && pos < NMS_CAP)
+                    out[pos] = ((unsigned long long)ub[e] << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+            }
         }
     }
 }
