@@ -22,6 +22,8 @@ import torch
 from yolo_amd import lib as L
 
 PK = os.environ.get('PK_LIB') or os.path.join(L.CSRC, '_ab', 'libyolo_pk.so')        # (PK_LIB: a variant build of the victim)
+TRIG = os.environ.get('TRIG_LIB')        # (a variant build of the co-running convolution, tools/pk_trigger.sh)
+ONLY = os.environ.get('PK_ONLY')         # (only the co-runners whose name contains this)
 
 
 def load(path):
@@ -36,6 +38,7 @@ def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     dev = torch.device('cuda:0')
     ship, pk = L.load(), load(PK)
+    trig = load(TRIG) if TRIG else ship
     g = torch.Generator(device='cpu').manual_seed(3)
     results = {}
     for (N, H, W, Cc) in ((4, 208, 208, 64), (64, 52, 52, 256)):
@@ -105,7 +108,7 @@ def main():
         def co_conv(algo):
             d.algo = algo
             for _ in range(6):
-                L.check(ship.yolo_conv_fwd(C.byref(d), side.cuda_stream), 'conv')
+                L.check(trig.yolo_conv_fwd(C.byref(d), side.cuda_stream), 'conv')
 
         cos = (('alone', co_none), ('beside torch.matmul (hipBLASLt)', co_matmul),
                ('beside a synthetic MFMA spinner', lambda: spin.spin_mfma(vp(spin_src.data_ptr()), vp(spin_out.data_ptr()), 3000, C.c_longlong(spin_src.numel() // 8), vp(side.cuda_stream))),
@@ -117,12 +120,37 @@ def main():
                ('beside a synthetic turnover spinner: short MFMA blocks (4 waves)', lambda: spin.spin_turnover(vp(spin_src.data_ptr()), vp(spin_out.data_ptr()), 3, 100000, 6, C.c_longlong(spin_src.numel() // 8), vp(side.cuda_stream))),
                ('beside a synthetic turnover spinner: short MFMA blocks + 64 KB LDS + barrier', lambda: spin.spin_turnover(vp(spin_src.data_ptr()), vp(spin_out.data_ptr()), 1, 60000, 6, C.c_longlong(spin_src.numel() // 8), vp(side.cuda_stream))),
                ('beside a synthetic turnover spinner: short VALU-only blocks (200 zeroed registers)', lambda: spin.spin_turnover(vp(spin_src.data_ptr()), vp(spin_out.data_ptr()), 2, 800000, 0, C.c_longlong(spin_src.numel() // 8), vp(side.cuda_stream))),
+               ('beside a synthetic DENSE MFMA spinner (16 accumulators, operands in registers), long blocks', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 0, 512, 4000, vp(side.cuda_stream))),
+               ('beside a synthetic DENSE MFMA spinner, operands from LDS, long blocks', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 1, 512, 4000, vp(side.cuda_stream))),
+               ('beside a synthetic DENSE MFMA spinner, operands from LDS + barrier, long blocks', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 2, 512, 4000, vp(side.cuda_stream))),
+               ('beside a synthetic DENSE MFMA spinner, operands from LDS + barrier, short blocks', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 2, 40000, 50, vp(side.cuda_stream))),
+               ('beside a synthetic DENSE MFMA spinner, LDS reads + writes + two barriers, long blocks', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 3, 512, 4000, vp(side.cuda_stream))),
+               ('beside a synthetic DENSE MFMA spinner, LDS reads + writes + two barriers, short blocks', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 3, 40000, 50, vp(side.cuda_stream))),
+               ('beside a synthetic MFMA spinner, each MFMA on JUST-READ LDS fragments (read, wait, use), long blocks', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 4, 512, 3000, vp(side.cuda_stream))),
+               ('beside a synthetic MFMA spinner, each MFMA on JUST-READ LDS fragments, next reads in flight, long blocks', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 5, 512, 3000, vp(side.cuda_stream))),
+               ('beside a synthetic MFMA spinner, each MFMA on JUST-READ LDS fragments, next reads in flight, short blocks', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 5, 40000, 40, vp(side.cuda_stream))),
+               ('beside a synthetic MFMA spinner in the REAL LOOP SHAPE (4 accumulators, swizzled 64-byte-row reads, 2 barriers), long blocks', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 6, 512, 600, vp(side.cuda_stream))),
+               ('beside a synthetic MFMA spinner in the REAL LOOP SHAPE, short blocks (676 x 12 steps)', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 6, 676 * 6, 12, vp(side.cuda_stream))),
+               ('beside a synthetic MFMA spinner in the REAL LOOP SHAPE, reads with 4-way BANK CONFLICTS, long blocks', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 7, 512, 600, vp(side.cuda_stream))),
+               ('beside a synthetic MFMA spinner in the REAL LOOP SHAPE, reads with 4-way BANK CONFLICTS, short blocks', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 7, 676 * 6, 12, vp(side.cuda_stream))),
+               ('beside a synthetic MFMA spinner in the REAL LOOP SHAPE, rows wrapping after 26 (few BANK CONFLICTS), long blocks', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 8, 512, 600, vp(side.cuda_stream))),
+               ('beside a synthetic MFMA spinner in the REAL LOOP SHAPE, rows wrapping after 26 (few BANK CONFLICTS), short blocks', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 8, 676 * 6, 12, vp(side.cuda_stream))),
+               ('beside a synthetic MFMA spinner in the REAL LOOP SHAPE with the real FOOTPRINT (48 KB LDS, 148 + 64 registers), long blocks', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 9, 512, 600, vp(side.cuda_stream))),
+               ('beside a synthetic MFMA spinner in the REAL LOOP SHAPE with the real FOOTPRINT (48 KB LDS, 148 + 64 registers), short blocks', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 9, 676 * 6, 12, vp(side.cuda_stream))),
+               ('beside a synthetic VALU spinner: v_mov_b64 v[n:n+1], 0 (no MFMA, no LDS)', lambda: spin.spin_mov64(vp(spin_out.data_ptr()), 0, 768, 20000, vp(side.cuda_stream))),
+               ('beside a synthetic VALU spinner: v_mov_b64 v[n:n+1], 1.0', lambda: spin.spin_mov64(vp(spin_out.data_ptr()), 1, 768, 20000, vp(side.cuda_stream))),
+               ('beside a synthetic VALU spinner: the same zeros by v_mov_b32 pairs (control for v_mov_b64)', lambda: spin.spin_mov64(vp(spin_out.data_ptr()), 2, 768, 20000, vp(side.cuda_stream))),
+               ('beside a synthetic MFMA spinner, REAL LOOP SHAPE + FOOTPRINT + v_mov_b64 zero fills, long blocks', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 10, 512, 600, vp(side.cuda_stream))),
+               ('beside a synthetic MFMA spinner, REAL LOOP SHAPE + FOOTPRINT + v_mov_b64 zero fills, short blocks', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 10, 676 * 6, 12, vp(side.cuda_stream))),
+               ('beside a synthetic DENSE MFMA spinner (operands in registers), short blocks', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 0, 40000, 50, vp(side.cuda_stream))),
                ('beside yolo_conv_fwd 3x3, generic kernel (register-staged MFMA)', lambda: co_conv(1)),
                ('beside yolo_conv_fwd 3x3, pipelined kernel (LDS-DMA + MFMA)', lambda: co_conv(4)),
                ('beside yolo_conv_wgrad 1x1 (GEMM / per-tap kernel)', lambda: wg(wx, wdw1, 128, 1)),
                ('beside yolo_conv_wgrad 3x3 Cin 32 (strip kernel)', lambda: wg(wx32, wdw32, 32, 3)),
                ('beside yolo_conv_wgrad 3x3 (row walk)', lambda: wg(wx, wdw, 128, 3)))
-        for lib_name, lib in (('packed', pk), ('shipped', ship)):
+        if ONLY:
+            cos = tuple(c for c in cos if ONLY in c[0])
+        for lib_name, lib in (('packed', pk),) if ONLY else (('packed', pk), ('shipped', ship)):
             for co_name, co in cos:
                 bad = zeros = events = 0
                 lanes = {}

@@ -27,7 +27,8 @@ def main():
     g = torch.Generator(device='cpu').manual_seed(5)
     a = torch.randn((n, 2), generator=g).to(dev)
     b = torch.randn((n, 2), generator=g).to(dev)
-    want = {0: torch.stack([a[:, 1], b[:, 0]], dim=1), 1: a * b, 2: a - b, 3: a * b, 4: a * b, 5: torch.stack([a[:, 1], a[:, 0]], dim=1), 6: torch.stack([(a * b)[:, 1], (a * b)[:, 0]], dim=1), 7: a * b}
+    want = {0: torch.stack([a[:, 1], b[:, 0]], dim=1), 1: a * b, 2: a - b, 3: a * b, 4: a * b, 5: torch.stack([a[:, 1], a[:, 0]], dim=1), 6: torch.stack([(a * b)[:, 1], (a * b)[:, 0]], dim=1), 7: a * b,
+            8: torch.stack([(a * b)[:, 1], (a * b)[:, 0]], dim=1), 9: torch.stack([a[:, 1], a[:, 0]], dim=1)}
     side = torch.cuda.Stream(device=dev)
     wx = torch.randn((8, 104, 104, 128), device=dev).to(torch.bfloat16)
     wdy = torch.randn((8, 104, 104, 128), device=dev).to(torch.bfloat16)
@@ -56,11 +57,16 @@ def main():
         with torch.cuda.stream(side):
             torch.matmul(ma, ma)
 
+    spin_out = torch.zeros(1 << 16, device=dev)
+    only = os.environ.get('PK_FORMS')          # e.g. PK_FORMS=8,9,6,5
     cos = (('alone', lambda: None), ('beside torch.matmul', co_matmul), ('beside yolo_conv_fwd generic', lambda: co_conv(1)),
+           ('beside spin_dense 10 (MFMA + v_mov_b64 0)', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 10, 676 * 6, 12, vp(side.cuda_stream))),
+           ('beside spin_dense 9 (MFMA only)', lambda: spin.spin_dense(vp(spin_out.data_ptr()), 9, 676 * 6, 12, vp(side.cuda_stream))),
            ('beside yolo_conv_fwd pipelined', lambda: co_conv(4)), ('beside yolo_conv_wgrad row walk', co_wgrad))
     names = {0: 'v_pk_mov_b32 op_sel:[1,0]', 1: 'v_pk_mul_f32', 2: 'v_pk_add_f32 neg_lo/neg_hi', 3: 'v_pk_mul_f32 ; v_mov_b64 src', 4: 'v_pk_mul_f32 ; s_nop 7 ; v_mov_b64', 5: 'v_pk_mov_b32 d, s, s op_sel:[1,0]',
-             6: 'v_pk_mul_f32 t ; v_pk_mov_b32 d, t, t', 7: '8 x {load ; pk_mul ; pk_mov swap}'}
-    for form in (7, 5, 6, 3, 4, 0, 1, 2):
+             6: 'v_pk_mul_f32 t ; v_pk_mov_b32 d, t, t', 7: '8 x {load ; pk_mul ; pk_mov swap}',
+             8: 'form 6 in a 254-register wave', 9: 'form 5 in a 254-register wave'}
+    for form in ([int(x) for x in only.split(',')] if only else (8, 9, 7, 5, 6, 3, 4, 0, 1, 2)):
         for cname, co in cos:
             bad = events = lo = lane48 = zeros = 0
             for r in range(rounds):

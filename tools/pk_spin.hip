@@ -100,7 +100,11 @@ __global__ __launch_bounds__(256) void k_pkform(const f2v* __restrict__ a, const
         // forms 5 / 6: the half-swap hipcc emits to re-pair packed results -- BOTH sources the same register pair:
         // v_pk_mov_b32 vdst, v[n:n+1], v[n:n+1] op_sel:[1,0] -> (hi, lo); form 6 feeds it straight from a packed multiply
         if (FORM == 5) asm volatile("v_pk_mov_b32 %0, %1, %1 op_sel:[1,0]" : "=v"(r) : "v"(va));
-        if (FORM == 6) {
+        // forms 8 / 9: forms 6 / 5 in a wave that owns 254 registers, like the BatchNorm kernel (the small-footprint forms share a
+        // SIMD with TWO waves of the convolution; a 254-register wave shares it with ONE and sits in the upper half of the file)
+        if (FORM == 8 || FORM == 9) asm volatile("" ::: "v253");
+        if (FORM == 9) asm volatile("v_pk_mov_b32 %0, %1, %1 op_sel:[1,0]" : "=v"(r) : "v"(va));
+        if (FORM == 6 || FORM == 8) {
             f2v t;
             asm volatile("v_pk_mul_f32 %0, %2, %3\n\tv_pk_mov_b32 %1, %0, %0 op_sel:[1,0]" : "=&v"(t), "=v"(r) : "v"(va), "v"(vb));
         }
@@ -141,7 +145,9 @@ extern "C" int victim_pkform(const void* a, const void* b, void* out, long long 
     else if (form == 4) k_pkform<4><<<1024, 256, 0, s>>>((const f2v*)a, (const f2v*)b, (f2v*)out, n);
     else if (form == 5) k_pkform<5><<<1024, 256, 0, s>>>((const f2v*)a, (const f2v*)b, (f2v*)out, n);
     else if (form == 6) k_pkform<6><<<1024, 256, 0, s>>>((const f2v*)a, (const f2v*)b, (f2v*)out, n);
-    else k_pkform<7><<<1024, 256, 0, s>>>((const f2v*)a, (const f2v*)b, (f2v*)out, n);
+    else if (form == 7) k_pkform<7><<<1024, 256, 0, s>>>((const f2v*)a, (const f2v*)b, (f2v*)out, n);
+    else if (form == 8) k_pkform<8><<<1024, 256, 0, s>>>((const f2v*)a, (const f2v*)b, (f2v*)out, n);
+    else k_pkform<9><<<1024, 256, 0, s>>>((const f2v*)a, (const f2v*)b, (f2v*)out, n);
     return (int)hipGetLastError();
 }
 // Register-file poison: every wave writes `bits` into v1..v255 and a0..a255 of its SIMD's register file and exits; VGPRs are not
@@ -707,6 +713,176 @@ __global__ __launch_bounds__(256) void k_turnover(const uint4* __restrict__ src,
     for (int k = 0; k < 8; ++k) sacc += acc[k][threadIdx.x & 15];
     if (KIND == 1) sacc += lds[threadIdx.x];
     if (sacc == 12345.678f) out[0] = sacc;
+}
+// DENSE MFMA co-runners (round 3, after tools/pk_trigger.sh): of the generic convolution kernel, the K loop alone is the trigger,
+// it stops being one without its MFMAs, and it stays one with its global loads cut out (MFMAs on zeros from LDS).  k_mfma above
+// waits for a global load per eight MFMAs -- its matrix pipe idles ~90 % of the time.  Here the pipe is kept full, as the real
+// loop keeps it: kind 0: 16 independent accumulators, operands constant in registers; 1: operands re-read from LDS
+// (ds_read_b128) before every group of MFMAs; 2: kind 1 + a barrier per step; 3: kind 2 + LDS writes and a second barrier;
+// 4 / 5: every MFMA consumes fragments that have just come back from LDS (below)
+template <int KIND>
+__global__ __launch_bounds__(256) void k_dense(float* __restrict__ out, int iters) {
+    // 9: kind 6 with the real kernel's FOOTPRINT: 48 KB of LDS and 148 + 64 registers (two blocks per CU, two of its waves per
+    //    SIMD, which leaves the victim's waves the same room the real kernel leaves them)
+    __shared__ __attribute__((aligned(16))) uint4 lds[KIND >= 9 ? 3072 : 2048];
+    for (int i = threadIdx.x; i < 2048; i += 256) lds[i] = make_uint4(0x3c003c00u + i, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+    if (KIND >= 9) {
+        lds[2048 + threadIdx.x] = make_uint4(1, 2, 3, 4);
+        asm volatile("" ::: "v147");
+    }
+    __syncthreads();
+    f16v acc[16];
+    unsigned zsum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    uint4 a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = lds[(threadIdx.x + 64 * j) & 2047]; b[j] = lds[(threadIdx.x * 3 + 17 * j) & 2047]; }
+    for (int it = 0; it < iters; ++it) {
+        if (KIND >= 6) {
+            // the real loop's shape: FOUR accumulators (dependent chains), four fragment reads per four MFMAs at the real kernel's
+            // addresses (64-byte rows, 16-byte half chosen by lane >> 5, XOR-swizzled by the row), 18 groups, then two barriers
+            const int l31 = threadIdx.x & 31, h = (threadIdx.x & 63) >> 5;
+            // 7: the same rows WITHOUT the swizzle (rows s and s + 4 on the same banks: 4-way conflicts in every read);
+            // 8: swizzled, but the 32 rows of a fragment wrap to the next image row after 26 (slot + 2), as a 3x3 tile's pixel
+            //    rows do in the staged halo -- a few 2-way conflicts
+            const int slot = KIND == 8 ? l31 + (l31 >= 26 ? 2 : 0) : l31;
+            const int base = slot * 64 + ((KIND == 7 ? h : (h ^ ((slot >> 2) & 3))) << 4) + (threadIdx.x >> 6) * 2048;
+            const char* L = reinterpret_cast<const char*>(lds);
+#pragma unroll
+            for (int g = 0; g < 18; ++g) {
+                const int o = ((g * 4096) & 16383) ^ ((g & 1) * 32);
+                const uint4 a0 = *(const uint4*)(L + ((base + o) & 32767)), a1 = *(const uint4*)(L + ((base + o + 2048) & 32767));
+                const uint4 b0 = *(const uint4*)(L + ((base + o + 8192) & 32767)), b1 = *(const uint4*)(L + ((base + o + 10240) & 32767));
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a0), __builtin_bit_cast(bf8, b0), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a0), __builtin_bit_cast(bf8, b1), acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a1), __builtin_bit_cast(bf8, b0), acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a1), __builtin_bit_cast(bf8, b1), acc[3], 0, 0, 0);
+                if (KIND == 10) {                          // 10: kind 9 + the zero fills (v_mov_b64 v[n:n+1], 0) the real loop interleaves
+                    unsigned long long z0, z1;
+                    asm volatile("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0" : "=v"(z0), "=v"(z1));
+                    zsum += (unsigned)z0 + (unsigned)(z1 >> 32);
+                }
+            }
+            __syncthreads();
+            __syncthreads();
+            continue;
+        }
+        if (KIND == 4) {
+            // every MFMA consumes a fragment pair that has JUST come back from LDS (read, wait, use -- eight times per trip)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint4 av = lds[(threadIdx.x + 64 * j + it) & 2047], bv = lds[(threadIdx.x * 3 + 17 * j + it) & 2047];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, av), __builtin_bit_cast(bf8, bv), acc[j], 0, 0, 0);
+                acc[j + 8] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, bv), __builtin_bit_cast(bf8, av), acc[j + 8], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            continue;
+        }
+        if (KIND == 5) {
+            // the same with the NEXT pair's reads in flight while a pair's MFMAs issue (counted lgkmcnt waits, as the real loop has)
+            uint4 av = lds[(threadIdx.x + it) & 2047], bv = lds[(threadIdx.x * 3 + it) & 2047];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint4 an = lds[(threadIdx.x + 64 * (j + 1) + it) & 2047], bn = lds[(threadIdx.x * 3 + 17 * (j + 1) + it) & 2047];
+                __builtin_amdgcn_sched_barrier(0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, av), __builtin_bit_cast(bf8, bv), acc[j], 0, 0, 0);
+                acc[j + 8] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, bv), __builtin_bit_cast(bf8, av), acc[j + 8], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                av = an; bv = bn;
+            }
+            continue;
+        }
+        if (KIND >= 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = lds[(threadIdx.x + 64 * j + it) & 2047];
+                b[j] = lds[(threadIdx.x * 3 + 17 * j + it) & 2047];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a[i]), __builtin_bit_cast(bf8, b[j]),
+                                                                         acc[i * 4 + j], 0, 0, 0);
+        if (KIND >= 2) __syncthreads();
+        if (KIND == 3) {                                   // the real loop's LDS refill: every thread writes 3 x 16 bytes, then a second barrier
+#pragma unroll
+            for (int j = 0; j < 3; ++j) lds[(threadIdx.x + 256 * j + it) & 2047] = a[j];
+            __syncthreads();
+        }
+    }
+    float sacc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sacc += acc[k][threadIdx.x & 15];
+    if (sacc == 12345.678f || zsum == 77u) out[0] = sacc;
+}
+// 64-BIT MOVES (round 3): what the real kernels' K loops have and none of the spinners above: `v_mov_b64 v[n:n+1], 0` -- the
+// zero fill of a staged 16-byte unit whose source pixel is padding (`uint4 v = 0; if (valid) v = load`) -- in every step.
+// kind 0: eight v_mov_b64 of zero per trip, nothing else; 1: v_mov_b64 of a non-zero constant pair (0x3f800000); 2: the same
+// zero written by two v_mov_b32 (the control)
+template <int KIND>
+__global__ __launch_bounds__(256) void k_mov64(float* __restrict__ out, int iters) {
+    typedef unsigned long long u64;
+    u64 r[8];
+    unsigned acc = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (KIND == 0) asm volatile("v_mov_b64 %0, 0" : "=v"(r[k]));
+            else if (KIND == 1) asm volatile("v_mov_b64 %0, 1.0" : "=v"(r[k]));
+            else { unsigned lo, hi; asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0" : "=v"(lo), "=v"(hi)); r[k] = ((u64)hi << 32) | lo; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += (unsigned)r[k] + (unsigned)(r[k] >> 32);
+    }
+    if (acc == 0x12345678u) out[0] = 1.f;
+}
+extern "C" int spin_mov64(void* out, int kind, int nblocks, int iters, void* st) {
+    hipStream_t s = (hipStream_t)st;
+    if (kind == 0) k_mov64<0><<<nblocks, 256, 0, s>>>((float*)out, iters);
+    else if (kind == 1) k_mov64<1><<<nblocks, 256, 0, s>>>((float*)out, iters);
+    else k_mov64<2><<<nblocks, 256, 0, s>>>((float*)out, iters);
+    return (int)hipGetLastError();
+}
+// SENTINEL victim (round 3): no packed operation at all.  A wave fills 224 VGPRs with known per-register, per-lane values, idles
+// (s_sleep) while the co-runner works beside it on the SIMD, and then checks every register: a register that changed was WRITTEN
+// by someone else.  All registers are stored ([block][register][lane]); the host compares.
+constexpr int NSENT = 224;
+// (pure assembly, so that exactly v16..v239 hold the sentinels and nothing spills: pk_sentinel_body.inc / _clobbers.inc are
+// generated -- one v_add_u32 per register, an s_sleep loop, one global_store_dword per register)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sentinel(unsigned* __restrict__ out, int naps) {
+    unsigned* dst = out + (size_t)blockIdx.x * NSENT * 64;
+    unsigned off = threadIdx.x * 4, lane = threadIdx.x;
+    asm volatile(
+#include "pk_sentinel_body.inc"
+        : [off] "+v"(off)
+        : [lane] "v"(lane), [naps] "s"(naps), [dst] "s"(dst)
+        :
+#include "pk_sentinel_clobbers.inc"
+    );
+}
+extern "C" int victim_sentinel(void* out, int nblocks, int naps, void* st) {
+    k_sentinel<<<nblocks, 64, 0, (hipStream_t)st>>>((unsigned*)out, naps);
+    return (int)hipGetLastError();
+}
+extern "C" int spin_dense(void* out, int kind, int nblocks, int iters, void* st) {
+    hipStream_t s = (hipStream_t)st;
+    if (kind == 0) k_dense<0><<<nblocks, 256, 0, s>>>((float*)out, iters);
+    else if (kind == 1) k_dense<1><<<nblocks, 256, 0, s>>>((float*)out, iters);
+    else if (kind == 2) k_dense<2><<<nblocks, 256, 0, s>>>((float*)out, iters);
+    else if (kind == 3) k_dense<3><<<nblocks, 256, 0, s>>>((float*)out, iters);
+    else if (kind == 4) k_dense<4><<<nblocks, 256, 0, s>>>((float*)out, iters);
+    else if (kind == 5) k_dense<5><<<nblocks, 256, 0, s>>>((float*)out, iters);
+    else if (kind == 6) k_dense<6><<<nblocks, 256, 0, s>>>((float*)out, iters);
+    else if (kind == 7) k_dense<7><<<nblocks, 256, 0, s>>>((float*)out, iters);
+    else if (kind == 8) k_dense<8><<<nblocks, 256, 0, s>>>((float*)out, iters);
+    else if (kind == 9) k_dense<9><<<nblocks, 256, 0, s>>>((float*)out, iters);
+    else k_dense<10><<<nblocks, 256, 0, s>>>((float*)out, iters);
+    return (int)hipGetLastError();
 }
 extern "C" int spin_turnover(const void* src, void* out, int kind, int nblocks, int iters, long long n16, void* st) {
     hipStream_t s = (hipStream_t)st;
