@@ -23,7 +23,9 @@ int wgrad_gemm_dispatch(const void*, const void*, float*, long long, int, int, l
 typedef float f16v_ __attribute__((ext_vector_type(16)));
 typedef __bf16 bf8_ __attribute__((ext_vector_type(8)));
 
-template <int MOV64>
+// MOV: 0 none; 1 `v_mov_b64 v[n:n+1], 0`; 2 `v_mov_b64 v[n:n+1], v[m:m+1]` of a recognisable non-zero pair (0x40490fdb twice);
+//      3 the same zeros written by two v_mov_b32 (control).   MFMA / LDSR: 0 leaves the MFMAs / the LDS fragment reads out.
+template <int MOV, int MFMA, int LDSR>
 __global__ __launch_bounds__(256) void trigger_kernel(float* __restrict__ out, int iters) {
     __shared__ __attribute__((aligned(16))) uint4 lds[3072];
     for (int i = threadIdx.x; i < 3072; i += 256) lds[i] = make_uint4(0x3c003c00u + i, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
@@ -38,21 +40,34 @@ __global__ __launch_bounds__(256) void trigger_kernel(float* __restrict__ out, i
     const int l31 = threadIdx.x & 31, h = (threadIdx.x & 63) >> 5;
     const int base = l31 * 64 + ((h ^ ((l31 >> 2) & 3)) << 4) + (threadIdx.x >> 6) * 2048;
     const char* L = reinterpret_cast<const char*>(lds);
+    unsigned long long pat = 0x40490fdb40490fdbull;
+    asm volatile("" : "+v"(pat));
+    uint4 a0 = lds[threadIdx.x], a1 = lds[threadIdx.x + 256], b0 = lds[threadIdx.x + 512], b1 = lds[threadIdx.x + 768];
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int g = 0; g < 18; ++g) {
             const int o = ((g * 4096) & 16383) ^ ((g & 1) * 32);
-            const uint4 a0 = *(const uint4*)(L + ((base + o) & 32767)), a1 = *(const uint4*)(L + ((base + o + 2048) & 32767));
-            const uint4 b0 = *(const uint4*)(L + ((base + o + 8192) & 32767)), b1 = *(const uint4*)(L + ((base + o + 10240) & 32767));
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_, a0), __builtin_bit_cast(bf8_, b0), acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_, a0), __builtin_bit_cast(bf8_, b1), acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_, a1), __builtin_bit_cast(bf8_, b0), acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_, a1), __builtin_bit_cast(bf8_, b1), acc[3], 0, 0, 0);
-            if (MOV64) {
-                unsigned long long z0, z1;
-                asm volatile("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0" : "=v"(z0), "=v"(z1));
-                zsum += (unsigned)z0 + (unsigned)(z1 >> 32);
+            if (LDSR) {
+                a0 = *(const uint4*)(L + ((base + o) & 32767)); a1 = *(const uint4*)(L + ((base + o + 2048) & 32767));
+                b0 = *(const uint4*)(L + ((base + o + 8192) & 32767)); b1 = *(const uint4*)(L + ((base + o + 10240) & 32767));
             }
+            if (MFMA) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_, a0), __builtin_bit_cast(bf8_, b0), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_, a0), __builtin_bit_cast(bf8_, b1), acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_, a1), __builtin_bit_cast(bf8_, b0), acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_, a1), __builtin_bit_cast(bf8_, b1), acc[3], 0, 0, 0);
+            } else {
+                zsum += a0.x ^ b0.y ^ a1.z ^ b1.w;
+            }
+            unsigned long long z0 = 0, z1 = 0;
+            if (MOV == 1) asm volatile("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0" : "=v"(z0), "=v"(z1));
+            if (MOV == 2) asm volatile("v_mov_b64 %0, %2\n\tv_mov_b64 %1, %2" : "=v"(z0), "=v"(z1) : "v"(pat));
+            if (MOV == 3) {
+                unsigned q0, q1, q2, q3;
+                asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3));
+                z0 = q0 | ((unsigned long long)q1 << 32); z1 = q2 | ((unsigned long long)q3 << 32);
+            }
+            if (MOV) zsum += (unsigned)z0 + (unsigned)(z1 >> 32);
         }
         __syncthreads();
         __syncthreads();
@@ -63,11 +78,122 @@ __global__ __launch_bounds__(256) void trigger_kernel(float* __restrict__ out, i
     if (sacc == 12345.678f || zsum == 77u) out[0] = sacc;
 }
 
+// SYNTHETIC VICTIM (--chain): the first instructions of the packed bn_apply_kernel, verbatim from its ISA with fixed registers:
+// four 16-byte loads of doubles, counted waits, v_cvt_f32_f64, v_pk_mul_f32 by an SGPR pair, the re-pairing
+// v_pk_mov_b32 d, s, s op_sel:[1,0], then everything is stored.  A thread's 16 output floats are [the four products pairs
+// v98..v105][the four swapped pairs v124..v131]; the host checks them against the same launch run alone AND against each other
+// (v124 must equal v105, ...: tells a wrong swap from a wrong product).  254 registers per wave, like the real kernel.
+__global__ __launch_bounds__(256) void chain_kernel(const double* __restrict__ src, float* __restrict__ dst, float factor, int reps, long long nthreads) {
+    const long long t = blockIdx.x * 256LL + threadIdx.x;
+    unsigned long long f2 = ((unsigned long long)__float_as_uint(factor) << 32) | __float_as_uint(factor);
+    f2 = __builtin_amdgcn_readfirstlane((unsigned)f2) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(f2 >> 32)) << 32);
+    for (int r = 0; r < reps; ++r) {
+        const double* p = src + ((t + (long long)r * nthreads) * 8);
+        float* q = dst + ((t + (long long)r * nthreads) * 16);
+        asm volatile(
+            "global_load_dwordx4 v[98:101], %[p], off\n\t"
+            "global_load_dwordx4 v[106:109], %[p], off offset:16\n\t"
+            "global_load_dwordx4 v[110:113], %[p], off offset:32\n\t"
+            "global_load_dwordx4 v[114:117], %[p], off offset:48\n\t"
+            "s_waitcnt vmcnt(3)\n\t"
+            "v_cvt_f32_f64_e32 v33, v[98:99]\n\t"
+            "v_cvt_f32_f64_e32 v32, v[100:101]\n\t"
+            "s_waitcnt vmcnt(2)\n\t"
+            "v_cvt_f32_f64_e32 v35, v[106:107]\n\t"
+            "v_cvt_f32_f64_e32 v34, v[108:109]\n\t"
+            "s_waitcnt vmcnt(1)\n\t"
+            "v_cvt_f32_f64_e32 v37, v[110:111]\n\t"
+            "v_cvt_f32_f64_e32 v36, v[112:113]\n\t"
+            "s_waitcnt vmcnt(0)\n\t"
+            "v_cvt_f32_f64_e32 v39, v[114:115]\n\t"
+            "v_cvt_f32_f64_e32 v38, v[116:117]\n\t"
+            "v_pk_mul_f32 v[98:99], %[f], v[32:33]\n\t"
+            "v_pk_mul_f32 v[100:101], %[f], v[34:35]\n\t"
+            "v_pk_mul_f32 v[102:103], %[f], v[36:37]\n\t"
+            "v_pk_mul_f32 v[104:105], %[f], v[38:39]\n\t"
+            "v_pk_mov_b32 v[124:125], v[104:105], v[104:105] op_sel:[1,0]\n\t"
+            "v_pk_mov_b32 v[126:127], v[102:103], v[102:103] op_sel:[1,0]\n\t"
+            "v_pk_mov_b32 v[128:129], v[100:101], v[100:101] op_sel:[1,0]\n\t"
+            "v_pk_mov_b32 v[130:131], v[98:99], v[98:99] op_sel:[1,0]\n\t"
+            "global_store_dwordx4 %[q], v[98:101], off\n\t"
+            "global_store_dwordx4 %[q], v[102:105], off offset:16\n\t"
+            "global_store_dwordx4 %[q], v[124:127], off offset:32\n\t"
+            "global_store_dwordx4 %[q], v[128:131], off offset:48\n\t"
+            "s_waitcnt vmcnt(0)\n\t"
+            :
+            : [p] "v"(p), [q] "v"(q), [f] "s"(f2)
+            : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107",
+              "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v124", "v125", "v126", "v127", "v128", "v129",
+              "v130", "v131", "v253", "memory");
+    }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
 static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
 
+static int chain_main(int rounds) {
+    const int nblocks = 2048, reps = 4;
+    const long long nthreads = nblocks * 256LL, nd = nthreads * reps * 8, nf = nthreads * reps * 16;
+    std::vector<double> hs(nd);
+    unsigned long long s = 0x9e3779b97f4a7c15ull;
+    for (long long i = 0; i < nd; ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; hs[i] = ((double)(s >> 11) / 9007199254740992.0) * 2000.0 - 1000.0; }
+    double* src; float *dst, *tout;
+    CK(hipMalloc(&src, nd * 8)); CK(hipMalloc(&dst, nf * 4)); CK(hipMalloc(&tout, 1 << 18));
+    CK(hipMemcpy(src, hs.data(), nd * 8, hipMemcpyHostToDevice));
+    hipStream_t s1, s2;
+    CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+    std::vector<unsigned> ref(nf), out(nf);
+    chain_kernel<<<nblocks, 256, 0, s1>>>(src, dst, 1.f / 173056.f, reps, nthreads);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(ref.data(), dst, nf * 4, hipMemcpyDeviceToHost));
+    // the reference itself: products against the host's arithmetic, swaps against the products
+    long long refbad = 0;
+    for (long long t = 0; t < nthreads * reps; ++t) {
+        const unsigned* o = &ref[t * 16];
+        for (int k = 0; k < 8; ++k) {
+            const float w = (1.f / 173056.f) * (float)hs[t * 8 + (k ^ 1)];
+            unsigned wb; memcpy(&wb, &w, 4);
+            if (o[k] != wb) ++refbad;
+            if (o[8 + k] != o[7 - k]) ++refbad;
+        }
+    }
+    printf("synthetic victim alone: %lld wrong values of %lld\n", refbad, nf);
+    struct Mode { const char* name; void (*launch)(float*, hipStream_t); };
+    const Mode modes[] = {
+        {"alone", nullptr},
+        {"beside the MFMA loop without VALU work (trigger 9)", [](float* o, hipStream_t st) { trigger_kernel<0, 1, 1><<<676 * 6, 256, 0, st>>>(o, 12); }},
+        {"beside the MFMA loop with v_mov_b64 v[n:n+1], 0 (trigger 10)", [](float* o, hipStream_t st) { trigger_kernel<1, 1, 1><<<676 * 6, 256, 0, st>>>(o, 12); }},
+        {"beside MFMAs + v_mov_b64 0, no LDS reads", [](float* o, hipStream_t st) { trigger_kernel<1, 1, 0><<<676 * 6, 256, 0, st>>>(o, 12); }},
+    };
+    for (const Mode& m : modes) {
+        long long bad = 0, prod = 0, swap = 0, zeros = 0, l48 = 0;
+        int events = 0;
+        for (int r = 0; r < rounds; ++r) {
+            CK(hipMemsetAsync(dst, 0xff, nf * 4, s1));
+            CK(hipDeviceSynchronize());
+            if (m.launch) m.launch(tout, s2);
+            chain_kernel<<<nblocks, 256, 0, s1>>>(src, dst, 1.f / 173056.f, reps, nthreads);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(out.data(), dst, nf * 4, hipMemcpyDeviceToHost));
+            long long k = 0;
+            for (long long i = 0; i < nf; ++i)
+                if (out[i] != ref[i]) {
+                    const long long t = i / 16; const int e = (int)(i % 16);
+                    if (k < 4 && events < 2) printf("    thread %lld (lane %lld) value %d: got %08x want %08x%s\n", t % nthreads, t % 64, e, out[i], ref[i],
+                                                     e >= 8 ? (out[i] == out[t * 16 + 15 - e] ? "  (= its source as stored)" : "  (its source as stored is right)") : "");
+                    ++k; (e < 8 ? prod : swap)++; zeros += out[i] == 0; l48 += (t % 64) >= 48;
+                }
+            if (k) { ++events; bad += k; }
+        }
+        printf("%-62s launches with a mismatch %3d / %d, values %6lld (products %lld, swapped pairs %lld; zeros %lld, lanes 48-63 %lld)\n", m.name, events, rounds, bad,
+               prod, swap, zeros, l48);
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "--chain")) return chain_main(argc > 2 ? atoi(argv[2]) : 10);
     const int rounds = argc > 1 ? atoi(argv[1]) : 20;
     const int N = 64, H = 52, W = 52, C = 256;
     const long long npix = (long long)N * H * W, n = npix * C;
@@ -101,26 +227,41 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     std::vector<unsigned short> href(n), hout(n);
     CK(hipMemcpy(href.data(), ref, n * 2, hipMemcpyDeviceToHost));
-    const char* names[3] = {"alone", "beside the MFMA loop without 64-bit moves (trigger 9)", "beside the MFMA loop with v_mov_b64 v[n:n+1], 0 (trigger 10)"};
+    struct Mode { const char* name; void (*launch)(float*, hipStream_t); };
+#define TRIG(MOV, MFMA, LDSR) [](float* o, hipStream_t st) { trigger_kernel<MOV, MFMA, LDSR><<<676 * 6, 256, 0, st>>>(o, 12); }
+    const Mode modes[] = {
+        {"alone", nullptr},
+        {"beside the MFMA loop without 64-bit moves (trigger 9)", TRIG(0, 1, 1)},
+        {"beside the MFMA loop with v_mov_b64 v[n:n+1], 0 (trigger 10)", TRIG(1, 1, 1)},
+        {"beside the MFMA loop with v_mov_b64 of a NON-ZERO pair 0x40490fdb", TRIG(2, 1, 1)},
+        {"beside the MFMA loop, the zeros by v_mov_b32 pairs (control)", TRIG(3, 1, 1)},
+        {"beside the loop WITHOUT MFMAs, with v_mov_b64 0", TRIG(1, 0, 1)},
+        {"beside the MFMA loop without LDS reads, with v_mov_b64 0", TRIG(1, 1, 0)},
+        {"beside v_mov_b64 0 alone (no MFMA, no LDS reads)", TRIG(1, 0, 0)},
+    };
+    const int nmodes = (int)(sizeof(modes) / sizeof(modes[0]));
     int any10 = 0, anyother = 0;
-    for (int mode = 0; mode < 3; ++mode) {
-        long long bad = 0, zeros = 0, l48 = 0;
+    for (int mode = 0; mode < nmodes; ++mode) {
+        long long bad = 0, zeros = 0, l48 = 0, pi = 0;
         int events = 0;
         for (int r = 0; r < rounds; ++r) {
             CK(hipMemsetAsync(dy, 0xff, n * 2, s1));
             CK(hipDeviceSynchronize());
-            if (mode == 1) trigger_kernel<0><<<676 * 6, 256, 0, s2>>>(tout, 12);
-            if (mode == 2) trigger_kernel<1><<<676 * 6, 256, 0, s2>>>(tout, 12);
+            if (modes[mode].launch) modes[mode].launch(tout, s2);
             bn(dy);
             CK(hipDeviceSynchronize());
             CK(hipMemcpy(hout.data(), dy, n * 2, hipMemcpyDeviceToHost));
             long long k = 0;
             for (long long i = 0; i < n; ++i)
-                if (hout[i] != href[i]) { ++k; zeros += (hout[i] & 0x7fff) == 0; l48 += ((i / 8) % 64) >= 48; }
+                if (hout[i] != href[i]) {
+                    if (events < 1 && mode == 2) printf("    pixel %lld channel %lld (oct %lld, element %lld): got %04x want %04x\n", i / C, i % C, (i % C) / 8, i % 8, hout[i], href[i]);
+                    ++k; zeros += (hout[i] & 0x7fff) == 0; l48 += ((i / 8) % 64) >= 48;
+                }
             if (k) { ++events; bad += k; }
         }
-        printf("%-66s launches with a mismatch %3d / %d, elements %7lld (exact zeros %lld, in lanes 48-63 %lld)\n", names[mode], events, rounds, bad, zeros, l48);
-        if (mode == 2) any10 = events; else anyother += events;
+        printf("%-66s launches with a mismatch %3d / %d, elements %7lld (exact zeros %lld, in lanes 48-63 %lld)\n", modes[mode].name, events, rounds, bad, zeros, l48);
+        if (mode == 2) any10 = events; else if (mode < 2) anyother += events;
+        (void)pi;
     }
     printf(any10 && !anyother ? "REPRODUCED: only beside the co-runner with the 64-bit zero moves\n" : any10 ? "REPRODUCED (see the table)\n" : "NOT REPRODUCED\n");
     return 0;
