@@ -128,6 +128,37 @@ __global__ __launch_bounds__(256) void chain_kernel(const double* __restrict__ s
     }
 }
 
+// SYNTHETIC VICTIM 2 (--pkloop): self-checking packed loops in a 254-register wave, registers as in the real pixel loop.  A thread
+// loads a pair x, applies 64 packed operations that must leave it unchanged (x * 1, x + 0, x - 0) and stores it: out == in, or an
+// operand was read wrong.  VAR 0: v_pk_mul_f32 v[228:229], v[120:121], v[228:229] (both sources start in VGPR bank 0: a bank
+// conflict); 1: v_pk_mul_f32 v[228:229], v[122:123], v[228:229] (banks 2 / 0: none); 2: v_pk_add_f32 v[228:229], v[228:229],
+// v[0:1] neg_lo neg_hi (banks 0 / 0); 3: v_pk_add_f32 v[238:239], v[238:239], v[0:1] neg (banks 2 / 0); 4: alternating 0 and 2
+template <int VAR>
+__global__ __launch_bounds__(256) void pkloop_kernel(const float2* __restrict__ src, float2* __restrict__ dst, int reps, long long nthreads) {
+    const long long t = blockIdx.x * 256LL + threadIdx.x;
+    for (int r = 0; r < reps; ++r) {
+        const float2 x = src[t + (long long)r * nthreads];
+        float2 y;
+#define PK8(op) op op op op op op op op
+#define PK64(op) PK8(op) PK8(op) PK8(op) PK8(op) PK8(op) PK8(op) PK8(op) PK8(op)
+        asm volatile(
+            "v_mov_b32 v228, %[x0]\n\tv_mov_b32 v229, %[x1]\n\tv_mov_b32 v238, %[x0]\n\tv_mov_b32 v239, %[x1]\n\t"
+            "v_mov_b32 v120, 1.0\n\tv_mov_b32 v121, 1.0\n\tv_mov_b32 v122, 1.0\n\tv_mov_b32 v123, 1.0\n\tv_mov_b32 v0, 0\n\tv_mov_b32 v1, 0\n\t"
+            "s_nop 4\n\t"
+            ".if %c[var] == 0\n\t" PK64("v_pk_mul_f32 v[228:229], v[120:121], v[228:229]\n\t") ".endif\n\t"
+            ".if %c[var] == 1\n\t" PK64("v_pk_mul_f32 v[228:229], v[122:123], v[228:229]\n\t") ".endif\n\t"
+            ".if %c[var] == 2\n\t" PK64("v_pk_add_f32 v[228:229], v[228:229], v[0:1] neg_lo:[0,1] neg_hi:[0,1]\n\t") ".endif\n\t"
+            ".if %c[var] == 3\n\t" PK64("v_pk_add_f32 v[238:239], v[238:239], v[0:1] neg_lo:[0,1] neg_hi:[0,1]\n\t") "v_mov_b32 v228, v238\n\tv_mov_b32 v229, v239\n\t" ".endif\n\t"
+            ".if %c[var] == 4\n\t" PK64("v_pk_mul_f32 v[228:229], v[120:121], v[228:229]\n\tv_pk_add_f32 v[228:229], v[228:229], v[0:1] neg_lo:[0,1] neg_hi:[0,1]\n\t") ".endif\n\t"
+            "s_nop 4\n\t"
+            "v_mov_b32 %[y0], v228\n\tv_mov_b32 %[y1], v229\n\t"
+            : [y0] "=v"(y.x), [y1] "=v"(y.y)
+            : [x0] "v"(x.x), [x1] "v"(x.y), [var] "n"(VAR)
+            : "v0", "v1", "v120", "v121", "v122", "v123", "v228", "v229", "v238", "v239", "v253");
+        dst[t + (long long)r * nthreads] = y;
+    }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
 static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
@@ -192,8 +223,52 @@ static int chain_main(int rounds) {
     return 0;
 }
 
+static int pkloop_main(int rounds) {
+    const int nblocks = 2048, reps = 8;
+    const long long nthreads = nblocks * 256LL, nv = nthreads * reps;
+    std::vector<float> hs(nv * 2);
+    unsigned long long s = 0x2545f4914f6cdd1dull;
+    for (long long i = 0; i < nv * 2; ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; hs[i] = (float)(((double)(s >> 11) / 9007199254740992.0) * 8.0 - 4.0) + 0.0078125f; }
+    float2 *src, *dst; float* tout;
+    CK(hipMalloc(&src, nv * 8)); CK(hipMalloc(&dst, nv * 8)); CK(hipMalloc(&tout, 1 << 18));
+    CK(hipMemcpy(src, hs.data(), nv * 8, hipMemcpyHostToDevice));
+    hipStream_t s1, s2;
+    CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+    std::vector<unsigned> out(nv * 2), in(nv * 2);
+    memcpy(in.data(), hs.data(), nv * 8);
+    const char* vnames[5] = {"v_pk_mul_f32 v[228:229], v[120:121], v[228:229] (bank conflict)", "v_pk_mul_f32 v[228:229], v[122:123], v[228:229] (none)",
+                             "v_pk_add_f32 v[228:229], v[228:229], v[0:1] neg (conflict)", "v_pk_add_f32 v[238:239], v[238:239], v[0:1] neg (none)",
+                             "alternating packed multiply and add (conflicts)"};
+    for (int var = 0; var < 5; ++var)
+        for (int mode = 0; mode < 3; ++mode) {
+            long long bad = 0, zeros = 0, l48 = 0, lo = 0;
+            int events = 0;
+            for (int r = 0; r < rounds; ++r) {
+                CK(hipMemsetAsync(dst, 0xff, nv * 8, s1));
+                CK(hipDeviceSynchronize());
+                if (mode == 1) trigger_kernel<1, 1, 1><<<676 * 6, 256, 0, s2>>>(tout, 12);
+                if (mode == 2) trigger_kernel<1, 1, 0><<<676 * 6, 256, 0, s2>>>(tout, 12);
+                if (var == 0) pkloop_kernel<0><<<nblocks, 256, 0, s1>>>(src, dst, reps, nthreads);
+                if (var == 1) pkloop_kernel<1><<<nblocks, 256, 0, s1>>>(src, dst, reps, nthreads);
+                if (var == 2) pkloop_kernel<2><<<nblocks, 256, 0, s1>>>(src, dst, reps, nthreads);
+                if (var == 3) pkloop_kernel<3><<<nblocks, 256, 0, s1>>>(src, dst, reps, nthreads);
+                if (var == 4) pkloop_kernel<4><<<nblocks, 256, 0, s1>>>(src, dst, reps, nthreads);
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(out.data(), dst, nv * 8, hipMemcpyDeviceToHost));
+                long long k = 0;
+                for (long long i = 0; i < nv * 2; ++i)
+                    if (out[i] != in[i]) { ++k; zeros += (out[i] & 0x7fffffffu) == 0; l48 += ((i / 2) % 64) >= 48; lo += (i & 1) == 0; }
+                if (k) { ++events; bad += k; }
+            }
+            printf("%-70s %-34s launches with a mismatch %2d / %d, values %6lld (zeros %lld, lanes 48-63 %lld, low element %lld)\n", vnames[var],
+                   mode == 0 ? "alone" : mode == 1 ? "beside trigger 10" : "beside MFMAs + v_mov_b64, no LDS", events, rounds, bad, zeros, l48, lo);
+        }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc > 1 && !strcmp(argv[1], "--chain")) return chain_main(argc > 2 ? atoi(argv[2]) : 10);
+    if (argc > 1 && !strcmp(argv[1], "--pkloop")) return pkloop_main(argc > 2 ? atoi(argv[2]) : 5);
     const int rounds = argc > 1 ? atoi(argv[1]) : 20;
     const int N = 64, H = 52, W = 52, C = 256;
     const long long npix = (long long)N * H * W, n = npix * C;
