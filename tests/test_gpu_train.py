@@ -91,6 +91,45 @@ def test_loss_grad_wrt_logits(cuda):
     _close(dl.cpu().numpy().reshape(gout.shape), gout, 1e-4, 'dlogits')
 
 
+@pytest.mark.parametrize('n,offset', [(4099, 0), (4099, 1), (3, 0), (8, 3)])
+def test_adam_c_abi_vector_and_unaligned(cuda, n, offset):
+    """yolo_adam_step / yolo_adam_step_dev straight through the C ABI, on arrays of any length and alignment: the host-scalar and
+    the device-slot rescale give the same bits, nothing outside the n elements is touched, and the values are the oracle's."""
+    import ctypes as C
+    from yolo_amd import lib as L
+    lib = L.load()
+    rng = np.random.default_rng(n + offset)
+    host = [rng.standard_normal(n).astype(np.float32) for _ in range(3)] + [np.abs(rng.standard_normal(n)).astype(np.float32)]
+    def run(off, dev_slot):
+        bufs = [torch.zeros(n + 8, device=cuda) for _ in range(4)]
+        views = [b[off:off + n] for b in bufs]
+        for vw, h in zip(views, host):
+            vw.copy_(torch.from_numpy(h))
+        w, g, m, v = views
+        st = torch.cuda.current_stream().cuda_stream
+        if dev_slot:
+            gb = torch.full((1,), 4.0, device=cuda)
+            rc = lib.yolo_adam_step_dev(w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, 3, C.c_float(1e-3), C.c_float(0.9),
+                                        C.c_float(0.999), C.c_float(1e-8), gb.data_ptr(), st)
+        else:
+            rc = lib.yolo_adam_step(w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, 3, C.c_float(1e-3), C.c_float(0.9),
+                                    C.c_float(0.999), C.c_float(1e-8), C.c_float(0.25), st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        for b, vw in zip(bufs, views):                     # nothing outside the n elements is touched
+            assert float(b[:off].abs().sum()) == 0 and float(b[off + n:].abs().sum()) == 0
+        return [x.cpu().numpy().copy() for x in (w, m, v)]
+    ref = run(0, False)
+    for got in (run(offset, False), run(offset, True)):
+        for a_, b_ in zip(got, ref):
+            assert np.array_equal(a_.view(np.int32), b_.view(np.int32))
+    w, g, m, v = (h.copy() for h in host)
+    ot.adam_step(w, g, m, v, 3, lr=1e-3, rescale=0.25)
+    np.testing.assert_allclose(ref[0], w, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(ref[1], m, rtol=1e-5, atol=1e-7)     # (1.f - beta in fp32 on the device, in double in the oracle)
+    np.testing.assert_allclose(ref[2], v, rtol=1e-5, atol=1e-8)
+
+
 def test_adam_update_and_second_step(cuda):
     spec, size, g, P, x, lab, net, tr = _setup(cuda)
     xt, lt = torch.from_numpy(x).to(cuda), torch.from_numpy(lab).to(cuda)

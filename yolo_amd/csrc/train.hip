@@ -1441,52 +1441,47 @@ extern "C" int yolo_add(const void* a, const void* b, void* y, long long n, int 
 // MXNet Adam: g = rescale*grad; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // w -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)       (epsilon OUTSIDE the bias correction)
 // ------------------------------------------------------------------------------------------------
-__global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long long n, float lr_t, float b1, float b2, float eps,
-                            float rescale) {
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float gr = g[i] * rescale;
-    const float mi = b1 * m[i] + (1.f - b1) * gr;
-    const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
-    m[i] = mi;
-    v[i] = vi;
-    w[i] = w[i] - lr_t * mi / (sqrtf(vi) + eps);
+// One element per thread ON PURPOSE: seven streams (four read, three written, 1.7 GB for Darknet-53) -- four elements per thread
+// with 16-byte accesses were measured 10 % SLOWER (591 against 539 us on one box, round 3).
+__device__ __forceinline__ void adam_one(float& w, float g, float& m, float& v, float lr_t, float b1, float b2, float eps, float rescale) {
+    const float gr = g * rescale;
+    const float mi = b1 * m + (1.f - b1) * gr;
+    const float vi = b2 * v + (1.f - b2) * gr * gr;
+    m = mi;
+    v = vi;
+    w = w - lr_t * mi / (sqrtf(vi) + eps);
 }
 
-// The same update with the rescale taken on the device: rescale = 1 / *global_batch_dev, a float the caller's gradient
-// exchange has just SUM-reduced over the ranks (each rank contributes its shard size in a slot of the last gradient
-// bucket) -- no collective of its own, no host read, and no per-rank decision whether to issue one.
-__global__ void adam_dev_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
-                                float* __restrict__ v, long long n, float lr_t, float b1, float b2, float eps,
-                                const float* __restrict__ gb) {
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float rescale = 1.f / gb[0];
-    const float gr = g[i] * rescale;
-    const float mi = b1 * m[i] + (1.f - b1) * gr;
-    const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
-    m[i] = mi;
-    v[i] = vi;
-    w[i] = w[i] - lr_t * mi / (sqrtf(vi) + eps);
+template <bool DEV>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n, float lr_t, float b1, float b2, float eps,
+                                                   float rescale_host, const float* __restrict__ gb) {
+    // DEV: rescale = 1 / *gb, a float the caller's gradient exchange has just SUM-reduced over the ranks (each rank contributes its
+    // shard size in a slot of the last gradient bucket) -- no collective of its own, no host read, no per-rank decision
+    const float rescale = DEV ? 1.f / gb[0] : rescale_host;
+    const long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (k < n) adam_one(w[k], g[k], m[k], v[k], lr_t, b1, b2, eps, rescale);
+}
+
+static int adam_launch(float* w, const float* grad, float* m, float* v, long long n, int t, float lr, float beta1, float beta2,
+                       float eps, float rescale, const float* gb, void* stream) {
+    const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
+    const dim3 grid((unsigned)((n + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (gb) YOLO_LAUNCH(adam_kernel<true>, grid, dim3(256), 0, st, w, grad, m, v, n, lr_t, beta1, beta2, eps, 0.f, gb);
+    else    YOLO_LAUNCH(adam_kernel<false>, grid, dim3(256), 0, st, w, grad, m, v, n, lr_t, beta1, beta2, eps, rescale, (const float*)nullptr);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
 }
 
 extern "C" int yolo_adam_step_dev(float* w, const float* grad, float* m, float* v, long long n, int t, float lr,
                                   float beta1, float beta2, float eps, const float* global_batch_dev, void* stream) {
     if (!w || !grad || !m || !v || !global_batch_dev || n <= 0 || t < 1) return YOLO_EINVAL;
-    const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
-    YOLO_LAUNCH(adam_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, grad, m, v, n,
-                lr_t, beta1, beta2, eps, global_batch_dev);
-    YOLO_LAUNCH_CHECK();
-    return YOLO_OK;
+    return adam_launch(w, grad, m, v, n, t, lr, beta1, beta2, eps, 0.f, global_batch_dev, stream);
 }
 
 extern "C" int yolo_adam_step(float* w, const float* grad, float* m, float* v, long long n, int t, float lr,
                               float beta1, float beta2, float eps, float rescale, void* stream) {
     if (!w || !grad || !m || !v || n <= 0 || t < 1) return YOLO_EINVAL;
-    const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
-    YOLO_LAUNCH(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, grad, m, v, n,
-                lr_t, beta1, beta2, eps, rescale);
-    YOLO_LAUNCH_CHECK();
-    return YOLO_OK;
+    return adam_launch(w, grad, m, v, n, t, lr, beta1, beta2, eps, rescale, nullptr, stream);
 }
