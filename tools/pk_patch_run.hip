@@ -1,0 +1,89 @@
+// Runs a PATCHED code object of the packed BatchNorm backward beside the synthetic trigger (tools/pk_patch.sh builds
+// the code objects with tools/pk_patch.py).  The victim kernel -- bn_apply_kernel<bf16_t, 1, 1> -- comes from the code object
+// (hipModuleLoad), everything else (the reduction that fills its sums, the launch geometry, the trigger) is compiled in.
+//   tools/_build/pk_patch_run <victim.co> [rounds]
+#include "../yolo_amd/csrc/train.hip"
+int wgrad_walk_dispatch(const void*, const void*, float*, int, int, int, int, int, long long, int, hipStream_t) { return YOLO_EUNSUPPORTED; }
+int wgrad_gemm_dispatch(const void*, const void*, float*, long long, int, int, long long, int, hipStream_t) { return YOLO_EUNSUPPORTED; }
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "pk_trigger_kernel.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
+
+struct ApplyArgs {                      // the kernel's argument list, each at its natural alignment (= the kernarg segment)
+    const void* y; const void* other; const float* mean; const float* invstd; const float* gamma; const float* beta;
+    const float* dgamma; const float* dbeta; float inv_n; void* out; int C; long long npix; int pix_per_block; float slope; BnFused f;
+};
+
+int main(int argc, char** argv) {
+    if (argc < 2) { printf("usage: pk_patch_run <victim.co> [rounds]\n"); return 2; }
+    const int rounds = argc > 2 ? atoi(argv[2]) : 10;
+    const int N = 64, H = 52, W = 52, C = 256;
+    const long long npix = (long long)N * H * W, n = npix * C;
+    std::vector<unsigned short> hy(n), hdz(n);
+    unsigned long long s = 88172645463325252ull;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (float)((double)(s >> 11) / 9007199254740992.0) * 2.f - 1.f; };
+    for (long long i = 0; i < n; ++i) { hy[i] = f2bf(rnd() * 1.7f); hdz[i] = f2bf(rnd() * 0.01f); }
+    std::vector<float> hm(C), hi(C), hg(C), hb(C);
+    for (int c = 0; c < C; ++c) { hm[c] = 0.01f * (c % 7); hi[c] = 1.f + 0.001f * c; hg[c] = 0.5f + 0.003f * c; hb[c] = 0.1f * ((c % 5) - 2); }
+    void *y, *dz, *dy, *ref;
+    float *mean, *invstd, *gamma, *beta, *dgam, *dbet, *tout;
+    double* ws[2];
+    CK(hipMalloc(&y, n * 2)); CK(hipMalloc(&dz, n * 2)); CK(hipMalloc(&dy, n * 2)); CK(hipMalloc(&ref, n * 2));
+    CK(hipMalloc(&mean, C * 4)); CK(hipMalloc(&invstd, C * 4)); CK(hipMalloc(&gamma, C * 4)); CK(hipMalloc(&beta, C * 4));
+    CK(hipMalloc(&dgam, C * 4)); CK(hipMalloc(&dbet, C * 4)); CK(hipMalloc(&tout, 1 << 18));
+    for (int k = 0; k < 2; ++k) { CK(hipMalloc(&ws[k], 4096 * 8)); CK(hipMemset(ws[k], 0, 4096 * 8)); }
+    CK(hipMemcpy(y, hy.data(), n * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dz, hdz.data(), n * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(mean, hm.data(), C * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(invstd, hi.data(), C * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(gamma, hg.data(), C * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(beta, hb.data(), C * 4, hipMemcpyHostToDevice));
+    hipStream_t s1, s2;
+    CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+    // the sums of this input, once (compiled-in reduction + apply; ws[0] keeps the sums, the call zeroes ws[1])
+    if (yolo_bn_train_bwd_pp(dz, y, mean, invstd, gamma, beta, ref, dgam, dbet, ws[0], ws[1], 4096, npix, C, 0.1f, YOLO_BF16, s1)) return 2;
+    CK(hipDeviceSynchronize());
+    hipModule_t mod; hipFunction_t fn;
+    CK(hipModuleLoad(&mod, argv[1]));
+    CK(hipModuleGetFunction(&fn, mod, "_Z15bn_apply_kernelI6bf16_tLi1ELi1EEvPKT_S3_PKfS5_S5_S5_S5_S5_fPS1_ixif7BnFused"));
+    int ppa; unsigned na;
+    bn_partition(npix, C, 2, false, &ppa, &na);
+    auto victim = [&](void* out) {
+        ApplyArgs a = {};
+        a.y = y; a.other = dz; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.inv_n = (float)(1.0 / (double)npix);
+        a.out = out; a.C = C; a.npix = npix; a.pix_per_block = ppa; a.slope = 0.1f;
+        a.f.sums = ws[0]; a.f.dgamma_out = dgam; a.f.dbeta_out = dbet;
+        size_t sz = sizeof(a);
+        void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+        CK(hipModuleLaunchKernel(fn, na, 1, 1, 256, 1, 1, 0, s1, nullptr, extra));
+    };
+    std::vector<unsigned short> href(n), hout(n), hlib(n);
+    CK(hipMemcpy(hlib.data(), ref, n * 2, hipMemcpyDeviceToHost));
+    victim(ref);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(href.data(), ref, n * 2, hipMemcpyDeviceToHost));
+    long long dl = 0;
+    for (long long i = 0; i < n; ++i) dl += href[i] != hlib[i];
+    printf("%s: alone vs the compiled-in kernel: %lld of %lld elements differ\n", argv[1], dl, n);
+    const char* names[3] = {"alone", "beside trigger 10 (MFMA loop + v_mov_b64 0)", "beside MFMAs + v_mov_b64 0, no LDS reads"};
+    for (int mode = 0; mode < 3; ++mode) {
+        long long bad = 0, zeros = 0, l48 = 0;
+        int events = 0;
+        for (int r = 0; r < rounds; ++r) {
+            CK(hipMemsetAsync(dy, 0xff, n * 2, s1));
+            CK(hipDeviceSynchronize());
+            if (mode == 1) trigger_kernel<1, 1, 1><<<676 * 6, 256, 0, s2>>>(tout, 12);
+            if (mode == 2) trigger_kernel<1, 1, 0><<<676 * 6, 256, 0, s2>>>(tout, 12);
+            victim(dy);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(hout.data(), dy, n * 2, hipMemcpyDeviceToHost));
+            long long k = 0;
+            for (long long i = 0; i < n; ++i)
+                if (hout[i] != href[i]) { ++k; zeros += (hout[i] & 0x7fff) == 0; l48 += ((i / 8) % 64) >= 48; }
+            if (k) { ++events; bad += k; }
+        }
+        printf("    %-46s launches with a mismatch %3d / %d, elements %7lld (exact zeros %lld, lanes 48-63 %lld)\n", names[mode], events, rounds, bad, zeros, l48);
+    }
+    return 0;
+}

@@ -20,63 +20,7 @@ int wgrad_gemm_dispatch(const void*, const void*, float*, long long, int, int, l
 #include <vector>
 #include <string.h>
 
-typedef float f16v_ __attribute__((ext_vector_type(16)));
-typedef __bf16 bf8_ __attribute__((ext_vector_type(8)));
-
-// MOV: 0 none; 1 `v_mov_b64 v[n:n+1], 0`; 2 `v_mov_b64 v[n:n+1], v[m:m+1]` of a recognisable non-zero pair (0x40490fdb twice);
-//      3 the same zeros written by two v_mov_b32 (control).   MFMA / LDSR: 0 leaves the MFMAs / the LDS fragment reads out.
-template <int MOV, int MFMA, int LDSR>
-__global__ __launch_bounds__(256) void trigger_kernel(float* __restrict__ out, int iters) {
-    __shared__ __attribute__((aligned(16))) uint4 lds[3072];
-    for (int i = threadIdx.x; i < 3072; i += 256) lds[i] = make_uint4(0x3c003c00u + i, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
-    asm volatile("" ::: "v147");
-    __syncthreads();
-    f16v_ acc[4];
-    unsigned zsum = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-    const int l31 = threadIdx.x & 31, h = (threadIdx.x & 63) >> 5;
-    const int base = l31 * 64 + ((h ^ ((l31 >> 2) & 3)) << 4) + (threadIdx.x >> 6) * 2048;
-    const char* L = reinterpret_cast<const char*>(lds);
-    unsigned long long pat = 0x40490fdb40490fdbull;
-    asm volatile("" : "+v"(pat));
-    uint4 a0 = lds[threadIdx.x], a1 = lds[threadIdx.x + 256], b0 = lds[threadIdx.x + 512], b1 = lds[threadIdx.x + 768];
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int g = 0; g < 18; ++g) {
-            const int o = ((g * 4096) & 16383) ^ ((g & 1) * 32);
-            if (LDSR) {
-                a0 = *(const uint4*)(L + ((base + o) & 32767)); a1 = *(const uint4*)(L + ((base + o + 2048) & 32767));
-                b0 = *(const uint4*)(L + ((base + o + 8192) & 32767)); b1 = *(const uint4*)(L + ((base + o + 10240) & 32767));
-            }
-            if (MFMA) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_, a0), __builtin_bit_cast(bf8_, b0), acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_, a0), __builtin_bit_cast(bf8_, b1), acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_, a1), __builtin_bit_cast(bf8_, b0), acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_, a1), __builtin_bit_cast(bf8_, b1), acc[3], 0, 0, 0);
-            } else {
-                zsum += a0.x ^ b0.y ^ a1.z ^ b1.w;
-            }
-            unsigned long long z0 = 0, z1 = 0;
-            if (MOV == 1) asm volatile("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0" : "=v"(z0), "=v"(z1));
-            if (MOV == 2) asm volatile("v_mov_b64 %0, %2\n\tv_mov_b64 %1, %2" : "=v"(z0), "=v"(z1) : "v"(pat));
-            if (MOV == 3) {
-                unsigned q0, q1, q2, q3;
-                asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3));
-                z0 = q0 | ((unsigned long long)q1 << 32); z1 = q2 | ((unsigned long long)q3 << 32);
-            }
-            if (MOV) zsum += (unsigned)z0 + (unsigned)(z1 >> 32);
-        }
-        __syncthreads();
-        __syncthreads();
-    }
-    float sacc = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) sacc += acc[k][threadIdx.x & 15];
-    if (sacc == 12345.678f || zsum == 77u) out[0] = sacc;
-}
+#include "pk_trigger_kernel.h"
 
 // SYNTHETIC VICTIM (--chain): the first instructions of the packed bn_apply_kernel, verbatim from its ISA with fixed registers:
 // four 16-byte loads of doubles, counted waits, v_cvt_f32_f64, v_pk_mul_f32 by an SGPR pair, the re-pairing
@@ -132,7 +76,10 @@ __global__ __launch_bounds__(256) void chain_kernel(const double* __restrict__ s
 // loads a pair x, applies 64 packed operations that must leave it unchanged (x * 1, x + 0, x - 0) and stores it: out == in, or an
 // operand was read wrong.  VAR 0: v_pk_mul_f32 v[228:229], v[120:121], v[228:229] (both sources start in VGPR bank 0: a bank
 // conflict); 1: v_pk_mul_f32 v[228:229], v[122:123], v[228:229] (banks 2 / 0: none); 2: v_pk_add_f32 v[228:229], v[228:229],
-// v[0:1] neg_lo neg_hi (banks 0 / 0); 3: v_pk_add_f32 v[238:239], v[238:239], v[0:1] neg (banks 2 / 0); 4: alternating 0 and 2
+// v[0:1] neg_lo neg_hi (banks 0 / 0); 3: v_pk_add_f32 v[238:239], v[238:239], v[0:1] neg (banks 2 / 0); 4: alternating 0 and 2;
+// 5: v_pk_mul_f32 v[228:229], v[120:121], v[228:229] op_sel:[0,1] op_sel_hi:[1,0] -- the CROSS-HALF form (low result = src0.lo *
+// src1.hi, high = src0.hi * src1.lo; 64 swaps by 1.0 give x back), the only packed instruction of the real kernel whose
+// replacement by two scalar multiplies makes it clean (tools/pk_patch.py); 6: the same form, destination != sources
 template <int VAR>
 __global__ __launch_bounds__(256) void pkloop_kernel(const float2* __restrict__ src, float2* __restrict__ dst, int reps, long long nthreads) {
     const long long t = blockIdx.x * 256LL + threadIdx.x;
@@ -149,6 +96,8 @@ __global__ __launch_bounds__(256) void pkloop_kernel(const float2* __restrict__ 
             ".if %c[var] == 1\n\t" PK64("v_pk_mul_f32 v[228:229], v[122:123], v[228:229]\n\t") ".endif\n\t"
             ".if %c[var] == 2\n\t" PK64("v_pk_add_f32 v[228:229], v[228:229], v[0:1] neg_lo:[0,1] neg_hi:[0,1]\n\t") ".endif\n\t"
             ".if %c[var] == 3\n\t" PK64("v_pk_add_f32 v[238:239], v[238:239], v[0:1] neg_lo:[0,1] neg_hi:[0,1]\n\t") "v_mov_b32 v228, v238\n\tv_mov_b32 v229, v239\n\t" ".endif\n\t"
+            ".if %c[var] == 5\n\t" PK64("v_pk_mul_f32 v[228:229], v[120:121], v[228:229] op_sel:[0,1] op_sel_hi:[1,0]\n\t") ".endif\n\t"
+            ".if %c[var] == 6\n\t" PK64("v_pk_mul_f32 v[238:239], v[122:123], v[228:229] op_sel:[0,1] op_sel_hi:[1,0]\n\tv_pk_mul_f32 v[228:229], v[120:121], v[238:239] op_sel:[0,1] op_sel_hi:[1,0]\n\t") ".endif\n\t"
             ".if %c[var] == 4\n\t" PK64("v_pk_mul_f32 v[228:229], v[120:121], v[228:229]\n\tv_pk_add_f32 v[228:229], v[228:229], v[0:1] neg_lo:[0,1] neg_hi:[0,1]\n\t") ".endif\n\t"
             "s_nop 4\n\t"
             "v_mov_b32 %[y0], v228\n\tv_mov_b32 %[y1], v229\n\t"
@@ -236,10 +185,11 @@ static int pkloop_main(int rounds) {
     CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
     std::vector<unsigned> out(nv * 2), in(nv * 2);
     memcpy(in.data(), hs.data(), nv * 8);
-    const char* vnames[5] = {"v_pk_mul_f32 v[228:229], v[120:121], v[228:229] (bank conflict)", "v_pk_mul_f32 v[228:229], v[122:123], v[228:229] (none)",
+    const char* vnames[7] = {"v_pk_mul_f32 v[228:229], v[120:121], v[228:229] (bank conflict)", "v_pk_mul_f32 v[228:229], v[122:123], v[228:229] (none)",
                              "v_pk_add_f32 v[228:229], v[228:229], v[0:1] neg (conflict)", "v_pk_add_f32 v[238:239], v[238:239], v[0:1] neg (none)",
-                             "alternating packed multiply and add (conflicts)"};
-    for (int var = 0; var < 5; ++var)
+                             "alternating packed multiply and add (conflicts)", "v_pk_mul_f32 d, a, d op_sel:[0,1] op_sel_hi:[1,0] (cross-half, in place)",
+                             "v_pk_mul_f32 d, a, b op_sel:[0,1] op_sel_hi:[1,0] (cross-half, d != a, b)"};
+    for (int var = 0; var < 7; ++var)
         for (int mode = 0; mode < 3; ++mode) {
             long long bad = 0, zeros = 0, l48 = 0, lo = 0;
             int events = 0;
@@ -253,6 +203,8 @@ static int pkloop_main(int rounds) {
                 if (var == 2) pkloop_kernel<2><<<nblocks, 256, 0, s1>>>(src, dst, reps, nthreads);
                 if (var == 3) pkloop_kernel<3><<<nblocks, 256, 0, s1>>>(src, dst, reps, nthreads);
                 if (var == 4) pkloop_kernel<4><<<nblocks, 256, 0, s1>>>(src, dst, reps, nthreads);
+                if (var == 5) pkloop_kernel<5><<<nblocks, 256, 0, s1>>>(src, dst, reps, nthreads);
+                if (var == 6) pkloop_kernel<6><<<nblocks, 256, 0, s1>>>(src, dst, reps, nthreads);
                 CK(hipDeviceSynchronize());
                 CK(hipMemcpy(out.data(), dst, nv * 8, hipMemcpyDeviceToHost));
                 long long k = 0;

@@ -1,0 +1,61 @@
+// The synthetic co-runner of tools/pk_repro2.hip and tools/pk_patch_run.hip: an MFMA loop in the shape and footprint of
+// the generic convolution's K loop, optionally with VALU moves between its MFMAs.
+#pragma once
+typedef float f16v_ __attribute__((ext_vector_type(16)));
+typedef __bf16 bf8_ __attribute__((ext_vector_type(8)));
+
+// MOV: 0 none; 1 `v_mov_b64 v[n:n+1], 0`; 2 `v_mov_b64 v[n:n+1], v[m:m+1]` of a recognisable non-zero pair (0x40490fdb twice);
+//      3 the same zeros written by two v_mov_b32 (control).   MFMA / LDSR: 0 leaves the MFMAs / the LDS fragment reads out.
+template <int MOV, int MFMA, int LDSR>
+__global__ __launch_bounds__(256) void trigger_kernel(float* __restrict__ out, int iters) {
+    __shared__ __attribute__((aligned(16))) uint4 lds[3072];
+    for (int i = threadIdx.x; i < 3072; i += 256) lds[i] = make_uint4(0x3c003c00u + i, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+    asm volatile("" ::: "v147");
+    __syncthreads();
+    f16v_ acc[4];
+    unsigned zsum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    const int l31 = threadIdx.x & 31, h = (threadIdx.x & 63) >> 5;
+    const int base = l31 * 64 + ((h ^ ((l31 >> 2) & 3)) << 4) + (threadIdx.x >> 6) * 2048;
+    const char* L = reinterpret_cast<const char*>(lds);
+    unsigned long long pat = 0x40490fdb40490fdbull;
+    asm volatile("" : "+v"(pat));
+    uint4 a0 = lds[threadIdx.x], a1 = lds[threadIdx.x + 256], b0 = lds[threadIdx.x + 512], b1 = lds[threadIdx.x + 768];
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int g = 0; g < 18; ++g) {
+            const int o = ((g * 4096) & 16383) ^ ((g & 1) * 32);
+            if (LDSR) {
+                a0 = *(const uint4*)(L + ((base + o) & 32767)); a1 = *(const uint4*)(L + ((base + o + 2048) & 32767));
+                b0 = *(const uint4*)(L + ((base + o + 8192) & 32767)); b1 = *(const uint4*)(L + ((base + o + 10240) & 32767));
+            }
+            if (MFMA) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_, a0), __builtin_bit_cast(bf8_, b0), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_, a0), __builtin_bit_cast(bf8_, b1), acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_, a1), __builtin_bit_cast(bf8_, b0), acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_, a1), __builtin_bit_cast(bf8_, b1), acc[3], 0, 0, 0);
+            } else {
+                zsum += a0.x ^ b0.y ^ a1.z ^ b1.w;
+            }
+            unsigned long long z0 = 0, z1 = 0;
+            if (MOV == 1) asm volatile("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0" : "=v"(z0), "=v"(z1));
+            if (MOV == 2) asm volatile("v_mov_b64 %0, %2\n\tv_mov_b64 %1, %2" : "=v"(z0), "=v"(z1) : "v"(pat));
+            if (MOV == 3) {
+                unsigned q0, q1, q2, q3;
+                asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3));
+                z0 = q0 | ((unsigned long long)q1 << 32); z1 = q2 | ((unsigned long long)q3 << 32);
+            }
+            if (MOV) zsum += (unsigned)z0 + (unsigned)(z1 >> 32);
+        }
+        __syncthreads();
+        __syncthreads();
+    }
+    float sacc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sacc += acc[k][threadIdx.x & 15];
+    if (sacc == 12345.678f || zsum == 77u) out[0] = sacc;
+}
+
