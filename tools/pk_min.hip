@@ -17,7 +17,8 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 #define R64(op) R8(op) R8(op) R8(op) R8(op) R8(op) R8(op) R8(op) R8(op)
 
 // FORM 0: cross-half multiply by (1, 1); 1: the plain multiply; 2: cross-half ADD of (0, 0); 3: cross-half FMA a * b + 0;
-// 4: the half swap v_pk_mov_b32 d, d, d op_sel:[1,0].
+// 4: the half swap v_pk_mov_b32 d, d, d op_sel:[1,0]; 5 / 6: the multiply with ONE operand half broadcast (a.lo for both results:
+// op_sel_hi:[0,1]; a.hi for both: op_sel:[1,0]); 7: form 0 with the swapped operand as src0.
 // BIG: the wave owns 254 VGPRs (one victim wave + one trigger wave per SIMD), else whatever the few registers below need.
 template <int FORM, int BIG>
 __global__ __launch_bounds__(256) void victim(const float2* __restrict__ src, float2* __restrict__ dst, long long n) {
@@ -31,6 +32,9 @@ __global__ __launch_bounds__(256) void victim(const float2* __restrict__ src, fl
                      ".if %c[f] == 2\n\t" R64("v_pk_add_f32 v[28:29], v[22:23], v[28:29] op_sel:[0,1] op_sel_hi:[1,0]\n\t") ".endif\n\t"
                      ".if %c[f] == 3\n\t" R64("v_pk_fma_f32 v[28:29], v[20:21], v[28:29], v[22:23] op_sel:[0,1,0] op_sel_hi:[1,0,1]\n\t") ".endif\n\t"
                      ".if %c[f] == 4\n\t" R64("v_pk_mov_b32 v[28:29], v[28:29], v[28:29] op_sel:[1,0]\n\t") ".endif\n\t"
+                     ".if %c[f] == 5\n\t" R64("v_pk_mul_f32 v[28:29], v[20:21], v[28:29] op_sel_hi:[0,1]\n\t") ".endif\n\t"
+                     ".if %c[f] == 6\n\t" R64("v_pk_mul_f32 v[28:29], v[20:21], v[28:29] op_sel:[1,0]\n\t") ".endif\n\t"
+                     ".if %c[f] == 7\n\t" R64("v_pk_mul_f32 v[28:29], v[28:29], v[20:21] op_sel:[1,0] op_sel_hi:[0,1]\n\t") ".endif\n\t"
                      "s_nop 4\n\tv_mov_b32 %[y0], v28\n\tv_mov_b32 %[y1], v29\n\t"
                      : [y0] "=v"(y.x), [y1] "=v"(y.y) : [x0] "v"(x.x), [x1] "v"(x.y), [f] "n"(FORM)
                      : "v20", "v21", "v22", "v23", "v28", "v29");
@@ -66,12 +70,13 @@ int main() {
     hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
     std::vector<unsigned> out(n * 2), in(n * 2);
     memcpy(in.data(), h.data(), n * 8);
-    const char* vn[7] = {"v_pk_mul_f32 cross-half, 254-register wave", "v_pk_mul_f32 plain,      254-register wave", "v_pk_add_f32 cross-half, 254-register wave",
+    const char* vn[10] = {"v_pk_mul_f32 cross-half, 254-register wave", "v_pk_mul_f32 plain,      254-register wave", "v_pk_add_f32 cross-half, 254-register wave",
                          "v_pk_fma_f32 cross-half, 254-register wave", "v_pk_mul_f32 cross-half, small wave", "v_pk_mul_f32 plain,      small wave",
-                         "v_pk_mov_b32 op_sel:[1,0] (half swap), 254 reg."};
+                         "v_pk_mov_b32 op_sel:[1,0] (half swap), 254 reg.", "v_pk_mul_f32 op_sel_hi:[0,1] (a.lo twice)", "v_pk_mul_f32 op_sel:[1,0] (a.hi twice)",
+                          "v_pk_mul_f32 cross-half on src0"};
     const char* tn[3] = {"alone", "beside MFMAs only", "beside MFMAs + v_mov_b64"};
     int bad_cross = 0, bad_other = 0;
-    for (int v = 0; v < 7; ++v)
+    for (int v = 0; v < 10; ++v)
         for (int t = 0; t < 3; ++t) {
             long long bad = 0, l48 = 0, zeros = 0;
             for (int r = 0; r < 5; ++r) {
@@ -85,14 +90,17 @@ int main() {
                 if (v == 4) victim<0, 0><<<2048, 256, 0, s1>>>(src, dst, n);
                 if (v == 5) victim<1, 0><<<2048, 256, 0, s1>>>(src, dst, n);
                 if (v == 6) victim<4, 1><<<2048, 256, 0, s1>>>(src, dst, n);
+                if (v == 7) victim<5, 1><<<2048, 256, 0, s1>>>(src, dst, n);
+                if (v == 8) victim<6, 1><<<2048, 256, 0, s1>>>(src, dst, n);
+                if (v == 9) victim<7, 1><<<2048, 256, 0, s1>>>(src, dst, n);
                 CK(hipDeviceSynchronize());
                 CK(hipMemcpy(out.data(), dst, n * 8, hipMemcpyDeviceToHost));
                 for (long long i = 0; i < n * 2; ++i)
                     if (out[i] != in[i]) { ++bad; zeros += (out[i] & 0x7fffffffu) == 0; l48 += ((i / 2) % 64) >= 48; }
             }
             printf("%-44s %-26s wrong values %8lld of %lld (zeros %lld, in lanes 48-63 %lld)\n", vn[v], tn[t], bad, 5 * n * 2, zeros, l48);
-            ((v == 1 || v == 5) ? bad_other : bad_cross) += bad != 0;
+            ((v == 0 || v == 2 || v == 3 || v == 4) ? bad_cross : bad_other) += bad != 0;
         }
-    printf(bad_cross && !bad_other ? "REPRODUCED: only cross-half (op_sel) packed forms (mul / add / fma; not the v_pk_mov_b32 swap), only beside the MFMA + VALU co-runner\n" : bad_cross ? "REPRODUCED (see the table)\n" : "NOT REPRODUCED\n");
+    printf(bad_cross && !bad_other ? "REPRODUCED: only packed arithmetic with src1's halves swapped (mul / add / fma), only beside the MFMA + VALU co-runner\n" : bad_cross ? "REPRODUCED (see the table)\n" : "NOT REPRODUCED\n");
     return 0;
 }
