@@ -184,6 +184,33 @@ def test_nms_list_overflow_falls_back(cuda):
         assert a[0][1, :int(a[2][1])].cpu().tolist() == rk.tolist()
 
 
+@pytest.mark.parametrize('ncls', [1, 2, 24, 58, 90])
+def test_decode_scores_any_class_count(cuda, ncls):
+    """The pipelined decode + scores kernel for row widths other than the car spec's 30: one class (C = 7), an odd tile tail, the
+    24-load-per-thread instantiation (C > 32) and its 96-value limit; bit-identical to yolo_decode + yolo_nms_scores, and the
+    scores are the oracle's softmax x objectness."""
+    from yolo_amd.detect import Detector
+    spec = dict(SPEC, slice_point=[1, 3, 5, 6, 6 + ncls])
+    size, B = (160, 224), 3
+    steps = od.init_steps(spec['layers'], spec['all_anchors'])
+    area = od.init_area(size, steps)
+    rng = np.random.default_rng(100 + ncls)
+    outs = [(2.0 * rng.standard_normal((B, a, 3, 6 + ncls))).astype(np.float32) for a in area]
+    det = Detector(spec, size, steps, device=cuda)
+    dev = [torch.from_numpy(o).to(cuda) for o in outs]
+    rows = det.decode(dev)
+    for mode in ('obj', 'class'):
+        scores = det.nms_scores(rows, mode)
+        rows2, scores2 = det.decode_scores(dev, mode)
+        assert torch.equal(rows.view(torch.int32), rows2.view(torch.int32))
+        assert torch.equal(scores.view(torch.int32), scores2.view(torch.int32))
+    r = rows.cpu().numpy()
+    logits = r[..., 6:]
+    e = np.exp(logits - logits.max(axis=-1, keepdims=True))
+    want = r[..., 0:1] * (e / e.sum(axis=-1, keepdims=True))
+    np.testing.assert_allclose(det.nms_scores(rows, 'class').cpu().numpy().reshape(want.shape), want, rtol=2e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize('mode', ['obj', 'class'])
 @pytest.mark.parametrize('size,B', [((416, 416), 3), ((608, 608), 2), ((320, 512), 1)])
 def test_decode_scores_fused_is_bit_identical(cuda, mode, size, B):

@@ -207,20 +207,21 @@ extern "C" int yolo_iou_ltrb_vs_cltrb(const float* boxes, const float* target, f
 // ---- NMS scores ------------------------------------------------------------------------------
 // mode 0: scores (B, nbox) = sigmoid(obj) column of rows.  mode 1: scores (B, nbox*ncls) =
 // sigmoid(obj) * softmax(cls)_c.  One thread per box.
-__global__ __launch_bounds__(256) void nms_scores_kernel(const float* __restrict__ rows, float* __restrict__ scores, int C,
-                                                         int ncls, int mode, long long nboxes) {
-    // 256 boxes per block, staged through LDS so that both the row reads and the score writes are coalesced
+template <int NB>                                        // boxes (= threads) per block
+__global__ __launch_bounds__(NB) void nms_scores_kernel(const float* __restrict__ rows, float* __restrict__ scores, int C,
+                                                        int ncls, int mode, long long nboxes) {
+    // NB boxes per block, staged through LDS so that both the row reads and the score writes are coalesced
     // (one thread per box walking its own 120-byte row ran at 1/18 of the HBM rate)
-    extern __shared__ float sm[];                        // 256*C floats of rows, then 256*ncls of scores
-    const long long k0 = blockIdx.x * 256LL;
-    const int nb = (int)min(256LL, nboxes - k0);
+    extern __shared__ float sm[];                        // NB*C floats of rows, then NB*ncls of scores
+    const long long k0 = (long long)blockIdx.x * NB;
+    const int nb = (int)min((long long)NB, nboxes - k0);
     if (mode == 0) {
         if ((int)threadIdx.x < nb) scores[k0 + threadIdx.x] = rows[(k0 + threadIdx.x) * C];
         return;
     }
-    for (int i = threadIdx.x; i < nb * C; i += 256) sm[i] = rows[k0 * C + i];
+    for (int i = threadIdx.x; i < nb * C; i += NB) sm[i] = rows[k0 * C + i];
     __syncthreads();
-    float* so = sm + 256 * C;
+    float* so = sm + NB * C;
     if ((int)threadIdx.x < nb) {
         const float* p = sm + threadIdx.x * C;
         float m = -FLT_MAX;
@@ -231,16 +232,21 @@ __global__ __launch_bounds__(256) void nms_scores_kernel(const float* __restrict
         for (int c = 0; c < ncls; ++c) so[threadIdx.x * ncls + c] = obj * (expf(p[6 + c] - m) / sum);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nb * ncls; i += 256) scores[k0 * ncls + i] = so[i];
+    for (int i = threadIdx.x; i < nb * ncls; i += NB) scores[k0 * ncls + i] = so[i];
 }
 
 extern "C" int yolo_nms_scores(const float* rows, float* scores, int B, int nbox, int C, int mode, void* stream) {
     if (!rows || !scores || B <= 0 || nbox <= 0 || C < 6) return YOLO_EINVAL;
     if (mode == 1 && C <= 6) return YOLO_EINVAL;
     const long long nboxes = (long long)B * nbox;
-    if (C > 96) return YOLO_EUNSUPPORTED;                      // LDS staging: kDecBoxes boxes x (C + ncls) floats
-    YOLO_LAUNCH(nms_scores_kernel, dim3((unsigned)((nboxes + 255) / 256)), dim3(256),
-                (size_t)256 * (C + (C - 6)) * sizeof(float), (hipStream_t)stream, rows, scores, C, C - 6, mode, nboxes);
+    if (C > 96) return YOLO_EUNSUPPORTED;                      // LDS staging: boxes x (C + ncls) floats
+    // 256 boxes per block while their staged rows + scores fit the 64 KiB a block gets without opting in (C <= 35), else 64
+    if ((size_t)256 * (C + (C - 6)) * sizeof(float) <= 65536)
+        YOLO_LAUNCH(nms_scores_kernel<256>, dim3((unsigned)((nboxes + 255) / 256)), dim3(256),
+                    (size_t)256 * (C + (C - 6)) * sizeof(float), (hipStream_t)stream, rows, scores, C, C - 6, mode, nboxes);
+    else
+        YOLO_LAUNCH(nms_scores_kernel<64>, dim3((unsigned)((nboxes + 63) / 64)), dim3(64),
+                    (size_t)64 * (C + (C - 6)) * sizeof(float), (hipStream_t)stream, rows, scores, C, C - 6, mode, nboxes);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
@@ -376,6 +382,14 @@ extern "C" int yolo_decode_scores(const float* out, float* rows, float* scores, 
     if (per_cu > 8) per_cu = 8;
     const long long ntiles = (nboxes + kDecBoxes - 1) / kDecBoxes;
     const dim3 grid((unsigned)(ntiles < cus * per_cu ? ntiles : cus * per_cu));
+    if (lds > 65536) {                                         // (C + classes > 128: the block opts in to more than 64 KiB, once)
+        static bool opted = false;
+        if (!opted) {
+            const hipError_t e = hipFuncSetAttribute((const void*)decode_scores_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            opted = true;
+        }
+    }
     if (C <= 32)
         YOLO_LAUNCH(decode_scores_kernel<8>, grid, dim3(kDecBoxes), lds, (hipStream_t)stream, out, rows, scores, C,
                     C - 6, mode, nbox, nboxes, d);
