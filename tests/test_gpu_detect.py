@@ -184,6 +184,43 @@ def test_nms_list_overflow_falls_back(cuda):
         assert a[0][1, :int(a[2][1])].cpu().tolist() == rk.tolist()
 
 
+def _extreme(kind, B=2):
+    rng = np.random.default_rng(7)
+    steps = od.init_steps(SPEC['layers'], SPEC['all_anchors'])
+    area = od.init_area((416, 416), steps)
+    o = [((40.0 if kind == 'huge' else 0.0 if kind == 'zeros' else 2.0) * rng.standard_normal((B, a, 3, 30))).astype(np.float32) for a in area]
+    if kind == 'nan':
+        o[0][0, 5, 1, 0] = np.nan              # an objectness: all 24 scores of that box are NaN
+        o[1][1, 7, 2, 9] = np.nan              # one class logit: the box's softmax is NaN
+    if kind == 'inf_obj':
+        o[0][:, :, :, 0] = np.inf
+    if kind == 'zero_area':
+        o[2][:, :, :, 3:5] = -np.inf
+    return o
+
+
+@pytest.mark.parametrize('kind,kw', [('plain', dict(valid_thresh=0.999)), ('plain', dict(valid_thresh=0.0)), ('plain', dict(topk=512, post_nms=1)),
+                                     ('plain', dict(topk=1)), ('plain', dict(iou_thresh=0.0)), ('plain', dict(iou_thresh=1.0)),
+                                     ('zeros', {}), ('huge', {}), ('nan', {}), ('inf_obj', {}), ('zero_area', {})])
+def test_nms_extremes_match_the_oracle(cuda, kind, kw):
+    """Threshold / count extremes and non-finite logits: nothing valid, everything valid, one candidate, suppress-all and
+    suppress-none IoU bars, mass ties, exp overflow (infinite boxes), NaN scores (never candidates), +inf scores (valid), zero-area
+    boxes -- kept ids of the chip-wide and the single-block selection against the oracle's, image by image."""
+    from yolo_amd.detect import Detector
+    steps = od.init_steps(SPEC['layers'], SPEC['all_anchors'])
+    det = Detector(SPEC, (416, 416), steps, device=cuda)
+    outs = _extreme(kind)
+    rows, scores = det.decode_scores([torch.from_numpy(o).to(cuda) for o in outs], 'class')
+    with np.errstate(all='ignore'):
+        want = [od.nms(rows[b].cpu().numpy(), 'class', scores=scores[b].cpu().numpy(), **kw)[0].tolist() for b in range(rows.shape[0])]
+    for fast in (True, False):
+        kept, _, cnt = det.nms(rows, 'class', scores=scores, fast=fast, **kw)
+        for b in range(rows.shape[0]):
+            assert kept[b, :int(cnt[b])].cpu().tolist() == want[b], (fast, b)
+    if kind == 'plain' and kw.get('valid_thresh') == 0.999:
+        assert cnt.cpu().tolist() == [0, 0]
+
+
 @pytest.mark.parametrize('ncls', [1, 2, 24, 58, 90])
 def test_decode_scores_any_class_count(cuda, ncls):
     """The pipelined decode + scores kernel for row widths other than the car spec's 30: one class (C = 7), an odd tile tail, the

@@ -408,6 +408,9 @@ extern "C" int yolo_decode_scores(const float* out, float* rows, float* scores, 
 //   2. bitonic sort of <=512 composite keys (score_bits<<32 | ~id) descending.
 //   3. suppression bit-matrix over candidate pairs (same class && IoU > thr), then one wavefront
 //      walks the candidates in order OR-ing rows of the matrix (lane w owns 64-bit word w).
+// A candidate is VALID iff valid_thresh <= score <= +inf as floats: as bit patterns vbits <= u <= 0x7f800000 (negative scores and
+// the padding sentinel have the sign bit set; NaN scores -- a NaN logit -- lie above +inf and are never candidates, as in the
+// oracle's `scores >= valid_thresh`).
 constexpr int NMS_MAXK = 512;
 constexpr int NMS_THREADS = 1024;
 // Chip-wide pre-selection (optional workspace): the single block per image above spends its time streaming the
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(256) void nms_hist_kernel(const float* __restrict__
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const unsigned u = ub[e];
-            if (u >= vbits && !(u & 0x80000000u)) {
+            if (u >= vbits && u <= 0x7f800000u) {
                 unsigned bin = 0xffffffffu;
                 if (pass == 0) bin = u >> 21;
                 else if ((u >> 21) == q1) bin = (u >> 10) & 2047u;
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(256) void nms_collect_kernel(const float* __restric
         load_score_batch(sc, base, i1, vec, ub);
         unsigned mine = 0;                                 // bit e: element e of the batch is taken
 #pragma unroll
-        for (int e = 0; e < 16; ++e) mine |= (ub[e] >= thr && !(ub[e] & 0x80000000u)) ? 1u << e : 0u;
+        for (int e = 0; e < 16; ++e) mine |= (ub[e] >= thr && ub[e] <= 0x7f800000u) ? 1u << e : 0u;
         if (!__ballot(mine != 0)) continue;                // the common case: nothing at or above the threshold in 4096 scores
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -608,7 +611,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
         const unsigned himask = pass == 0 ? 0u : (0xffffffffu << (shift + widths[pass]));
         for (long long i = tid; i < ncand; i += NMS_THREADS) {
             const unsigned u = __float_as_uint(sc[i]);
-            if (u >= vbits && !(u & 0x80000000u) && ((u & himask) == (prefix & himask)))
+            if (u >= vbits && u <= 0x7f800000u && ((u & himask) == (prefix & himask)))
                 atomicAdd(&hist[(u >> shift) & (nb - 1)], 1u);
         }
         __syncthreads();
@@ -637,7 +640,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
     // strictly-above candidates (or all valid when all_taken): unordered append
     for (long long i = tid; i < ncand; i += NMS_THREADS) {
         const unsigned u = __float_as_uint(sc[i]);
-        const bool valid = u >= vbits && !(u & 0x80000000u);
+        const bool valid = u >= vbits && u <= 0x7f800000u;
         const bool take = valid && (all_taken ? true : (u > T));
         if (take) {
             const unsigned pos = atomicAdd(&sh_cnt, 1u);
