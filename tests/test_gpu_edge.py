@@ -51,3 +51,51 @@ def test_edge_shape_end_to_end(cuda, name, dtype, tol):
         losses = tr.train_step(torch.from_numpy(x).to(cuda), torch.from_numpy(lab).to(cuda))
         rl, _, _ = ot.train_step_reference(g, P, x, lab, spec, size)
         np.testing.assert_allclose(losses.cpu().numpy(), np.stack(rl), rtol=1e-3, atol=1e-6)
+
+
+def _row(ncls, c, y, x, h, w, r=0.1):
+    v = -np.ones(6 + ncls, np.float32)
+    v[:6] = [c, y, x, h, w, r]
+    v[6:] = 0.0
+    v[6 + int(c)] = 1.0
+    return v
+
+
+def _label_cases():
+    n = MICRO['slice_point'][-1] - 6
+    none = -np.ones(6 + n, np.float32)
+    S = (64, 96)
+    return {
+        'no object in any image': (S, [[none], [none]], None),
+        'object only in one image': (S, [[none], [_row(n, 1, .5, .5, .4, .3)]], None),
+        'two objects in one cell': (S, [[_row(n, 0, .5, .5, .4, .3), _row(n, 2, .51, .51, .38, .31)], [_row(n, 1, .3, .7, .2, .2), none]], None),
+        'objects on the border and the corner': (S, [[_row(n, 0, .0, .0, .3, .3)], [_row(n, 3, 1.0, 1.0, .5, .5)]], None),
+        'tiny and oversized boxes': (S, [[_row(n, 0, .5, .5, .01, .01)], [_row(n, 1, .5, .5, 1.5, 1.5)]], None),
+        'batch 1 at 32x32 (BatchNorm over one pixel)': ((32, 32), [[_row(n, 1, .5, .5, .4, .3)]], None),
+        'constant image (zero variance in the stem)': (S, [[_row(n, 1, .5, .5, .4, .3)], [_row(n, 2, .4, .6, .3, .3)]], 0.5),
+        'rotation at +-pi': (S, [[_row(n, 0, .5, .5, .4, .3, r=np.pi)], [_row(n, 1, .5, .5, .4, .3, r=-np.pi)]], None),
+    }
+
+
+@pytest.mark.parametrize('name', sorted(_label_cases()))
+def test_training_step_label_and_input_edges(cuda, name):
+    """One fp32 training step (update off) on label / input edge cases: the five losses and EVERY parameter gradient against the
+    oracle's autograd restatement."""
+    from yolo_amd.net import CarNet
+    from yolo_amd.train import Trainer
+    size, labels, xconst = _label_cases()[name]
+    labels = np.asarray(labels, np.float32)
+    B = labels.shape[0]
+    g = og.build_graph(MICRO)
+    P = og.init_params(g, seed=1, bn='random')
+    x = np.random.default_rng(3).random((B, 3) + size, dtype=np.float32)
+    if xconst is not None:
+        x[:] = xconst
+    tr = Trainer(CarNet(MICRO, dtype='f32', device=cuda).load_params(P), size)
+    losses = tr.train_step(torch.from_numpy(x).to(cuda), torch.from_numpy(labels).to(cuda), update=False)
+    rl, rg, _ = ot.train_step_reference(g, P, x, labels, MICRO, size)
+    np.testing.assert_allclose(losses.cpu().numpy(), np.stack(rl), rtol=1e-4, atol=1e-6)
+    for n, gr in tr.grads().items():
+        ref = rg[n]
+        den = max(float(np.abs(ref).max()), 1e-6)
+        assert float(np.abs(gr.cpu().numpy() - ref).max()) / den < 1e-2, n
