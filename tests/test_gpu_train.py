@@ -130,6 +130,37 @@ def test_adam_c_abi_vector_and_unaligned(cuda, n, offset):
     np.testing.assert_allclose(ref[2], v, rtol=1e-5, atol=1e-8)
 
 
+def test_trainer_for_another_size_keeps_the_optimiser_state(cuda):
+    """net.trainer(size) for a new image size: new grid and plan, the same hyper-parameters, Adam moments and update count."""
+    from yolo_amd.train import Trainer
+    spec, size, g, P, x, lab, net, tr = _setup(cuda)
+    tr = Trainer(net, size, learning_rate=3e-4, negative_weight=0.2)
+    xt, lt = torch.from_numpy(x).to(cuda), torch.from_numpy(lab).to(cuda)
+    tr.train_step(xt, lt)
+    m, v, w = tr.mflat.clone(), tr.vflat.clone(), tr.wflat.clone()
+    other = (size[0] + 32, size[1])
+    tr2 = net.trainer(other)
+    assert tr2 is not tr and tr2.size == other and net.trainer() is tr2
+    assert tr2.t == 1 and tr2.lr == 3e-4 and tr2.neg_w == 0.2
+    assert torch.equal(tr2.mflat, m) and torch.equal(tr2.vflat, v) and torch.equal(tr2.wflat, w)
+    x2 = torch.rand((2, 3) + other, device=cuda)
+    assert torch.isfinite(tr2.train_step(x2, lt)).all() and tr2.t == 2
+    assert net.trainer(other) is tr2                                   # same size again: the same object
+
+
+def test_save_state_writes_the_path_it_is_given(cuda, tmp_path):
+    spec, size, g, P, x, lab, net, tr = _setup(cuda)
+    path = str(tmp_path / 'weights.pt')
+    net.save_state(path)
+    import os
+    assert os.path.exists(path) and not os.path.exists(path + '.npz')
+    from yolo_amd.net import CarNet
+    n2 = CarNet(spec, dtype='f32', device=cuda)
+    n2.load_state(path)
+    for k, v in net.params.items():
+        assert torch.equal(v, n2.params[k]), k
+
+
 def test_adam_update_and_second_step(cuda):
     spec, size, g, P, x, lab, net, tr = _setup(cuda)
     xt, lt = torch.from_numpy(x).to(cuda), torch.from_numpy(lab).to(cuda)

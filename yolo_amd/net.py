@@ -134,9 +134,12 @@ class CarNet(object):
 
     def save_state(self, path, params=None):
         """Writes `params` (averaged_params(), see there) or, by default, this rank's own parameters.  No collective."""
-        np.savez(path, **{k: v.detach().cpu().numpy() for k, v in (self.params if params is None else params).items()})
+        with open(path, 'wb') as f:                      # (a file object: np.savez(path) would append ".npz" to the name given)
+            np.savez(f, **{k: v.detach().cpu().numpy() for k, v in (self.params if params is None else params).items()})
 
     def load_state(self, path):
+        if not os.path.exists(path) and os.path.exists(path + '.npz'):
+            path = path + '.npz'                         # (files written before round 3 carry numpy's suffix)
         with np.load(path) as z:
             return self.load_params({k: z[k] for k in z.files})
 
@@ -437,6 +440,10 @@ class CarNet(object):
 
     # ---- forward ------------------------------------------------------------------------------------
     def forward(self, x, training=False):
+        """-> the three (B, HiWi, A, C) fp32 logit tensors, fine -> coarse (CarLPNet: (outs, [LP])).  They are VIEWS of one merged
+        buffer owned by the plan of this input shape -- an executor's output arrays, as in the reference's deployed path
+        (`net.forward(is_train=False, data=...)`, yolo_gluon.py:204-242) -- so the next forward of the same shape overwrites them:
+        `.clone()` what must outlive it.  (A gluon block called under `autograd` returns fresh arrays; the Trainer keeps its own.)"""
         if training:
             # `self.net(bx)` under autograd.record (car/YOLO.py:381): batch-statistics BatchNorm, everything backward()
             # needs is kept.  Runs through the Trainer that owns the flat parameter buffers (built on first use with the
@@ -483,7 +490,9 @@ class CarNet(object):
             if size is None:
                 raise L.YoloError('no Trainer is attached to this net yet: pass the image size')
             from .train import Trainer
-            tr = Trainer(self, size)
+            # a new image size needs a new anchor grid and activation plan, NOT a new optimiser: hyper-parameters, Adam moments
+            # and the update count move over (gluon's Trainer is independent of the input size)
+            tr = Trainer(self, size) if tr is None else tr.resized(size)
         return tr
 
     def backward(self, grads, lp_grads=None):

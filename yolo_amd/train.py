@@ -111,6 +111,17 @@ class Trainer(object):
         self._repack()
         self._packed_version = net._version
 
+    def resized(self, size):
+        """A Trainer for another image size with THIS one's hyper-parameters and optimiser state (Adam moments, update count):
+        the anchor grid and the activation plan depend on the size, the optimiser does not."""
+        new = Trainer(self.net, size, scale=self.scale, learning_rate=self.lr, positive_weight=self.pos_w, negative_weight=self.neg_w,
+                      car_rotate=self.car_rotate, beta1=self.b1, beta2=self.b2, eps=self.eps, lp_scale=self.lp_scale,
+                      lp_r_max=self.lp_r_max, lp_positive_weight=self.lp_pos_w, lp_negative_weight=self.lp_neg_w)
+        new.mflat.copy_(self.mflat)
+        new.vflat.copy_(self.vflat)
+        new.t = self.t
+        return new
+
     # ---- weight images for the forward and data-gradient convolutions (re-packed after every update) ----
     def _repack(self):
         """Forward and data-gradient weight images of every conv, re-packed after each update in ONE launch
