@@ -744,6 +744,7 @@ extern "C" int yolo_pack_conv_weights_pairs(const void* items_device, const long
 
 extern "C" long long yolo_packed_weight_bytes(int Cout, int Cin, int ksize, int dtype) {
     if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 2 && ksize != 3)) return YOLO_EINVAL;
+    if (dtype != YOLO_BF16 && dtype != YOLO_F32) return YOLO_EINVAL;
     const int nchunks = (Cin * elem_size(dtype) + 63) / 64;
     return (long long)nchunks * ksize * ksize * round_up(Cout, YOLO_COUT_PAD) * 64;
 }

@@ -1359,7 +1359,8 @@ __global__ void dilate2_kernel(const T* __restrict__ dy, T* __restrict__ d, int 
 
 extern "C" int yolo_dilate2x(const void* dy, void* d, int N, int H, int W, int Ho, int Wo, int C, int dtype,
                              void* stream) {
-    if (!dy || !d || N <= 0 || H <= 0 || W <= 0 || C <= 0) return YOLO_EINVAL;
+    if (!dy || !d || N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || C <= 0) return YOLO_EINVAL;
+    if (2 * Ho - 1 > H || 2 * Wo - 1 > W) return YOLO_EINVAL;     // dy pixel (i, j) lands on (2i, 2j): it must exist in the target
     if (C % 8) return YOLO_EUNSUPPORTED;
     const long long total8 = (long long)N * H * W * (C / 8);
     const unsigned nb = (unsigned)((total8 + 255) / 256);
