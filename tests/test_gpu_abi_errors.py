@@ -77,6 +77,47 @@ def test_invalid_arguments_return_a_status(cuda):
     chk('dilate2x dy larger than the target allows', lib.yolo_dilate2x(p, p, 1, 8, 8, 5, 5, 8, L.BF16, st))
     chk('dilate2x Ho=0', lib.yolo_dilate2x(p, p, 1, 8, 8, 0, 4, 8, L.BF16, st))
 
+    # second sweep: the fused / elementwise / training families with NULL pointers and empty extents
+    g2 = L.GridDesc()
+    s5 = (C.c_float * 5)(0.1, 0.01, 10.0, 0.0, 0.3)
+    chk('stem_conv_fwd NULL', lib.yolo_stem_conv_fwd(None, p, p, p, p, 1, 8, 8, 3, 32, L.BF16, f(0.1), st))
+    chk('stem_conv_fwd N=0', lib.yolo_stem_conv_fwd(p, p, p, p, p, 0, 8, 8, 3, 32, L.BF16, f(0.1), st))
+    chk('stem_conv_fwd cin=5', lib.yolo_stem_conv_fwd(p, p, p, p, p, 1, 8, 8, 5, 32, L.BF16, f(0.1), st))
+    chk('stem_down_fwd NULL', lib.yolo_stem_down_fwd(None, p, p, p, p, p, p, p, 1, 8, 8, 32, 64, L.BF16, f(0.1), st))
+    chk('stem_down_fwd widths 16 -> 64', lib.yolo_stem_down_fwd(p, p, p, p, p, p, p, p, 1, 8, 8, 16, 64, L.BF16, f(0.1), st))
+    chk('res_block_fwd NULL', lib.yolo_res_block_fwd(None, p, p, p, p, p, p, p, 1, 8, 8, 64, L.BF16, f(0.1), st))
+    chk('res_block_fwd C=96', lib.yolo_res_block_fwd(p, p, p, p, p, p, p, p, 1, 8, 8, 96, L.BF16, f(0.1), st))
+    chk('res_block_fwd f32', lib.yolo_res_block_fwd(p, p, p, p, p, p, p, p, 1, 8, 8, 64, L.F32, f(0.1), st))
+    chk('composite n=0', lib.yolo_composite(p, p, p, p, C.c_longlong(0), st))
+    chk('composite NULL', lib.yolo_composite(None, p, p, p, C.c_longlong(8), st))
+    chk('composite_unit NULL', lib.yolo_composite_unit(p, None, p, p, C.c_longlong(8), st))
+    chk('upsample2x_concat NULL', lib.yolo_upsample2x_concat(None, p, p, 1, 8, 8, 8, 8, L.BF16, st))
+    chk('upsample2x_concat C not 16-byte', lib.yolo_upsample2x_concat(p, p, p, 1, 8, 8, 3, 8, L.BF16, st))
+    chk('predict_lp hw=0', lib.yolo_predict_lp(p, p, p, 10, 0, 0, f(45), f(60), f(45), st))
+    chk('predict_lp C=3', lib.yolo_predict_lp(p, p, p, 3, 4, 4, f(45), f(60), f(45), st))
+    chk('image_u8_to_nchw NULL', lib.yolo_image_u8_to_nchw(None, p, 1, 8, 8, 3, st))
+    chk('nhwc_to_nchw C=0', lib.yolo_nhwc_to_nchw(p, p, 1, 0, 8, 8, L.BF16, st))
+    chk('pack_conv_weights_dgrad k=5', lib.yolo_pack_conv_weights_dgrad(p, p, 32, 32, 5, L.BF16, st))
+    chk('pack_conv_weights_dgrad_s2 NULL', lib.yolo_pack_conv_weights_dgrad_s2(None, p, 32, 32, L.BF16, st))
+    chk('conv_dgrad_s2 NULL desc', lib.yolo_conv_dgrad_s2(None, st))
+    chk('pack_batch_blocks k=7', lib.yolo_pack_batch_blocks(32, 32, 7, L.BF16))
+    chk('pack_conv_weights_batch n=0', lib.yolo_pack_conv_weights_batch(p, p, 0, C.c_longlong(4), L.BF16, st))
+    chk('pack_pair_blocks Cin=24', lib.yolo_pack_pair_blocks(32, 24, 3))
+    chk('pack_conv_weights_pairs NULL', lib.yolo_pack_conv_weights_pairs(None, p, 1, C.c_longlong(4), st))
+    chk('bias_grad C=0', lib.yolo_bias_grad(p, p, C.c_longlong(8), 0, C.c_longlong(8), L.BF16, st))
+    chk('gather_rows NULL', lib.yolo_gather_rows(None, p, 8, C.c_longlong(8), 8, 8, C.c_longlong(8), C.c_longlong(8), L.BF16, st))
+    chk('upsample2x_concat_bwd NULL', lib.yolo_upsample2x_concat_bwd(None, p, p, 1, 8, 8, 8, 8, 0, 0, L.BF16, st))
+    chk('assign_targets NULL grid', lib.yolo_assign_targets(p, p, p, 1, 1, 4, None, st))
+    chk('assign_targets B=0', lib.yolo_assign_targets(p, p, p, 0, 1, 4, C.byref(g2), st))
+    chk('loss_fwd_bwd B=0', lib.yolo_loss_fwd_bwd(p, p, p, p, 0, 10, 10, 1, s5, f(1.0), f(0.1), st))
+    chk('loss_fwd_bwd NULL scales', lib.yolo_loss_fwd_bwd(p, p, p, p, 1, 10, 10, 1, None, f(1.0), f(0.1), st))
+    chk('assign_targets_lp B=0', lib.yolo_assign_targets_lp(p, p, 0, 1, 4, 8, 8, 16, 64, f(45), f(60), f(45), st))
+    chk('loss_lp_fwd_bwd NULL', lib.yolo_loss_lp_fwd_bwd(None, p, p, p, 1, 10, 10, 1, s5, f(1.0), f(0.1), st))
+    chk('conv_wgrad_workspace_bytes k=5', lib.yolo_conv_wgrad_workspace_bytes(32, 32, 5, L.BF16))
+    chk('nms_workspace_bytes B=0', lib.yolo_nms_workspace_bytes(0, 10, 30, 1, 400))
+    chk('nms_select_workspace_bytes B=0', lib.yolo_nms_select_workspace_bytes(0))
+    chk('bn_train_fwd_partials rows=0', lib.yolo_bn_train_fwd_partials(p, 0, 32, p, p, p, None, p, p, p, p, p, p, p, 16, C.c_longlong(64), 8, f(1e-5), f(0.9), f(0.1), L.BF16, st))
+    chk('bn_train_bwd_partials f32', lib.yolo_bn_train_bwd_partials(p, 4, 32, p, p, p, p, p, p, p, p, p, p, p, 16, C.c_longlong(64), 8, f(0.1), L.F32, st))
     torch.cuda.synchronize()
     assert not bad, bad
     assert float(buf.abs().sum()) == 0                     # nothing was launched on the scratch buffer

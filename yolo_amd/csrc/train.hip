@@ -1182,6 +1182,7 @@ __global__ void wgrad_finish_kernel(float* __restrict__ dwt, float* __restrict__
 }
 
 extern "C" long long yolo_conv_wgrad_workspace_bytes(int Cin, int Cout, int ksize, int dtype) {
+    if (Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (dtype != YOLO_BF16 && dtype != YOLO_F32)) return YOLO_EINVAL;
     if (dtype != YOLO_BF16) return 0;
     return (long long)Cin * Cout * ksize * ksize * 4;
 }
