@@ -130,6 +130,23 @@ def test_adam_c_abi_vector_and_unaligned(cuda, n, offset):
     np.testing.assert_allclose(ref[2], v, rtol=1e-5, atol=1e-8)
 
 
+def test_train_step_rejects_malformed_labels(cuda):
+    """Label tensors of the wrong rank, batch or row width raise ValueError before anything is launched (their rows would be
+    read with the wrong stride); CPU / float64 labels are converted."""
+    spec, size, g, P, x, lab, net, tr = _setup(cuda)
+    xt, lt = torch.from_numpy(x).to(cuda), torch.from_numpy(lab).to(cuda)
+    w = tr.wflat.clone()
+    for bad in (lt[..., :-1], lt[:, 0], lt[:1], torch.cat([lt, lt], dim=0), lt[:, :0]):
+        with pytest.raises(ValueError):
+            tr.train_step(xt, bad)
+    with pytest.raises(ValueError):
+        tr.train_step(torch.rand((2, 3, size[0] + 32, size[1]), device=cuda), lt)
+    assert torch.equal(w, tr.wflat) and tr.t == 0
+    a = tr.train_step(xt, lt, update=False)
+    b = tr.train_step(xt, lt.cpu().double(), update=False)
+    assert torch.equal(a, b)
+
+
 def test_trainer_for_another_size_keeps_the_optimiser_state(cuda):
     """net.trainer(size) for a new image size: new grid and plan, the same hyper-parameters, Adam moments and update count."""
     from yolo_amd.train import Trainer

@@ -735,11 +735,18 @@ class Trainer(object):
         cls < 0 = no object.  Returns losses (5,B) [score, box_yx, box_hw, rotate, class] (device)."""
         lib, st = self.lib, L.stream_ptr()
         labels = labels.to(self.dev, torch.float32).contiguous()
+        C_ = self.net.graph.per_anchor
+        if labels.dim() != 3 or labels.shape[0] != images.shape[0] or labels.shape[1] < 1 or labels.shape[2] != C_:
+            # (the kernels take the row width from the net: a label tensor of another width would be read with the wrong stride)
+            raise ValueError('labels must be (B=%d, nobj >= 1, %d) [cls, y, x, h, w, rot, class distribution...], got %s'
+                             % (images.shape[0], C_, tuple(labels.shape)))
+        if self.net.graph.lp_out is not None and lp_labels is not None:
+            if lp_labels.dim() != 3 or lp_labels.shape[0] != images.shape[0] or lp_labels.shape[1] < 1:
+                raise ValueError('lp_labels must be (B=%d, nobj >= 1, 10), got %s' % (images.shape[0], tuple(lp_labels.shape)))
         self.forward(images)
         P = self._plans[self._fwd_B]
         B, _, H, W = images.shape
         nobj, ncls = labels.shape[1], labels.shape[2] - 6
-        C_ = self.net.graph.per_anchor
         rec = torch.empty((B, nobj, 7 + ncls), dtype=torch.float32, device=self.dev)
         L.check(lib.yolo_assign_targets(L.ptr(labels), L.ptr(self.anchors_ltrb), L.ptr(rec), B, nobj, ncls,
                                         C.byref(self.grid), st), 'assign')
