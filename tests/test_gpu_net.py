@@ -253,3 +253,53 @@ def test_fused_stem_matches_unfused(cuda):
         outs.append([t.clone() for t in o])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_two_nets_on_two_streams_and_two_threads(cuda):
+    """"distinct streams are independent (no global mutable state)".  Two nets (different specs) launched
+    interleaved on two streams from one thread, then from two host threads with a stream each: every result bit-identical to
+    the serial one."""
+    import threading
+    from yolo_amd.net import CarNet
+    from yolo_amd.detect import Detector
+    specs, sizes = [og.spec_micro(), og.spec_d53()], [(96, 160), (160, 160)]
+    nets, xs, refs, dets = [], [], [], []
+    for sp, sz in zip(specs, sizes):
+        n = CarNet(sp, dtype='bf16', device=cuda).initialize(seed=3)
+        x = torch.rand(4, 3, *sz, device=cuda)
+        o = [t.clone() for t in n(x)]
+        d = Detector(sp, sz, n.graph.steps(), device=cuda)
+        p, i = d.predict_device(o)
+        nets.append(n); xs.append(x); refs.append((o, p.clone(), i.clone())); dets.append(d)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=cuda) for _ in range(2)]
+    for rep in range(10):
+        outs = []
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                o = nets[k](xs[k])
+                p, i = dets[k].predict_device(o)
+                outs.append(([t.clone() for t in o], p.clone(), i.clone()))
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert all(torch.equal(a, b) for a, b in zip(outs[k][0], refs[k][0])), (rep, k)
+            assert torch.equal(outs[k][1], refs[k][1]) and torch.equal(outs[k][2], refs[k][2]), (rep, k)
+    errs = []
+
+    def worker(k):
+        try:
+            st = torch.cuda.Stream(device=cuda)
+            with torch.cuda.stream(st):
+                for rep in range(20):
+                    o = nets[k](xs[k])
+                    _, i = dets[k].predict_device(o)
+                    st.synchronize()
+                    if not (all(torch.equal(a, b) for a, b in zip(o, refs[k][0])) and torch.equal(i, refs[k][2])):
+                        errs.append((k, rep))
+                        return
+        except Exception as e:                                       # noqa: BLE001 (reported through the assert below)
+            errs.append((k, repr(e)))
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errs, errs
