@@ -119,3 +119,15 @@ def test_committed_bench_line_follows_the_contract():
     c = d['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['sample']
     assert abs(d['value'] - d['n_gpus'] * d['config']['global_batch'] / d['n_gpus'] / (d['ms_per_step'] / 1e3)) / d['value'] < 0.01
+
+
+def test_objects_refuse_a_foreign_current_device(monkeypatch):
+    """One process per GPU: an object built for cuda:1 used while cuda:0 is current must be refused (its kernels would be
+    launched on the wrong device); same device: no complaint."""
+    import torch
+    from yolo_amd import lib as L
+    monkeypatch.setattr(torch.cuda, 'current_device', lambda: 0)
+    L.require_current_device(torch.device('cuda:0'), 'x')
+    L.require_current_device(torch.device('cuda'), 'x')
+    with pytest.raises(L.YoloError, match='set_device'):
+        L.require_current_device(torch.device('cuda:1'), 'this CarNet')

@@ -49,6 +49,7 @@ class Detector(object):
 
     def _merged(self, outs):
         """Accepts the list of per-scale outputs (fine->coarse) or an already merged (B,N,A,C) tensor."""
+        L.require_current_device(self.device, 'this Detector')
         if isinstance(outs, (list, tuple)):
             base = outs[0]._base
             if (base is not None and all(o._base is base for o in outs) and base.dim() == 3

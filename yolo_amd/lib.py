@@ -143,3 +143,15 @@ def ptr(t):
 def stream_ptr():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def require_current_device(device, what):
+    """The library launches on the CURRENT device's current stream (one process per GPU: `torch.cuda.set_device(LOCAL_RANK)`
+    first, as bench.py does).  An object living on another GPU than the current one would have its kernels launched on the
+    wrong device with its pointers -- refuse that here instead."""
+    import torch
+    idx = device.index if device.index is not None else 0
+    cur = torch.cuda.current_device()
+    if cur != idx:
+        raise YoloError('%s lives on cuda:%d but the current device is cuda:%d: call torch.cuda.set_device(%d) (one process '
+                        'per GPU) before using it' % (what, idx, cur, idx))

@@ -450,6 +450,7 @@ class CarNet(object):
             # reference's defaults; `Trainer(net, size, ...)` beforehand to choose the hyper-parameters).
             tr = self.trainer((int(x.shape[2]), int(x.shape[3])))
             return tr.forward(x)
+        L.require_current_device(self.device, 'this CarNet')
         self._ensure_prepared()
         if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or not x.is_cuda:
             raise ValueError('expected a (B,3,H,W) float32 CUDA tensor')

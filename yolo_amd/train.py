@@ -646,6 +646,7 @@ class Trainer(object):
         """`self.net(bx)` in train mode (car/YOLO.py:381): (B,3,H,W) float32 NCHW -> list of 3 fp32 (B, HiWi, A, C) logits
         fine -> coarse with batch-statistics BatchNorm (running statistics updated); CarLPNet: (outs, [LP_output]).  The
         tensors are views of one buffer that the next forward of the same batch size overwrites."""
+        L.require_current_device(self.dev, 'this Trainer')
         if images.dim() != 4 or images.shape[1] != 3 or images.dtype != torch.float32 or not images.is_cuda:
             raise ValueError('expected a (B,3,H,W) float32 CUDA tensor')
         images = images.contiguous()
