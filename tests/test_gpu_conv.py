@@ -58,6 +58,27 @@ def test_conv_bf16(lib, cuda, case):
     assert np.mean(np.abs(y - ref) > 1e-3 * (1 + np.abs(ref))) < 0.02
 
 
+# shapes no width-dividing strip fits (prime widths on tall batches, maps one or two pixels wide): the generic kernel's ragged
+# strips / row-limited tiles (launch_cfg's fallback; these were refused with -2 until round 3 -- found by fuzzing the C ABI)
+RAGGED = [(5, 16, 25, 61, 48, 3, 1, False), (5, 512, 38, 61, 384, 3, 1, False), (5, 320, 33, 67, 256, 3, 1, True),
+          (5, 16, 39, 1, 64, 3, 1, False), (5, 256, 34, 61, 8, 3, 1, True), (4, 32, 31, 122, 64, 3, 2, False),
+          (6, 24, 29, 2, 32, 3, 1, True), (5, 96, 31, 61, 256, 3, 1, False)]
+
+
+@pytest.mark.parametrize('algo', [0, 1])
+@pytest.mark.parametrize('dtype', ['bf16', 'f32'])
+@pytest.mark.parametrize('case', RAGGED)
+def test_conv_widths_no_strip_divides(lib, cuda, case, dtype, algo):
+    x, w, scale, bias, r = _mk(case, 5)
+    y = run_conv(lib, cuda, x, w, scale, bias, case[6], 0.1, dtype, residual=r, algo=algo)
+    ref = ref_conv(x, w, scale, bias, case[6], 0.1, residual=r, bf16=(dtype == 'bf16'))
+    assert not np.isnan(y).any()
+    if dtype == 'f32':
+        np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-4)
+    else:
+        np.testing.assert_allclose(y, ref, rtol=1.6e-2, atol=2e-2)
+
+
 def test_conv_out_f32_linear(lib, cuda):
     """Head-logit mode: bias only, linear, float32 output from bf16 activations."""
     case = (2, 64, 13, 13, 90, 1, 1, False)

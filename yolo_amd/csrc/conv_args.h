@@ -30,6 +30,7 @@ struct ConvArgs {
     char* y;
     int N, H, W, Cin, Ho, Wo, Cout, Cout_pad;
     int TWt, nstrips, tiles_per_strip, PW, total_i;
+    int tile_px;            // conv_igemm.hip: strip pixels a tile covers (= its 128 unless the shape needs row-limited tiles); 0 elsewhere
     int nchunks, tiles_c;
     int out_f32;
     int x_ps;       // elements between input pixels (>= Cin: x may be a channel slice of a wider NHWC buffer)

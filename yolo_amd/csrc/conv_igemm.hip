@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int tile_c = bid % a.tiles_c;
     const int tile_p = bid / a.tiles_c;
     const int strip = tile_p / a.tiles_per_strip;
-    const int i0 = (tile_p - strip * a.tiles_per_strip) * BP;
+    const int i0 = (tile_p - strip * a.tiles_per_strip) * a.tile_px;       // (tile_px = BP except for row-limited tiles, launch_cfg)
     const int co0 = tile_c * BC;
     const int H = a.H, W = a.W, Ho = a.Ho, Wo = a.Wo, TWt = a.TWt, PW = a.PW;
     const int row_bytes = a.Cin * (int)sizeof(T);           // channel extent of a pixel
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     // ---- geometry of the staged input tile ----------------------------------------------
     int Rin_lo = 0, HS = XSLOTS, x0 = 0;
     if constexpr (KS == 3) {
-        const int i_last = min(i0 + BP, a.total_i) - 1;
+        const int i_last = min(i0 + a.tile_px, a.total_i) - 1;
         const int r_first = i0 / TWt, r_last = i_last / TWt;
         const int n_f = r_first / Ho, n_l = r_last / Ho;
         Rin_lo = n_f * (H + 1) + (r_first - n_f * Ho) * S;
@@ -132,12 +132,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int i = i0 + (wave_p * NI + ni) * 32 + l31;
-        const bool ok = i < a.total_i;
+        bool ok = i < a.total_i && i - i0 < a.tile_px;
         const int ii = ok ? i : i0;
         int n, pix;
         if constexpr (KS == 3) {
             const int r = ii / TWt;
             const int tx = ii - r * TWt;
+            if (strip * TWt + tx >= Wo) ok = false;            // (a ragged last strip: launch_cfg's fallback for widths no strip divides)
             n = r / Ho;
             const int oy = r - n * Ho;
             const int slot00 = (n * (H + 1) + oy * S - Rin_lo) * PW + tx * S;
@@ -322,18 +323,32 @@ static int launch_cfg(ConvArgs& a, hipStream_t st, const NameOut* name) {
             const int hs = conv_halo_slots(BP, d, a.Ho, a.H, S, (long long)a.N * a.Ho);
             if (hs <= XSLOTS && hs <= best_hs) { best = d; best_hs = hs; }
         }
-        if (best < 0) return YOLO_EUNSUPPORTED;
+        a.tile_px = BP;
+        if (best < 0) {
+            // No divisor of the width gives strips whose 128-pixel tiles fit the staged halo (prime widths on tall batches, maps a
+            // pixel or two wide): strips of ANY width -- the last one ragged, its missing columns masked in the kernel -- and tiles
+            // limited to whole rows of the strip, as many as the halo holds.  The widest strip that works wins.
+            for (int d = a.Wo < BP ? a.Wo : BP; d >= 1 && best < 0; --d)
+                for (int rows = BP / d; rows >= 1; --rows)
+                    if (conv_halo_slots(rows * d, d, a.Ho, a.H, S, (long long)a.N * a.Ho) <= XSLOTS) {
+                        best = d;
+                        a.tile_px = rows * d;
+                        break;
+                    }
+            if (best < 0) return YOLO_EUNSUPPORTED;
+        }
         a.TWt = best;
         a.PW = (best - 1) * S + 3;
     } else {
         a.TWt = a.Wo;
         a.PW = a.Wo;
+        a.tile_px = BP;
     }
-    a.nstrips = a.Wo / a.TWt;
+    a.nstrips = (a.Wo + a.TWt - 1) / a.TWt;
     const long long tot = (long long)a.N * a.Ho * a.TWt;
     if (tot > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
     a.total_i = (int)tot;
-    a.tiles_per_strip = (a.total_i + BP - 1) / BP;
+    a.tiles_per_strip = (a.total_i + a.tile_px - 1) / a.tile_px;
     a.tiles_c = (a.Cout + BC - 1) / BC;
     const long long grid = (long long)a.nstrips * a.tiles_per_strip * a.tiles_c;
     if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
