@@ -40,12 +40,11 @@ while time.time() - t0 < budget:
     # its channel's dgamma / dbeta (and through them every dy of the channel) by O(dz): such channels are compared on z only
     a_ref = ((yf - mean) / torch.sqrt(var + 1e-5) * gam + bet).detach()
     chan_ok = ~(a_ref.abs() < 2e-5 * (1 + a_ref.abs().amax(dim=0, keepdim=True))).any(dim=0)
-    # a handful of nearly equal values: the kernels' one-pass variance (fp32 partial sums of y and y*y, combined in double) loses
-    # digits when mean^2 >> variance -- 0.4 % in invstd at mean^2 / var ~ 10^6, against torch's two-pass fp32 -- DESIGN 5
-    few = npix < 16
+    few = False                                          # (until round 3 the one-pass variance lost digits on a handful of nearly
+                                                         #  equal values; the sums are now taken around a value of the channel)
     ncase += 1
     tol = (1e-4, 1e-5) if dtype == 'f32' else (1e-2, 1e-2)
-    if few: tol = (tol[0] * 50, tol[1] * 50)
+    if npix < 16: tol = (tol[0] * 20, tol[1] * 20)            # (invstd up to 316: rounding noise of y - mean is amplified)
     for form in ('three', 'pp'):
         zd = torch.full_like(y, float('nan')); m_ = torch.empty(C_, device=dev); is_ = torch.empty(C_, device=dev)
         rm = torch.zeros(C_, device=dev); rv = torch.ones(C_, device=dev)
@@ -74,7 +73,7 @@ while time.time() - t0 < budget:
         close(form + ' running_var', rv, 0.9 + 0.1 * var.detach(), 1e-4, 1e-6, ctx)
         if not bool(chan_ok.any()):
             continue
-        gscale = float(yf.grad[:, chan_ok].abs().max()) + 1e-9
+        gscale = float(yf.grad[:, chan_ok].abs().max()) + 1e-6
         close(form + ' dy', dyd[:, chan_ok], yf.grad[:, chan_ok], tol[0] * 10, tol[1] * gscale * (1 if dtype == 'bf16' else 10), ctx)
         close(form + ' dgamma', dg[chan_ok], gam.grad[chan_ok], 2e-3, 2e-3 * (float(gam.grad[chan_ok].abs().max()) + 1e-6), ctx)
         close(form + ' dbeta', db[chan_ok], bet.grad[chan_ok], 2e-3, 2e-3 * (float(bet.grad[chan_ok].abs().max()) + 1e-6), ctx)

@@ -70,14 +70,22 @@ static void bn_partition(long long npix, int C, int elem, bool reduces, int* ppb
     *nb = (unsigned)((npix + p - 1) / p);
 }
 
-// MODE 0: sums[0..C) = sum(y), sums[C..2C) = sum(y*y)
+// one element as float (the pivot of the shifted sums below)
+template <typename T> __device__ __forceinline__ float ld1(const T* p);
+template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(p)); }
+
+// MODE 0: sums[0..C) = sum(y), sums[C..2C) = sum(y*y) -- or, with `shift`, the same sums of (y - k_c), k_c = the channel's value
+//         at pixel 0: a one-pass variance from fp32 partial sums loses digits when mean^2 >> variance (0.4 % in invstd at a ratio of
+//         10^6 -- a few nearly equal values, i.e. the tiny deepest maps of small inputs; found by tools/fuzz_bn.py /
+//         fuzz_labels.py), and around a value of the channel itself that ratio is of order one.  The finalize adds k_c back.
 // MODE 1: sums[0..C) = sum(da), sums[C..2C) = sum(da*xhat), da = dz * lrelu'(gamma*xhat+beta)
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ y, const T* __restrict__ dz,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         double* __restrict__ sums, int C, long long npix,
-                                                        int pix_per_block, float slope) {
+                                                        int pix_per_block, float slope, int shift = 0) {
     constexpr int U = MODE == 0 ? 8 : 4;
     __shared__ float red[2][256][8];
     const int noct = C >> 3;
@@ -95,6 +103,10 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ y,
         for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
         if (oct < noct && pl < lanes) {
             float mu[8], is[8], g[8], b[8];
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) mu[e] = shift ? ld1<T>(y + oct * 8 + e) : 0.f;      // the pivots k_c
+            }
             if (MODE == 1) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { mu[e] = mean[oct * 8 + e]; is[e] = invstd[oct * 8 + e]; g[e] = gamma[oct * 8 + e]; b[e] = beta[oct * 8 + e]; }
@@ -102,7 +114,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ y,
             auto accum = [&](const float (&v)[8], const float (&d)[8]) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    if (MODE == 0) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+                    if (MODE == 0) { const float dv = v[e] - mu[e]; s[e] += dv; q[e] += dv * dv; }
                     else {
                         const float xh = (v[e] - mu[e]) * is[e];
                         const float da = d[e] * ((g[e] * xh + b[e]) > 0.f ? 1.f : slope);
@@ -148,14 +160,17 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ y,
 
 // mean / invstd (biased variance, eps) + running-stat update (momentum m: r = m*r + (1-m)*batch;
 // running_var takes the BIASED batch variance -- the MXNet CPU convention).
+template <typename T>
 __global__ void bn_finalize_kernel(double* __restrict__ sums, float* __restrict__ mean,
                                    float* __restrict__ invstd, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, int C, double inv_n, float eps, float momentum) {
+                                   float* __restrict__ running_var, int C, double inv_n, float eps, float momentum,
+                                   const T* __restrict__ pivot) {        // pivot: pixel 0 of y when the sums are shifted, else NULL
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double m = sums[c] * inv_n;
-    double v = sums[C + c] * inv_n - m * m;
+    const double d = sums[c] * inv_n;
+    double v = sums[C + c] * inv_n - d * d;
     if (v < 0) v = 0;
+    const double m = d + (pivot ? (double)ld1<T>(pivot + c) : 0.0);
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(v + (double)eps));
     sums[c] = 0.0;                                   // leave the workspace zeroed for the next call
@@ -192,6 +207,7 @@ struct BnFused {
     float* dgamma_out; float* dbeta_out;                                             // MODE 1
     double inv_n;
     float eps, momentum;
+    int shifted;              // MODE 0: the sums are of (y - y[pixel 0][c]) (bn_reduce_kernel's shift)
 };
 
 template <typename T, int MODE, int FUSED = 0>
@@ -210,9 +226,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
     if (FUSED && blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += 256) {
             if (MODE == 0) {
-                const double m = f.sums[c] * f.inv_n;
-                double v = f.sums[C + c] * f.inv_n - m * m;
+                const double d = f.sums[c] * f.inv_n;
+                double v = f.sums[C + c] * f.inv_n - d * d;
                 if (v < 0) v = 0;
+                const double m = d + (f.shifted ? (double)ld1<T>(y + c) : 0.0);
                 f.mean_out[c] = (float)m;
                 f.invstd_out[c] = (float)(1.0 / sqrt(v + (double)f.eps));
                 if (f.running_mean) {
@@ -235,9 +252,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
         for (int e = 0; e < 8; ++e) {
             const int c = oct * 8 + e;
             if (FUSED && MODE == 0) {
-                const double m = f.sums[c] * f.inv_n;
-                double v = f.sums[C + c] * f.inv_n - m * m;
+                const double d = f.sums[c] * f.inv_n;
+                double v = f.sums[C + c] * f.inv_n - d * d;
                 if (v < 0) v = 0;
+                const double m = d + (f.shifted ? (double)ld1<T>(y + c) : 0.0);
                 mu[e] = (float)m; is[e] = (float)(1.0 / sqrt(v + (double)f.eps));
             } else {
                 mu[e] = mean[c]; is[e] = invstd[c];
@@ -358,10 +376,11 @@ static int bn_fwd_t(const T* y, const float* gamma, const float* beta, const T* 
     bn_partition(npix, C, (int)sizeof(T), false, &ppa, &na);
     if (part)       // the producing convolution already took the sums (its statistics epilogue): no pass over y
         bn_stats_finish(part, part_rows, C, part_cp, workspace, st);
-    else
+    else                                                      // (shifted sums: see bn_reduce_kernel)
         YOLO_LAUNCH((bn_reduce_kernel<T, 0>), dim3(nb, (C + BN_CG - 1) / BN_CG), dim3(256), 0, st, y, (const T*)nullptr, (const float*)nullptr,
-                    (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, workspace, C, npix, ppb, slope);
+                    (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, workspace, C, npix, ppb, slope, 1);
     BnFused f = {};
+    f.shifted = part ? 0 : 1;
     if (fused) {
         f.sums = workspace; f.zero_next = zero_next; f.zero_n = zero_n; f.mean_out = mean; f.invstd_out = invstd;
         f.running_mean = running_mean; f.running_var = running_var; f.inv_n = 1.0 / (double)npix; f.eps = eps; f.momentum = momentum;
@@ -370,8 +389,8 @@ static int bn_fwd_t(const T* y, const float* gamma, const float* beta, const T* 
         YOLO_LAUNCH_CHECK();
         return YOLO_OK;
     }
-    YOLO_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, mean, invstd, running_mean,
-                running_var, C, 1.0 / (double)npix, eps, momentum);
+    YOLO_LAUNCH(bn_finalize_kernel<T>, dim3((C + 255) / 256), dim3(256), 0, st, workspace, mean, invstd, running_mean,
+                running_var, C, 1.0 / (double)npix, eps, momentum, part ? (const T*)nullptr : y);
     YOLO_LAUNCH((bn_apply_kernel<T, 0>), dim3(na), dim3(256), 0, st, y, residual, mean, invstd, gamma, beta,
                 (const float*)nullptr, (const float*)nullptr, 0.f, z, C, npix, ppa, slope, f);
     YOLO_LAUNCH_CHECK();

@@ -217,7 +217,9 @@ class Trainer(object):
             d = self._conv_desc(xin.val, xin.shape, wp, ident[0], ident[1], yraw.val, Cc, c.cout, c.k, c.stride)
             self._tune(d)
             op = dict(kind='conv_bn', c=c, x=xin, yraw=yraw, z=z, mean=mean, invstd=invstd, res=residual, desc=d, srows=0, brows=0)
-            if self._fuse_fwd and not (c is g.stem) and self._pipe_kernel(d):
+            # (small maps keep the reduction pass of their own: it costs nothing there, and its sums are taken around a value of the
+            #  channel -- the epilogue's plain fp32 partial sums lose digits when a few nearly equal values make mean^2 >> variance)
+            if self._fuse_fwd and not (c is g.stem) and N * ho * wo >= 4096 and self._pipe_kernel(d):
                 d.stats, d.stats_mode = 1, 1                      # (any non-NULL pointer for the query)
                 rows = self.lib.yolo_conv_stats_rows(C.byref(d))
                 if rows > 0:
