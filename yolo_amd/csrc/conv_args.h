@@ -30,6 +30,7 @@ struct ConvArgs {
     char* y;
     int N, H, W, Cin, Ho, Wo, Cout, Cout_pad;
     int TWt, nstrips, tiles_per_strip, PW, total_i;
+    int halo_strict;        // conv_pipe.hip launch_pipe: leave one slot of the staged halo unused (the 2x2-window 4-wave tile)
     int tile_px;            // conv_igemm.hip: strip pixels a tile covers (= its 128 unless the shape needs row-limited tiles); 0 elsewhere
     int nchunks, tiles_c;
     int out_f32;

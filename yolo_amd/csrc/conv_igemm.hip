@@ -473,6 +473,7 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     a.nchunks = (d->Cin * es + 63) / 64;
     a.out_f32 = d->out_f32;
     a.d2s = 0;
+    a.halo_strict = 0;
     a.up2 = d->upsample2x ? 1 : 0;
     if (d->x_pixel_stride < 0 || (d->x_pixel_stride && d->x_pixel_stride < d->Cin) || d->x_pixel_stride > 0x7fffffffLL) return YOLO_EINVAL;
     a.x_ps = d->x_pixel_stride ? (int)d->x_pixel_stride : d->Cin;
@@ -552,6 +553,7 @@ extern "C" int yolo_conv_dgrad_s2(const yolo_conv_desc* d, void* stream) {
     a.Cout_pad = round_up(d->Cout, YOLO_COUT_PAD);
     a.nchunks = (d->Cin * 2 + 63) / 64;
     a.out_f32 = 0; a.d2s = 1; a.up2 = 0; a.x_ps = d->Cin; a.slope = d->slope;
+    a.halo_strict = 0;
     a.stats = nullptr; a.stats_mode = 0;
     if (d->x_pixel_stride || d->upsample2x || d->stats) return YOLO_EUNSUPPORTED;
     a.y_ps = d->Cout / 4;
@@ -561,7 +563,7 @@ extern "C" int yolo_conv_dgrad_s2(const yolo_conv_desc* d, void* stream) {
     if (d->algo) return conv_pipe_dispatch(a, 2, 1, d->dtype, d->algo, st, nullptr);
     // rounds x tile cost as in conv_auto_algo, then the first variant whose halo fits
     struct V { int algo, bp, bc, bpc; };
-    static const V vs[] = {{2, 256, 256, 1}, {6, 192, 256, 1}, {10, 128, 256, 1}, {4, 128, 128, 2}};
+    static const V vs[] = {{2, 256, 256, 1}, {6, 192, 256, 1}, {10, 128, 256, 1}, {4, 128, 128, 2}};      // (algo 4: large regular maps only, conv_pipe.hip)
     const long long px = (long long)a.N * a.Ho * a.Wo;
     double cost[4];
     for (int i = 0; i < 4; ++i) {

@@ -562,7 +562,7 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
         for (int d = 1; d <= a.Wo; ++d) {
             if (a.Wo % d) continue;
             const int hs = conv_halo_slots(BP, d, a.Ho, a.H, S, (long long)a.N * a.Ho, KS);
-            if (hs <= XSLOTS && hs <= best_hs) { best = d; best_hs = hs; }
+            if (hs <= XSLOTS - (a.halo_strict ? 1 : 0) && hs <= best_hs) { best = d; best_hs = hs; }
         }
         if (best < 0) return YOLO_EUNSUPPORTED;
         a.TWt = best;
@@ -674,7 +674,15 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
                 case 2: return launch_pipe<T, 2, 2, 4, 2, 4, 512>(a, st, nm);    // 256 px x 256 cout
                 case 6: return launch_pipe<T, 2, 2, 4, 2, 3, 384>(a, st, nm);    // 192 px x 256 cout
                 case 10: return launch_pipe<T, 2, 2, 4, 2, 2, 384>(a, st, nm);   // 128 px x 256 cout
-                case 4: return launch_pipe<T, 2, 2, 2, 2, 2, 256>(a, st, nm);    // 128 px x 128 cout, 4 waves
+                case 4:                                                           // 128 px x 128 cout, 4 waves
+                    // RESTRICTED to large regular maps (width a multiple of 8, >= 1024 pixels per image): tools/fuzz_dgrad.py found
+                    // this tile returning wrong sub-pixel phases for a few pixels on two shapes out of 5000 -- dy of 25 x 2 and of
+                    // 17 x 31 at batch 6 -- where the three 8-wave tiles are exact.  Not root-caused (it is neither the halo
+                    // capacity nor tiles spanning several images alone); inside this domain 2 700 fuzzed shapes
+                    // (FUZZ_S2_REGULAR=1) and the device one-hop tests of the D53 step are exact, and it is what makes the first
+                    // down-sampling layer's data gradient 380 instead of 604 us at 416^2 batch 64.
+                    if ((a.Wo % 8) || (long long)a.Ho * a.Wo < 1024) return YOLO_EUNSUPPORTED;
+                    return launch_pipe<T, 2, 2, 2, 2, 2, 256>(a, st, nm);
             }
         }
         return YOLO_EUNSUPPORTED;
