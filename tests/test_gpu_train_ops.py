@@ -224,7 +224,7 @@ def test_wgrad_bf16_row_walk(lib, cuda, case, algo):
 
 @pytest.mark.parametrize('case', [(2, 32, 16, 24, 64), (3, 64, 26, 26, 128), (2, 8, 12, 20, 32), (1, 128, 52, 52, 256),
                                   (4, 256, 26, 26, 512), (70, 32, 4, 4, 64), (1, 40, 6, 10, 96), (2, 64, 2, 2, 32),
-                                  # the two shapes on which the 4-wave variant was wrong (tools/fuzz_dgrad.py): it refuses them now; and large regular maps, its domain
+                                  # the two shapes on which the 4-wave variant raced (an input DMA of a chunk's last phase read one phase later: conv_pipe.hip)
                                   (2, 32, 64, 64, 64), (3, 64, 48, 80, 128),
                                   (6, 256, 50, 4, 512), (6, 64, 34, 62, 256)])
 def test_dgrad_s2_subpixel(lib, cuda, case):

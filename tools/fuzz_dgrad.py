@@ -23,7 +23,7 @@ while time.time() - t0 < budget:
     cin = int(rng.choice([8, 16, 32, 64, 128, 256, 512])); cout = int(rng.choice([8, 32, 64, 128, 256, 512]))
     N = int(rng.choice([1, 2, 3, 6]))
     H = int(rng.integers(1, 30)) * s; W = int(rng.integers(1, 36)) * s
-    if os.environ.get('FUZZ_S2_REGULAR'):                 # the 4-wave sub-pixel tile's domain: dy width a multiple of 8, >= 1024 pixels
+    if os.environ.get('FUZZ_S2_REGULAR'):                 # large regular maps only (dy width a multiple of 8, >= 1024 pixels)
         k, s = 3, 2; W = 16 * int(rng.integers(1, 14)); lo = max(1, 2048 // W); H = 2 * int(rng.integers(lo, lo + 40))
         cin = int(rng.choice([8, 16, 32, 64, 128])); cout = int(rng.choice([32, 64, 128, 256])); N = int(rng.choice([1, 2, 3, 5]))
     if N * H * W * max(cin, cout) > (3e7 if os.environ.get('FUZZ_S2_REGULAR') else 6e6): continue

@@ -342,8 +342,17 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         }
         // phase gp+1's data must have landed: everything except what this phase issued for gp+2 (the
         // input DMAs are issued before the weight DMAs, so leaving WL outstanding covers them too)
-        if constexpr (KS != 1) wait_vmcnt<(WR - 2) * WL>();
-        else wait_vmcnt<(R1 - 2) * (WL + XL)>();
+        if constexpr (KS != 1) {
+            // (round 3, found by tools/fuzz_dgrad.py) 2x2 window with as many input DMAs per tile as phases per chunk (XL == PPC:
+            // the 4-wave 128 x 128 and the 8-wave 256 x 256 tiles): the LAST phase of a chunk issues an input DMA that the very
+            // next phase reads -- with a weight ring of four slots the counted wait above still lets it fly (it is older than
+            // this phase's weight DMAs only), and the tile computed on a stale unit whenever its halo reached into the last
+            // quarter of the staged slots.  There the wait keeps this phase's weight DMAs in flight and nothing else.
+            if (KS == 2 && XL == PPC && q == PPC - 1) wait_vmcnt<((WR - 2) * WL < WL ? (WR - 2) * WL : WL)>();
+            else wait_vmcnt<(WR - 2) * WL>();
+        } else {
+            wait_vmcnt<(R1 - 2) * (WL + XL)>();
+        }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);      // keep the next phase's address math out of this phase (VGPR pressure)
     };
@@ -674,14 +683,7 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
                 case 2: return launch_pipe<T, 2, 2, 4, 2, 4, 512>(a, st, nm);    // 256 px x 256 cout
                 case 6: return launch_pipe<T, 2, 2, 4, 2, 3, 384>(a, st, nm);    // 192 px x 256 cout
                 case 10: return launch_pipe<T, 2, 2, 4, 2, 2, 384>(a, st, nm);   // 128 px x 256 cout
-                case 4:                                                           // 128 px x 128 cout, 4 waves
-                    // RESTRICTED to large regular maps (width a multiple of 8, >= 1024 pixels per image): tools/fuzz_dgrad.py found
-                    // this tile returning wrong sub-pixel phases for a few pixels on two shapes out of 5000 -- dy of 25 x 2 and of
-                    // 17 x 31 at batch 6 -- where the three 8-wave tiles are exact.  Not root-caused (it is neither the halo
-                    // capacity nor tiles spanning several images alone); inside this domain 2 700 fuzzed shapes
-                    // (FUZZ_S2_REGULAR=1) and the device one-hop tests of the D53 step are exact, and it is what makes the first
-                    // down-sampling layer's data gradient 380 instead of 604 us at 416^2 batch 64.
-                    if ((a.Wo % 8) || (long long)a.Ho * a.Wo < 1024) return YOLO_EUNSUPPORTED;
+                case 4:                                                           // 128 px x 128 cout, 4 waves (see the wait at the end of `phase`)
                     return launch_pipe<T, 2, 2, 2, 2, 2, 256>(a, st, nm);
             }
         }
