@@ -1,28 +1,28 @@
 #!/usr/bin/env python
 """Where does the packed-fp32 corruption of the BatchNorm backward come from?  (csrc/Makefile NOPK, DESIGN 4.2, round-2
-verdict item 7.)  tools/pk_repro.hip -- a synthetic packed-VALU kernel beside a synthetic MFMA spinner -- does NOT
+verdict item 7.)  tools/erratum/pk_repro.hip -- a synthetic packed-VALU kernel beside a synthetic MFMA spinner -- does NOT
 reproduce it, so this script isolates the REAL kernel outside the Trainer: yolo_bn_train_bwd_pp from a library whose
 train.hip was built WITH the packed operations (`make -C yolo_amd/csrc pk` -> yolo_amd/csrc/_ab/libyolo_pk.so) runs
 on stream 1 on one fixed input while stream 2 runs, in turn: nothing; a bf16 torch.matmul (hipBLASLt's MFMA kernel: not
-this repository's code, its own buffers only); synthetic one-feature spinners (tools/pk_spin.hip: MFMA, plain and
+this repository's code, its own buffers only); synthetic one-feature spinners (tools/erratum/pk_spin.hip: MFMA, plain and
 transposing LDS reads, fp32 atomics, LDS-DMA); this library's forward convolution (generic register-staged kernel and
 pipelined LDS-DMA kernel) and its weight gradients (GEMM, strip, row walk) -- all on buffers of their own.  Every dy is
 compared bit for bit with the same call of the shipped (no packed operations) library run alone.
 
-    python tools/pk_bisect.py [rounds]
+    python tools/erratum/pk_bisect.py [rounds]
 """
 import ctypes as C
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 
 from yolo_amd import lib as L
 
 PK = os.environ.get('PK_LIB') or os.path.join(L.CSRC, '_ab', 'libyolo_pk.so')        # (PK_LIB: a variant build of the victim)
-TRIG = os.environ.get('TRIG_LIB')        # (a variant build of the co-running convolution, tools/pk_trigger.sh)
+TRIG = os.environ.get('TRIG_LIB')        # (a variant build of the co-running convolution, tools/erratum/pk_trigger.sh)
 ONLY = os.environ.get('PK_ONLY')         # (only the co-runners whose name contains this)
 
 

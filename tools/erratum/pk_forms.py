@@ -1,16 +1,16 @@
 #!/usr/bin/env python
-"""Which packed instruction form is the victim?    tools/pk_bisect.py + victim variants narrowed the BatchNorm
-corruption to the kernel's prologue; this probe runs ONE packed instruction form at a time (tools/pk_spin.hip victim_pkform:
+"""Which packed instruction form is the victim?    tools/erratum/pk_bisect.py + victim variants narrowed the BatchNorm
+corruption to the kernel's prologue; this probe runs ONE packed instruction form at a time (tools/erratum/pk_spin.hip victim_pkform:
 v_pk_mov_b32 op_sel:[1,0], v_pk_mul_f32, v_pk_add_f32 with neg modifiers) over two arrays beside this library's kernels (the
 co-runners that corrupt the real kernel) and checks every output pair against the instruction's definition.
 
-    python tools/pk_forms.py [rounds]
+    python tools/erratum/pk_forms.py [rounds]
 """
 import ctypes as C
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 

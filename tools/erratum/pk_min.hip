@@ -1,11 +1,11 @@
 // MINIMAL stand-alone reproducer (MI355X / gfx950): a packed fp32 instruction with CROSS-HALF operand selection
 //     v_pk_mul_f32 d, a, b op_sel:[0,1] op_sel_hi:[1,0]        (d.lo = a.lo * b.hi, d.hi = a.hi * b.lo)
 // returns +0 in the 16 lanes 48-63 of a wave when ANOTHER wave on the same SIMD issues VALU instructions while its own MFMAs are
-// in flight.  No library code, ~100 lines:  hipcc --offload-arch=gfx950 -O3 tools/pk_min.hip -o pk_min && ./pk_min
+// in flight.  No library code, ~100 lines:  hipcc --offload-arch=gfx950 -O3 tools/erratum/pk_min.hip -o pk_min && ./pk_min
 //   victim  (stream 1): every thread loads a pair x, applies 64 packed operations that must give x back, stores it; out != in = wrong.
 //   trigger (stream 2): independent MFMAs with `v_mov_b64 v[n:n+1], 0` between them (VALU = 0: MFMAs only), buffers of its own.
 // Found while isolating why this repository's BatchNorm backward stored wrong values when built with packed fp32 operations
-// (the library is built with -packed-fp32-ops for that reason).  Output of a run: profiles/r03_pk_min.txt.
+// (the library is built with -packed-fp32-ops for that reason).  Output of a run: tools/erratum/profiles/r03_pk_min.txt.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>

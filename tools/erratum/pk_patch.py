@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Instruction-level patches of the packed BatchNorm backward: which CLASS of packed instruction is it?
 
-    python tools/pk_patch.py <train_pk.s> <patch> <out.s>
+    python tools/erratum/pk_patch.py <train_pk.s> <patch> <out.s>
 
 Rewrites the body of bn_apply_kernel<bf16_t, 1, 1> in the device assembly hipcc emitted for train.hip (packed build) and leaves
 every other instruction, register and the schedule as they are:
@@ -12,7 +12,7 @@ every other instruction, register and the schedule as they are:
   mul-neg / mul-sel / mul-plain / mul-sgpr / mul-inplace / mul-fresh: only that sub-class of the packed multiplies (see patch_line)
   loop-mul / loop-add / prologue-mul ...: the same restricted to the pixel loop (after the first global_store) or to what precedes it
   nop       s_nop 0 after every packed instruction (timing only)
-tools/pk_patch.sh assembles the result into a code object and tools/pk_patch_run.hip runs it beside the synthetic trigger.
+tools/erratum/pk_patch.sh assembles the result into a code object and tools/erratum/pk_patch_run.hip runs it beside the synthetic trigger.
 """
 import re
 import sys

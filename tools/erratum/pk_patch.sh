@@ -1,7 +1,7 @@
 #!/bin/bash
-# Builds the patched victims of tools/pk_patch_run.hip: train.hip's device assembly (packed build, paired factor set-up)
-# -> tools/pk_patch.py <patch> -> code object tools/_build/pk_victim_<patch>.co, and the runner itself.
-#   bash tools/pk_patch.sh [patch ...]    then on a GPU box:   for p in ...; do tools/_build/pk_patch_run tools/_build/pk_victim_$p.co 10; done
+# Builds the patched victims of tools/erratum/pk_patch_run.hip: train.hip's device assembly (packed build, paired factor set-up)
+# -> tools/erratum/pk_patch.py <patch> -> code object tools/_build/pk_victim_<patch>.co, and the runner itself.
+#   bash tools/erratum/pk_patch.sh [patch ...]    then on a GPU box:   for p in ...; do tools/_build/pk_patch_run tools/_build/pk_victim_$p.co 10; done
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/_build
@@ -9,11 +9,11 @@ LLVM=/opt/rocm/lib/llvm/bin
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -ffp-contract=off -DYOLO_BN_PAIRED_FACTORS -I include \
     -S --cuda-device-only yolo_amd/csrc/train.hip -o tools/_build/train_pk.s 2>/dev/null
 for p in ${@:-none mul add mov all nop loop-all prologue-all}; do
-    python tools/pk_patch.py tools/_build/train_pk.s $p tools/_build/train_pk_$p.s
+    python tools/erratum/pk_patch.py tools/_build/train_pk.s $p tools/_build/train_pk_$p.s
     $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c tools/_build/train_pk_$p.s -o tools/_build/train_pk_$p.o
     $LLVM/ld.lld -shared tools/_build/train_pk_$p.o -o tools/_build/pk_victim_$p.co
     rm -f tools/_build/train_pk_$p.o tools/_build/train_pk_$p.s
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-function -Xclang -target-feature -Xclang -packed-fp32-ops \
-    -Wno-unused-command-line-argument -I yolo_amd/csrc -I include tools/pk_patch_run.hip -o tools/_build/pk_patch_run
+    -Wno-unused-command-line-argument -I yolo_amd/csrc -I include tools/erratum/pk_patch_run.hip -o tools/_build/pk_patch_run
 ls -la tools/_build/pk_victim_*.co tools/_build/pk_patch_run

@@ -2,7 +2,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.getcwd())
 import torch
 from yolo_amd import lib as L
-exec(open('tools/pk_bisect.py').read().split("def main():")[0])
+exec(open('tools/erratum/pk_bisect.py').read().split("def main():")[0])
 dev = torch.device('cuda:0')
 ship, pk = L.load(), load(PK)
 spin = C.CDLL('tools/_build/libpk_spin.so')

@@ -9,7 +9,7 @@
 //            of the library's convolutions and weight gradients has).  --trigger 9 is the same loop without the 64-bit moves.
 // Every dy of a co-run is compared bit for bit with the same call run alone.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DYOLO_BN_PAIRED_FACTORS -I yolo_amd/csrc -I include \
-//         tools/pk_repro2.hip -o tools/_build/pk_repro2 && tools/_build/pk_repro2 [rounds]
+//         tools/erratum/pk_repro2.hip -o tools/_build/pk_repro2 && tools/_build/pk_repro2 [rounds]
 // Measured (MI355X, ROCm 7.0.2 runtime, hipcc 7.2): trigger 10 corrupts 19-20 of 20 launches (exact zeros, lanes 48-63 of a wave),
 // trigger 9 none, alone none; the same binary built with -Xclang -target-feature -Xclang -packed-fp32-ops: none anywhere.
 #include "../yolo_amd/csrc/train.hip"
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const double* __restrict__ s
 // v[0:1] neg_lo neg_hi (banks 0 / 0); 3: v_pk_add_f32 v[238:239], v[238:239], v[0:1] neg (banks 2 / 0); 4: alternating 0 and 2;
 // 5: v_pk_mul_f32 v[228:229], v[120:121], v[228:229] op_sel:[0,1] op_sel_hi:[1,0] -- the CROSS-HALF form (low result = src0.lo *
 // src1.hi, high = src0.hi * src1.lo; 64 swaps by 1.0 give x back), the only packed instruction of the real kernel whose
-// replacement by two scalar multiplies makes it clean (tools/pk_patch.py); 6: the same form, destination != sources
+// replacement by two scalar multiplies makes it clean (tools/erratum/pk_patch.py); 6: the same form, destination != sources
 template <int VAR>
 __global__ __launch_bounds__(256) void pkloop_kernel(const float2* __restrict__ src, float2* __restrict__ dst, int reps, long long nthreads) {
     const long long t = blockIdx.x * 256LL + threadIdx.x;

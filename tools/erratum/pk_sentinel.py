@@ -1,16 +1,16 @@
 #!/usr/bin/env python
-"""Is the packed-fp32 corruption a STRAY WRITE?    The victim here has no packed operation: tools/pk_spin.hip
+"""Is the packed-fp32 corruption a STRAY WRITE?    The victim here has no packed operation: tools/erratum/pk_spin.hip
 k_sentinel fills 224 VGPRs of a wave with known values, idles beside the co-runner and checks them.  Co-runners: none; the
 synthetic MFMA loop in the real kernel's shape and footprint WITHOUT and WITH `v_mov_b64 v[n:n+1], 0` (spin_dense 9 / 10 --
 10 corrupts the packed BatchNorm backward, 9 does not); this library's generic convolution.
 
-    python tools/pk_sentinel.py [rounds]
+    python tools/erratum/pk_sentinel.py [rounds]
 """
 import ctypes as C
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 

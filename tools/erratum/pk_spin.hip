@@ -1,4 +1,4 @@
-// Synthetic co-runners for tools/pk_bisect.py (one hardware feature each), launched on the caller's stream.
+// Synthetic co-runners for tools/erratum/pk_bisect.py (one hardware feature each), launched on the caller's stream.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256) void k_turnover(const uint4* __restrict__ src,
     if (KIND == 1) sacc += lds[threadIdx.x];
     if (sacc == 12345.678f) out[0] = sacc;
 }
-// DENSE MFMA co-runners (round 3, after tools/pk_trigger.sh): of the generic convolution kernel, the K loop alone is the trigger,
+// DENSE MFMA co-runners (round 3, after tools/erratum/pk_trigger.sh): of the generic convolution kernel, the K loop alone is the trigger,
 // it stops being one without its MFMAs, and it stays one with its global loads cut out (MFMAs on zeros from LDS).  k_mfma above
 // waits for a global load per eight MFMAs -- its matrix pipe idles ~90 % of the time.  Here the pipe is kept full, as the real
 // loop keeps it: kind 0: 16 independent accumulators, operands constant in registers; 1: operands re-read from LDS

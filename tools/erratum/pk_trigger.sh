@@ -1,8 +1,8 @@
 #!/bin/bash
-# Trigger variants for tools/pk_bisect.py: the generic convolution kernel -- the simplest co-runner beside which the
+# Trigger variants for tools/erratum/pk_bisect.py: the generic convolution kernel -- the simplest co-runner beside which the
 # packed BatchNorm backward is corrupted -- built with ONE part cut out (-DYOLO_TRIG=n, the cut points in conv_igemm.hip), linked
 # with the shipped objects into yolo_amd/csrc/_ab/libyolo_trig_<n>.so.
-#   bash tools/pk_trigger.sh   then   TRIG_LIB=.../libyolo_trig_1.so PK_ONLY=generic python tools/pk_bisect.py 20
+#   bash tools/erratum/pk_trigger.sh   then   TRIG_LIB=.../libyolo_trig_1.so PK_ONLY=generic python tools/erratum/pk_bisect.py 20
 set -e
 cd "$(dirname "$0")/../yolo_amd/csrc"
 make -s pk >/dev/null 2>&1

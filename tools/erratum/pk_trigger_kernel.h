@@ -1,4 +1,4 @@
-// The synthetic co-runner of tools/pk_repro2.hip and tools/pk_patch_run.hip: an MFMA loop in the shape and footprint of
+// The synthetic co-runner of tools/erratum/pk_repro2.hip and tools/erratum/pk_patch_run.hip: an MFMA loop in the shape and footprint of
 // the generic convolution's K loop, optionally with VALU moves between its MFMAs.
 #pragma once
 typedef float f16v_ __attribute__((ext_vector_type(16)));

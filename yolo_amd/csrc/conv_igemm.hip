@@ -67,13 +67,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wave_p = wave % WAVES_P, wave_c = wave / WAVES_P;
-#ifdef YOLO_TRIG
-    // tools/pk_trigger.sh: which part of this kernel makes it a trigger of the packed-fp32 corruption?  Cut points
-    // the compiler cannot see through (a.N is never -7): 1 = leave at entry (same registers, LDS and launch), 2 = no main loop,
-    // 3 = no epilogue, 4 = main loop without its MFMAs, 5 = main loop without its global loads, 6 = no barriers (unsafe),
-    // 7 = no LDS writes in the loop, 8 = no LDS fragment reads, 9 = fragment reads at linear addresses
-    if (YOLO_TRIG == 1 && a.N != -7) return;
-#endif
 
     const int bid = blockIdx.x;
     const int tile_c = bid % a.tiles_c;
@@ -173,26 +166,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     uint4 xr[XP], wr[WP];
-#if defined(YOLO_TRIG) && YOLO_TRIG == 5
-    const bool TRIG_LOADS = a.N == -7;
-#else
-    constexpr bool TRIG_LOADS = true;
-#endif
-#if defined(YOLO_TRIG) && YOLO_TRIG == 7
-    const bool TRIG_LDSW = a.N == -7;                       // 7 = no LDS writes in the loop
-#else
-    constexpr bool TRIG_LDSW = true;
-#endif
-#if defined(YOLO_TRIG) && YOLO_TRIG == 6
-#define TRIG_SYNC() do { if (a.N == -7) __syncthreads(); } while (0)
-#else
-#define TRIG_SYNC() __syncthreads()
-#endif
 #define LOAD_X(chunk_base)                                                                      \
     _Pragma("unroll") for (int j = 0; j < XP; ++j) {                                            \
         const int byte = (chunk_base) * 64 + xlp[j];                                            \
         uint4 v = make_uint4(0, 0, 0, 0);                                                       \
-        if (xoff[j] >= 0 && byte < row_bytes && TRIG_LOADS) v = *(const uint4*)(a.x + xoff[j] + byte); \
+        if (xoff[j] >= 0 && byte < row_bytes) v = *(const uint4*)(a.x + xoff[j] + byte);        \
         xr[j] = v;                                                                              \
     }
     // plane0 = first (chunk*taps + tap) plane of the packed weights for the step
@@ -203,35 +181,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const int u = tid + j * 256;                                                            \
         const int t = (j * 256) / (BC * 4);                                                     \
         uint4 v = make_uint4(0, 0, 0, 0);                                                       \
-        if ((W_UNITS % 256 == 0 || u < W_UNITS) && TRIG_LOADS)                                  \
+        if (W_UNITS % 256 == 0 || u < W_UNITS)                                                  \
             v = *(const uint4*)(wsrc + ((plane0) + t) * wplane + (j * 256 - t * BC * 4) * 16);  \
         wr[j] = v;                                                                              \
     }
     static_assert((BC * 4) % 256 == 0 || 256 % (BC * 4) == 0, "tap index must be uniform per pass");
 
     int nouter = (KS == 3) ? a.nchunks : a.nchunks / TS;
-#if defined(YOLO_TRIG) && YOLO_TRIG == 2
-    if (a.N != -7) nouter = 0;
-#endif
     LOAD_X(0);
     LOAD_W(0);
     for (int c = 0; c < nouter; ++c) {
 #pragma unroll
         for (int kh = 0; kh < KSTEPS; ++kh) {
-            TRIG_SYNC();
+            __syncthreads();
             if (kh == 0) {
 #pragma unroll
                 for (int j = 0; j < XP; ++j) {
                     const int u = tid + j * 256;
-                    if ((X_UNITS % 256 == 0 || u < X_UNITS) && TRIG_LDSW) *(uint4*)(Xl + u * 16) = xr[j];
+                    if ((X_UNITS % 256 == 0 || u < X_UNITS)) *(uint4*)(Xl + u * 16) = xr[j];
                 }
             }
 #pragma unroll
             for (int j = 0; j < WP; ++j) {
                 const int u = tid + j * 256;
-                if ((W_UNITS % 256 == 0 || u < W_UNITS) && TRIG_LDSW) *(uint4*)(Wl + u * 16) = wr[j];
+                if ((W_UNITS % 256 == 0 || u < W_UNITS)) *(uint4*)(Wl + u * 16) = wr[j];
             }
-            TRIG_SYNC();
+            __syncthreads();
             // prefetch the next step into registers while this one computes
             if (kh + 1 < KSTEPS) {
                 LOAD_W((c * KSTEPS + kh + 1) * TS);
@@ -244,32 +219,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     uint4 af[MI], bf[NI];
-#if defined(YOLO_TRIG) && YOLO_TRIG == 8
-                    if (a.N != -7) {                         // 8 = no LDS fragment reads: the MFMAs run on loop-invariant registers
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) af[mi] = make_uint4(tid, mi, t, ks);
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) bf[ni] = make_uint4(ni, tid, 1, 2);
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                            for (int ni = 0; ni < NI; ++ni) Frag<T>::mma(af[mi], bf[ni], acc[mi][ni]);
-                        continue;
-                    }
-#endif
-#if defined(YOLO_TRIG) && YOLO_TRIG == 9
-                    if (a.N != -7) {                         // 9 = the fragment reads at LINEAR addresses (lane * 16 bytes + constants)
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) af[mi] = *(const uint4*)(Wl + t * BC * 64 + mi * 2048 + ks * 1024 + lane * 16);
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) bf[ni] = *(const uint4*)(Xl + ((kh * 3 + t) * 2 + ks) * 2048 + ni * 1024 + lane * 16);
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                            for (int ni = 0; ni < NI; ++ni) Frag<T>::mma(af[mi], bf[ni], acc[mi][ni]);
-                        continue;
-                    }
-#endif
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
                         af[mi] = *(const uint4*)(Wl + t * BC * 64 + mi * 2048 + (aoff0 ^ (ks * 32)));
@@ -282,12 +231,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni) {
-#if defined(YOLO_TRIG) && YOLO_TRIG == 4
-                            if (a.N == -7) Frag<T>::mma(af[mi], bf[ni], acc[mi][ni]);
-                            else acc[mi][ni][0] += __uint_as_float(af[mi].x ^ bf[ni].y);      // (keeps the LDS reads alive)
-#else
                             Frag<T>::mma(af[mi], bf[ni], acc[mi][ni]);
-#endif
                         }
                 }
             }
@@ -295,13 +239,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 
     // ---- epilogue (conv_epilogue.h): every wave transposes its slab through its own LDS scratch ------
-    TRIG_SYNC();                         // all waves are done reading the staged tiles
-#if defined(YOLO_TRIG) && YOLO_TRIG == 3
-    if (a.N != -7) {                     // (one store keeps the accumulators alive)
-        if (acc[0][0][0] == 12345.678f) a.stats[0] = acc[0][0][1];
-        return;
-    }
-#endif
+    __syncthreads();                         // all waves are done reading the staged tiles
     float* srow = STATS ? a.stats + ((size_t)tile_p * WAVES_P + wave_p) * 2 * a.Cout_pad : nullptr;     // (conv_epilogue.h)
     conv_epilogue<T, MI, NI, STATS>(acc, yoff, smem + wave * YOLO_EPI_WAVE_BYTES, a, co0 + wave_c * MI * 32, lane, roff, srow);
 }
