@@ -16,6 +16,14 @@ measured live in a second pass over the same K steps (events bracket each launch
 kernels run on; the headline `value` pass itself carries no events).  `cpu_baseline` times the
 CPU oracle (torch-CPU fp32 restatement of the reference graph; the reference's MXNet cannot run
 here) on a bounded sample on rank 0 at N=1.
+
+The step OWNS its device->host copy, as the reference's `predict` does (car/YOLO.py:597): the (B, 6+C) rows go to a
+pinned host buffer by an asynchronous copy on the stream, two buffers deep, so the copy of step i overlaps the launches
+of step i+1 (`value_blocking_predict` is the same pass with a blocking `.cpu()` per step).  The extra keys on the 608x608
+bs 64 shape (`northstar_608_forward` / `northstar_608` / `northstar_608_nms`) and the training key are SUSTAINED runs:
+>= 2 s of the same pass as pre-heat, >= 20 warm-up steps, then >= 300 (training: 120) timed steps, with the mean shader
+clock and socket power sampled over the timed region (`sustained_s`, `sclk_mhz`, `power_w`).  The headline `value`
+keeps the driver's --steps / --warmup exactly.
 """
 import argparse
 import json
@@ -31,6 +39,76 @@ import numpy as np
 import torch
 
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # /opt/skills/guides/MI355X_MICROARCH.md (dense)
+
+
+class Telemetry(object):
+    """Mean shader clock (MHz) and socket power (W) over a timed region, sampled from a background thread: the amdgpu
+    hwmon files when they exist (a read costs microseconds), else `rocm-smi --showclocks --showpower` once a second
+    (what tools/clock_probe.sh does).  Purely descriptive: nothing in the timed region waits for it."""
+
+    def __init__(self, index=0, period=0.2):
+        import glob
+        self.period, self.index = period, index
+        self.freq_file = self.power_file = None
+        cards = sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*'))
+        if index < len(cards):
+            hw = cards[index]
+            for name in ('freq1_input',):
+                if os.path.exists(os.path.join(hw, name)):
+                    self.freq_file = os.path.join(hw, name)
+            for name in ('power1_average', 'power1_input'):
+                if os.path.exists(os.path.join(hw, name)):
+                    self.power_file = os.path.join(hw, name)
+                    break
+        self.source = 'hwmon' if (self.freq_file or self.power_file) else 'rocm-smi'
+        self._stop = self._thread = None
+        self.clk, self.pw = [], []
+
+    def _sample(self):
+        import re
+        import subprocess
+        if self.source == 'hwmon':
+            try:
+                if self.freq_file:
+                    self.clk.append(int(open(self.freq_file).read()) / 1e6)
+                if self.power_file:
+                    self.pw.append(int(open(self.power_file).read()) / 1e6)
+            except (OSError, ValueError):
+                pass
+            return
+        try:
+            txt = subprocess.run(['rocm-smi', '-d', str(self.index), '--showclocks', '--showpower'], capture_output=True, text=True,
+                                 timeout=10).stdout
+        except Exception:
+            return
+        m = re.search(r'sclk clock level: \d+: \((\d+)Mhz\)', txt)
+        if m:
+            self.clk.append(float(m.group(1)))
+        m = re.search(r'Power \(W\): ([0-9.]+)', txt)
+        if m:
+            self.pw.append(float(m.group(1)))
+
+    def start(self):
+        import threading
+        self.clk, self.pw = [], []
+        self._stop = threading.Event()
+
+        def run():
+            while not self._stop.is_set():
+                self._sample()
+                self._stop.wait(self.period if self.source == 'hwmon' else 1.0)
+
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join(timeout=15)
+        mean = lambda v: round(sum(v) / len(v), 1) if v else None
+        return {'sclk_mhz': mean(self.clk), 'power_w': mean(self.pw), 'telemetry_samples': max(len(self.clk), len(self.pw)),
+                'telemetry_source': self.source}
 
 
 def cpu_baseline(size, seconds=6.0, batch=8):
@@ -93,8 +171,30 @@ def pmc_traffic(kernel, B, size):
             continue
         ent = prof.get('kernels', {}).get(kernel)
         if ent:
-            return int(ent['hbm_bytes_per_launch']), os.path.relpath(path, ROOT)
-    return None, None
+            return int(ent['hbm_bytes_per_launch']), os.path.relpath(path, ROOT), None
+    # no committed PMC pass holds this instantiation (the tuner picked another dominant kernel on this box): say so and
+    # name the nearest profiled instantiation of the same kernel template instead of a bare null
+    import re
+    args = lambda n: [a.strip() for a in re.sub(r'^[^<]*<|>\(.*$', '', n).split(',')]
+    fam = kernel.split('<')[0]
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')), reverse=True):
+        with open(path) as f:
+            prof = json.load(f)
+        if prof.get('workload') != [B, size[0], size[1]]:
+            continue
+        for name, ent in prof.get('kernels', {}).items():
+            if name.split('<')[0] != fam or '<' not in name:
+                continue
+            same = sum(1 for a, b in zip(args(name), args(kernel)) if a == b)
+            if best is None or same > best[0]:
+                best = (same, name, int(ent['hbm_bytes_per_launch']), os.path.relpath(path, ROOT))
+        if best:
+            break
+    note = 'no committed PMC pass of this workload holds the dominant kernel of this run'
+    if best:
+        note += '; nearest profiled instantiation: %s = %d bytes per launch (%s)' % (best[1], best[2], best[3])
+    return None, None, note
 
 
 def synthetic_labels(batch, seed, num_class=24):
@@ -116,11 +216,12 @@ def synthetic_labels(batch, seed, num_class=24):
     return lab
 
 
-def train_pass(args, spec, size, B, rank, world, dev, dist, steps, warmup):
+def train_pass(args, spec, size, B, rank, world, dev, dist, steps, warmup, preheat_s=0.0, telemetry=None):
     """BASELINE configs[2] (N=1) / configs[3] (N>1): car/YOLO.py training step, B images per GPU, the gradient
     bucket all-reduced over RCCL (one exchange per step), identical Adam on every rank.  Returns the result dict."""
     from yolo_amd.net import CarNet
     from yolo_amd.train import Trainer
+    from yolo_amd import parallel
     net = CarNet(spec, dtype=args.dtype, device=dev, tune='measure', tune_cache=args.tune_cache,
                  fuse_stem=not args.no_fuse_stem).initialize(seed=1234)
     tr = Trainer(net, size)
@@ -134,18 +235,45 @@ def train_pass(args, spec, size, B, rank, world, dev, dist, steps, warmup):
             dist.barrier()
             torch.cuda.synchronize()
 
+    tuning_same = None
+    if dist is not None:
+        # rank 0 measures the forward / data-gradient / weight-gradient variants in one local step (no exchange, no update),
+        # every rank adopts its choices: all ranks run the same kernels, nobody is the straggler the all-reduce waits for
+        if rank == 0:
+            tr.tune(x, lab)
+        parallel.share_tuning(tr, src=0)
+        tr.train_step(x, lab)                     # (every rank's first step: plan build with rank 0's choices, one real exchange)
+        # (a rank that had to measure a shape itself would hold choices rank 0 never made)
+        tuning_same = parallel.same_on_all_ranks(sorted((n, repr(k), repr(v)) for n, d_ in tr.tuning_state().items() for k, v in d_.items()))
+    if preheat_s > 0:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < preheat_s:
+            for _ in range(3):
+                tr.train_step(x, lab)
+            torch.cuda.synchronize()
+            if dist is not None:                  # (the ranks leave the pre-heat together: a rank still inside would hang the others' exchange)
+                go = torch.tensor([1.0 if time.perf_counter() - t0 < preheat_s else 0.0], device=dev)
+                dist.all_reduce(go, op=dist.ReduceOp.MIN)
+                if float(go.item()) == 0.0:
+                    break
     for _ in range(max(warmup, 1)):               # the first step also measures the kernel variants
         tr.train_step(x, lab)
     fence()
+    if telemetry is not None:
+        telemetry.start()
     t0 = time.perf_counter()
     for _ in range(steps):
         losses = tr.train_step(x, lab)
     fence()
     el = time.perf_counter() - t0
+    tinfo = telemetry.stop() if telemetry is not None else {}
+    per_rank = [el]
     if dist is not None:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        t = torch.zeros(world, device=dev, dtype=torch.float64)
+        t[rank] = el
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank = [float(v) for v in t.tolist()]
+        el = max(per_rank)
     value = world * B * steps / el
     fl = 3 * net.graph.flops(*size)
     tf = fl * value / 1e12 / world
@@ -161,11 +289,14 @@ def train_pass(args, spec, size, B, rank, world, dev, dist, steps, warmup):
                 dist.all_reduce(tr.gflat[a:b], op=dist.ReduceOp.SUM)
         e1.record(); e1.synchronize()
         ar_ms = e0.elapsed_time(e1) / reps
-        # ... and what it costs inside the step: the same K steps with the exchange switched off (local gradients only)
+        # ... and what it costs inside the step: the same K steps with the exchange switched off (local gradients only).
+        # NOTE: these steps apply LOCAL gradients, so the ranks' weights diverge -- this Trainer must not be used for anything
+        # after this block (it is the last thing the pass does with it).
+        k_off = min(steps, 20)
         saved, tr.buckets.active = tr.buckets.active, (lambda: False)
         fence()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(k_off):
             tr.train_step(x, lab, global_batch=B * world)
         fence()
         el_off = time.perf_counter() - t0
@@ -177,11 +308,12 @@ def train_pass(args, spec, size, B, rank, world, dev, dist, steps, warmup):
         exch = {'rccl_world': dist.get_world_size(), 'backend': dist.get_backend(), 'buckets': len(tr.buckets.ranges), 'bytes': nbytes,
                 'allreduce_ms_per_step_standalone': round(ar_ms, 3),
                 'allreduce_busbw_GBps': round(2.0 * (world - 1) / max(world, 1) * nbytes / (ar_ms * 1e-3) / 1e9, 1),
-                'ms_per_step_without_exchange': round(el_off / steps * 1e3, 4),
-                'exposed_ms_per_step': round((el - el_off) / steps * 1e3, 4)}
-    return {
+                'ms_per_step_without_exchange': round(el_off / k_off * 1e3, 4),
+                'exposed_ms_per_step': round((el / steps - el_off / k_off) * 1e3, 4)}
+    res = {
         'metric': 'training images/sec at %dx%d bs=%d per GPU (fwd + loss + bwd + train-mode BN + Adam)' % (size[0], size[1], B),
         'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+        'preheat_s': preheat_s, 'sustained_s': round(el, 3),
         'ms_per_step': round(el / steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[%d]: car/YOLO.py training step, Darknet-53 spec + 3-scale YOLO head '
@@ -195,6 +327,11 @@ def train_pass(args, spec, size, B, rank, world, dev, dist, steps, warmup):
         'final_losses': [round(float(v), 6) for v in losses.sum(dim=1).tolist()],
         'exchange': exch,
     }
+    res.update(tinfo)
+    if dist is not None:
+        res['per_rank_ms_per_step'] = [round(t_ / steps * 1e3, 4) for t_ in per_rank]
+        res['tuning_identical_across_ranks'] = bool(tuning_same)
+    return res
 
 
 def bench_train(args, spec, size, B, rank, world, dev, dist):
@@ -259,9 +396,15 @@ def emit(out):
     print(json.dumps(out), flush=True)
 
 
-def timed_pass(net, det, x, post, steps, warmup, fence):
-    """W untimed + K timed steps of forward + post-processing; returns seconds for the K steps (this rank)."""
-    def step():
+def timed_pass(net, det, x, post, steps, warmup, fence, preheat_s=0.0, telemetry=None):
+    """W untimed + K timed steps of forward + post-processing; returns (seconds for the K steps on this rank, telemetry dict).
+    post: 'none' forward only | 'top1' decode + per-image arg-max + the (B, 6+C) rows copied to the host (the reference's
+    predict owns its D2H, car/YOLO.py:597; pipelined two deep: no host stall) | 'top1_blocking' the same with a blocking
+    .cpu() per step | 'nms' decode + per-class NMS (kept ids stay on the device).  preheat_s: run the same step for that
+    many seconds first (clock / power state of a sustained run), outside the timed region."""
+    pend = [None]
+
+    def step(i=0):
         outs = net(x)
         if post == 'none':
             return outs
@@ -269,16 +412,31 @@ def timed_pass(net, det, x, post, steps, warmup, fence):
             rows, scores = det.decode_scores(outs, mode='class')
             kept, ks, cnt = det.nms(rows, mode='class', scores=scores)
             return kept, cnt
-        return det.predict_device(outs)
+        if post == 'top1_blocking':
+            return det.predict(outs)
+        host, ev = det.predict_async(outs, slot=i & 1)
+        if pend[0] is not None:
+            pend[0].synchronize()                      # the rows of step i-1 are on the host before step i+1 re-uses their buffer
+        pend[0] = ev
+        return host
 
-    for _ in range(warmup):
-        step()
+    if preheat_s > 0:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < preheat_s:
+            for i in range(10):
+                step(i)
+            torch.cuda.synchronize()
+    for i in range(warmup):
+        step(i)
     fence()
+    if telemetry is not None:
+        telemetry.start()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    for i in range(steps):
+        step(i)
     fence()
-    return time.perf_counter() - t0
+    el = time.perf_counter() - t0
+    return el, (telemetry.stop() if telemetry is not None else {})
 
 
 def main():
@@ -296,9 +454,9 @@ def main():
     ap.add_argument('--no-fuse-res', action='store_true', help='never use the fused residual-block kernel (A/B)')
     ap.add_argument('--no-side-stream', action='store_true', help='run the head tip/output convolutions on the main stream (A/B)')
     ap.add_argument('--tune-cache', default=None, help='JSON file remembering the measured per-layer kernel choices')
-    ap.add_argument('--post', default='top1', choices=['top1', 'nms'],
-                    help="post-processing inside the timed step: 'top1' = the reference's predict (decode + per-image arg-max);"
-                         " 'nms' = decode + per-class greedy NMS (BASELINE configs[4])")
+    ap.add_argument('--post', default='top1', choices=['top1', 'nms', 'none'],
+                    help="post-processing inside the timed step: 'top1' = the reference's predict (decode + per-image arg-max + D2H of"
+                         " the rows); 'nms' = decode + per-class greedy NMS (BASELINE configs[4]); 'none' = the network forward alone")
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                     help="'infer' = BASELINE configs[1] (the headline metric); 'train' = configs[2]/[3]: one training "
                          "step (fwd + loss + bwd + train-mode BN + gradient all-reduce + Adam) per step")
@@ -308,7 +466,10 @@ def main():
     ap.add_argument('--train-key', action='store_true', help='(default now) the training pass also runs under N > 1: BASELINE configs[3]')
     ap.add_argument('--no-repeats', action='store_true', help='skip the four extra K-step passes behind value_median')
     ap.add_argument('--no-f32-key', action='store_true', help='skip the extra fp32-path pass (the arithmetic the 1e-3 parity bar is tested on)')
-    ap.add_argument('--train-timeout', type=float, default=300.0,
+    ap.add_argument('--sustain-steps', type=int, default=300,
+                    help='timed steps of the SUSTAINED extra keys (608x608 bs 64; the training key runs 0.4x as many): each after a 2 s '
+                         'pre-heat of the same pass and >= 20 warm-up steps.  0 = short legacy passes of --steps / 2 (tests)')
+    ap.add_argument('--train-timeout', type=float, default=600.0,
                     help='watchdog (s) around the training pass under N > 1: when it fires the line is printed without the pass')
     ap.add_argument('--launch-check', action='store_true',
                     help='start the N ranks, rendezvous, barrier, MAX-reduce, print the world that ran, and exit (no benchmark)')
@@ -353,6 +514,7 @@ def main():
     from yolo_amd.net import CarNet
     from yolo_amd.detect import Detector
     from yolo_amd.spec import darknet53_spec
+    from yolo_amd import parallel
 
     spec = darknet53_spec()
     size = (args.size, args.size)
@@ -366,6 +528,7 @@ def main():
     det = Detector(spec, size, net.graph.steps(), device=dev)
     gen = torch.Generator(device='cpu').manual_seed(100 + rank)
     x = torch.rand((B, 3) + size, generator=gen).to(dev)            # synthetic images, resident in HBM
+    errors = []
 
     def fence():
         torch.cuda.synchronize()
@@ -373,47 +536,78 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def max_over_ranks(el):
-        if dist is not None:
-            t = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el
+    def over_ranks(el):
+        """(MAX over the ranks, [every rank's own seconds])"""
+        if dist is None:
+            return el, [el]
+        t = torch.zeros(world, device=dev, dtype=torch.float64)
+        t[rank] = el
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per = [float(v) for v in t.tolist()]
+        return max(per), per
 
+    def pin_plan(n, Bp, sz):
+        """N > 1: rank 0 measures the kernel variants of this shape, every rank adopts its choices (parallel.share_tuning) and
+        the launch plans are compared -- all ranks run the same kernel instantiations.  -> (identical?, md5 of the plan)"""
+        import hashlib
+        if dist is not None and rank == 0:
+            n.plan_signature(Bp, *sz)
+        if dist is not None:
+            parallel.share_tuning(n, src=0)
+        sig = n.plan_signature(Bp, *sz)
+        return parallel.same_on_all_ranks(sig), hashlib.md5(json.dumps(sig).encode()).hexdigest()[:12]
+
+    plans_same, plan_md5 = pin_plan(net, B, size)
     # --warmup 0: one untimed step still runs first (as the training pass does): the first forward of a shape builds its launch
     # plan and MEASURES the kernel variants -- set-up, not a step; reported as `setup_steps`
     setup_steps = 1 if args.warmup == 0 else 0
-    el = max_over_ranks(timed_pass(net, det, x, args.post, args.steps, args.warmup + setup_steps, fence))
+    el, per_rank = over_ranks(timed_pass(net, det, x, args.post, args.steps, args.warmup + setup_steps, fence)[0])
     ms_per_step = el / args.steps * 1e3
     value = world * B * args.steps / el
     # the same K-step pass four more times: `value` stays the first pass (what the driver's clock brackets), the median of
     # the five tells a 1-3 % change from run-to-run noise
-    reps = [value] + [world * B * args.steps / max_over_ranks(timed_pass(net, det, x, args.post, args.steps, 0, fence))
+    reps = [value] + [world * B * args.steps / over_ranks(timed_pass(net, det, x, args.post, args.steps, 0, fence)[0])[0]
                       for _ in range(0 if args.no_repeats else 4)]
+    post_name = {'nms': 'per-class NMS', 'top1': 'top-1 + D2H of the rows', 'none': 'nothing (forward alone)'}[args.post]
 
     out = {
         'metric': 'images/sec at %dx%d bs=%d per GPU (Darknet-53 spec + 3-scale YOLO head forward, anchor '
-                  'decode + %s)' % (size[0], size[1], B, 'per-class NMS' if args.post == 'nms' else 'top-1'),
+                  'decode + %s)' % (size[0], size[1], B, post_name),
         'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.dtype, 'data': 'synthetic', 'setup_steps': setup_steps,
         'config': {'workload': 'BASELINE configs[1]: Darknet-53 spec layers [1,2,8,8,4] channels [32..1024] + '
                                '3-scale YOLO head (A=3, C=30) forward, random Xavier weights, %dx%d, bs=%d per GPU, '
-                               '+ decode/%s' % (size[0], size[1], B, 'per-class NMS (valid 0.01, IoU 0.45, top-k 400, keep 100)' if args.post == 'nms' else 'top-1'),
+                               '+ decode/%s' % (size[0], size[1], B, 'per-class NMS (valid 0.01, IoU 0.45, top-k 400, keep 100)' if args.post == 'nms' else post_name),
                    'global_batch': B * world, 'image': list(size),
                    'parallelism': 'dp%d (batch-sharded, no data-path collective)' % world,
                    'gflop_per_image': round(net.graph.flops(*size) / 1e9, 2)},
     }
     out['value_median'] = round(float(np.median(reps)), 2)
     out['value_repeats'] = [round(v, 1) for v in reps]
+    if args.post == 'top1' and not args.no_repeats:
+        # the same pass with the reference's literal predict(): a blocking .cpu() of the rows in every step
+        elb = over_ranks(timed_pass(net, det, x, 'top1_blocking', args.steps, 0, fence)[0])[0]
+        out['value_blocking_predict'] = round(world * B * args.steps / elb, 2)
+    if dist is not None:
+        # stragglers and rank-dependent plans, visible the day a node exists: every rank's own time for the K steps and
+        # whether all ranks launch the same kernel instantiations (rank 0 measured, the others adopted its choices)
+        out['per_rank_ms_per_step'] = [round(t / args.steps * 1e3, 4) for t in per_rank]
+        out['rank_ms_per_step_min_max'] = [round(min(per_rank) / args.steps * 1e3, 4), round(max(per_rank) / args.steps * 1e3, 4)]
+        out['plans_identical_across_ranks'] = bool(plans_same)
+        out['plan_md5'] = plan_md5
     if shared:
         out['shared_gpu_test'] = 'TEST ONLY: %d ranks share %d GPU(s) over gloo -- not an N-GPU measurement' % (world, torch.cuda.device_count())
     out['net_tflops'] = round(net.graph.flops(*size) * value / 1e12 / world, 1)          # per GPU
     out['net_frac'] = round(out['net_tflops'] / MFMA_PEAK_TFLOPS[args.dtype], 4)           # whole pass vs the dense MFMA peak
+    out['net_frac_median'] = round(net.graph.flops(*size) * out['value_median'] / 1e12 / world / MFMA_PEAK_TFLOPS[args.dtype], 4)
 
     if rank == 0 and not args.no_roofline:
         kernels = net.plan_kernels(B, *size)
         info = {n: (k, f) for n, k, f in kernels}
+        hist = {}
+        for n, k, f in kernels:
+            hist[k] = hist.get(k, 0) + 1
         agg = {}
         for _ in range(args.steps):
             ev = []
@@ -429,7 +623,7 @@ def main():
         tsec, nl, fl = agg[dom]
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         ach = fl / tsec / 1e12
-        traffic, traffic_src = pmc_traffic(dom, B, size)
+        traffic, traffic_src, traffic_note = pmc_traffic(dom, B, size)
         out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s',
                            'frac': round(ach / peak, 4), 'traffic': traffic,
                            # (a committed rocprofv3 --pmc pass of this workload, not a counter read of this run)
@@ -437,32 +631,47 @@ def main():
                            'launches_per_step': nl // args.steps,
                            'avg_launch_us': round(tsec / nl * 1e6, 2),
                            'flops_per_launch': fl // nl}
+        if traffic_note:
+            out['roofline']['traffic_note'] = traffic_note
         out['kernels'] = [{'kernel': k, 'launches_per_step': v[1] // args.steps,
                            'ms_per_step': round(v[0] / args.steps * 1e3, 4),
                            'tflops': round(v[2] / v[0] / 1e12, 1) if v[2] else None}
                           for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])]
-    if not args.no_northstar and (args.size, B, args.post) == (416, 32, 'top1') and args.dtype == 'bf16':
+    headline = (args.size, B, args.post) == (416, 32, 'top1') and args.dtype == 'bf16'
+    sustain = args.sustain_steps > 0
+    if not args.no_northstar and headline:
         # The north-star shape (BASELINE.json: ">= 40 % of bf16 MFMA peak on the Darknet-53 forward at 608x608 bs=64") and
         # BASELINE configs[4]'s per-GPU shape (the same + decode + per-class NMS), timed in this same process so that the
-        # driver-run line carries them: same net object, new launch plan, K/2 steps each.
+        # driver-run line carries them: same net object, new launch plan.  SUSTAINED: 2 s of the same pass first, >= 20 warm-up
+        # steps, >= 300 timed steps (yolo_gluon.py:317-331 times 10 + 100 iterations), clock and power sampled alongside.
         del x
         size6, B6 = (608, 608), 64
         det6 = Detector(spec, size6, net.graph.steps(), device=dev)
         x6 = torch.rand((B6, 3) + size6, generator=gen).to(dev)
-        k6, w6 = max(args.steps // 2, 3), max(args.warmup // 2, 2)
+        if sustain:
+            k6, w6, heat = max(args.steps, args.sustain_steps), max(args.warmup, 20), 2.0
+        else:
+            k6, w6, heat = max(args.steps // 2, 3), max(args.warmup // 2, 2), 0.0
         fl6 = net.graph.flops(*size6)
+        same6, md5_6 = pin_plan(net, B6, size6)
         # (`northstar_608_forward`: the network forward alone -- the quantity BASELINE.json's target is worded on, "the Darknet-53
         #  forward at 608x608 bs=64"; the other two keys add the post-processing to the timed step)
         for key, post in (('northstar_608_forward', 'none'), ('northstar_608', 'top1'), ('northstar_608_nms', 'nms')):
-            el6 = max_over_ranks(timed_pass(net, det6, x6, post, k6, w6, fence))
+            tel = Telemetry(local) if (rank == 0 and sustain) else None
+            el_, tinfo = timed_pass(net, det6, x6, post, k6, w6, fence, preheat_s=heat, telemetry=tel)
+            el6, per6 = over_ranks(el_)
             v6 = world * B6 * k6 / el6
             tf6 = fl6 * v6 / 1e12 / world
-            out[key] = {'workload': 'D53 spec forward 608x608 bs=64 per GPU' + ('' if post == 'none' else ' + decode/%s' % ('per-class NMS' if post == 'nms' else 'top-1')),
-                        'value': round(v6, 2), 'unit': 'images/s', 'steps': k6, 'warmup': w6,
-                        'ms_per_step': round(el6 / k6 * 1e3, 4), 'net_tflops': round(tf6, 1),
+            out[key] = {'workload': 'D53 spec forward 608x608 bs=64 per GPU' + ('' if post == 'none' else ' + decode/%s' % ('per-class NMS' if post == 'nms' else 'top-1 + D2H')),
+                        'value': round(v6, 2), 'unit': 'images/s', 'steps': k6, 'warmup': w6, 'preheat_s': heat,
+                        'sustained_s': round(el6, 3), 'ms_per_step': round(el6 / k6 * 1e3, 4), 'net_tflops': round(tf6, 1),
                         'frac_of_peak': round(tf6 / MFMA_PEAK_TFLOPS[args.dtype], 4), 'gflop_per_image': round(fl6 / 1e9, 2)}
+            out[key].update(tinfo)
+            if dist is not None:
+                out[key]['per_rank_ms_per_step'] = [round(t / k6 * 1e3, 4) for t in per6]
+                out[key]['plans_identical_across_ranks'] = bool(same6)
         del x6
-    if not args.no_f32_key and (args.size, B, args.post) == (416, 32, 'top1') and args.dtype == 'bf16' and world == 1:
+    if not args.no_f32_key and headline and world == 1:
         # what the arithmetic of the 1e-3 parity bar costs: the SAME workload on the fp32 path (exact-f32 MFMA, fp32
         # activations; tests/test_gpu_configs.py holds it to <= 1e-3 of the oracle)
         del net
@@ -471,7 +680,7 @@ def main():
         net32.prepare()
         x32 = torch.rand((B, 3) + size, generator=gen).to(dev)
         k32 = max(args.steps // 2, 3)
-        el32 = timed_pass(net32, det, x32, 'top1', k32, 2, fence)
+        el32 = timed_pass(net32, det, x32, 'top1', k32, 2, fence)[0]
         v32 = B * k32 / el32
         out['f32_path'] = {'workload': 'the headline workload on the fp32 parity path (<= 1e-3 vs the oracle)', 'value': round(v32, 2),
                            'unit': 'images/s', 'steps': k32, 'ms_per_step': round(el32 / k32 * 1e3, 4),
@@ -479,37 +688,49 @@ def main():
                            'frac_of_f32_peak': round(net32.graph.flops(*size) * v32 / 1e12 / MFMA_PEAK_TFLOPS['f32'], 4)}
         net = net32
         del x32
-    if not args.no_train_key and (args.size, B, args.post) == (416, 32, 'top1') and args.dtype == 'bf16':
+    if not args.no_train_key and headline:
         # BASELINE configs[2] (training step, 416x416 bs=64 per GPU) in the same driver-run line; under N > 1 this is
         # configs[3]: the RCCL all-reduce of the gradient buckets inside the step.  A collective that hangs must not cost
-        # the headline line: a watchdog on every rank prints the line without the pass and ends the process.
+        # the headline line: a watchdog on every rank prints the line without the pass and ends the process -- with a
+        # NON-ZERO status and a top-level `errors` entry, so that a failed configs[3] run cannot pass for a clean one.
         del net
         torch.cuda.empty_cache()
         import threading
 
         def give_up():
             if rank == 0:
-                out['train_416_bs64'] = {'error': 'the training pass did not finish within %.0f s (watchdog)' % args.train_timeout,
-                                         'n_gpus': world}
+                msg = 'the training pass did not finish within %.0f s (watchdog)' % args.train_timeout
+                out['train_416_bs64'] = {'error': msg, 'n_gpus': world}
+                out['errors'] = errors + ['train_416_bs64: ' + msg]
                 emit(out)
-            os._exit(0)
+            os._exit(3)
 
         dog = threading.Timer(args.train_timeout, give_up) if world > 1 else None
         if dog is not None:
             dog.daemon = True
             dog.start()
         try:
-            t = train_pass(args, spec, size, 64, rank, world, dev, dist, max(args.steps // 2, 5), 2)
-            out['train_416_bs64'] = {k: t[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'net_tflops',
-                                                       'net_frac', 'final_losses', 'exchange')}
+            if sustain:
+                kt, wt, heat = max(args.steps, int(0.4 * args.sustain_steps)), max(args.warmup, 20), 2.0
+            else:
+                kt, wt, heat = max(args.steps // 2, 5), 2, 0.0
+            t = train_pass(args, spec, size, 64, rank, world, dev, dist, kt, wt, preheat_s=heat,
+                           telemetry=Telemetry(local) if (rank == 0 and sustain) else None)
+            out['train_416_bs64'] = {k: t[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'preheat_s', 'sustained_s',
+                                                       'ms_per_step', 'net_tflops', 'net_frac', 'final_losses', 'exchange', 'sclk_mhz',
+                                                       'power_w', 'telemetry_samples', 'telemetry_source', 'per_rank_ms_per_step',
+                                                       'tuning_identical_across_ranks') if k in t}
             out['train_416_bs64']['workload'] = t['config']['workload']
             out['train_416_bs64']['global_batch'] = t['config']['global_batch']
         except Exception as e:                                   # (a rank-local failure: the other ranks meet the watchdog)
-            out['train_416_bs64'] = {'error': '%s: %s' % (type(e).__name__, e), 'n_gpus': world}
+            msg = '%s: %s' % (type(e).__name__, e)
+            out['train_416_bs64'] = {'error': msg, 'n_gpus': world}
+            errors.append('train_416_bs64: ' + msg)
             if world > 1:
                 if rank == 0:
+                    out['errors'] = errors
                     emit(out)
-                os._exit(0)
+                os._exit(3)
         finally:
             if dog is not None:
                 dog.cancel()
@@ -518,8 +739,12 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if errors:
+        out['errors'] = errors
     if rank == 0:
         emit(out)
+    if errors:
+        sys.exit(3)
 
 
 if __name__ == '__main__':

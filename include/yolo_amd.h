@@ -290,7 +290,9 @@ int yolo_bn_train_bwd(const void* dz, const void* y, const float* mean, const fl
 /* The same two calls as TWO launches each: the per-layer finalize / parameter-gradient launches are folded into the apply
  * pass.  `workspace` (2*C doubles) must be ZERO on entry and is left dirty; `zero_next` (a different buffer of
  * zero_next_count doubles -- the next call may have more channels --, or NULL) is zeroed for the caller's next BatchNorm
- * call: callers alternate two workspaces.  Same arithmetic as yolo_bn_train_fwd / _bwd. */
+ * call: callers alternate two workspaces.  Same arithmetic as yolo_bn_train_fwd / _bwd.  yolo_bn_train_fwd_pp does NOT
+ * work in place: z == y is refused with YOLO_EINVAL (every block re-reads y at pixel 0, the pivot of its shifted sums,
+ * while another block writes z there); yolo_bn_train_fwd may run in place. */
 int yolo_bn_train_fwd_pp(const void* y, const float* gamma, const float* beta, const void* residual,
                          void* z, float* mean, float* invstd, float* running_mean, float* running_var,
                          double* workspace, double* zero_next, int zero_next_count, long long npix, int C, float eps,

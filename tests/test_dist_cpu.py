@@ -192,3 +192,48 @@ def test_rank0_only_save_does_not_deadlock(tmp_path):
         assert z['c.running_mean'].tolist() == [1.5] * 3 and z['c.weight'].tolist() == [5.0, 5.0]
     with np.load(path + '.local.npz') as z:
         assert z['c.running_mean'].tolist() == [1.0] * 3
+
+
+class _Tuned(object):
+    """Stand-in for CarNet / Trainer: the tuning-state protocol of parallel.share_tuning."""
+    def __init__(self, choices):
+        self.cache = dict(choices)
+
+    def tuning_state(self):
+        return {'algo': dict(self.cache)}
+
+    def load_tuning_state(self, st):
+        self.cache.update(st['algo'])
+
+
+def _tuning_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    # every rank "measured" its own variants (tune='measure' is box-dependent); rank 1 knows one shape rank 0 never saw
+    t = _Tuned({(32, 13, 13, 1024): 6 + rank, (32, 26, 26, 512): 2 + 3 * rank})
+    if rank == 1:
+        t.cache[(1, 1, 1, 1)] = 9
+    before = P.same_on_all_ranks(sorted(t.cache.items()))
+    state = P.share_tuning(t, src=0)
+    shared = {k: t.cache[k] for k in state['algo']}
+    after = P.same_on_all_ranks(sorted(shared.items()))
+    q.put((rank, before, after, sorted(t.cache.items())))
+    dist.destroy_process_group()
+
+
+def test_share_tuning_pins_rank0_choices_two_ranks():
+    """bench.py --gpus N / a multi-GPU trainer: rank 0's measured kernel choices reach every rank (same launch plan on all
+    ranks); shapes only another rank knows stay as they are."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_tuning_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(timeout=60) for p in ps]
+    assert [o[1] for o in out] == [False, False] and [o[2] for o in out] == [True, True]
+    assert dict(out[0][3]) == {(32, 13, 13, 1024): 6, (32, 26, 26, 512): 2}
+    assert dict(out[1][3]) == {(32, 13, 13, 1024): 6, (32, 26, 26, 512): 2, (1, 1, 1, 1): 9}
+    # a single process is its own world
+    t = _Tuned({1: 2})
+    assert P.share_tuning(t) == {'algo': {1: 2}} and P.same_on_all_ranks('x')

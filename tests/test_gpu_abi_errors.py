@@ -67,6 +67,9 @@ def test_invalid_arguments_return_a_status(cuda):
     chk('bn_train_fwd npix=0', lib.yolo_bn_train_fwd(p, p, p, None, p, p, p, p, p, p, C.c_longlong(0), 8, f(1e-5), f(0.9), f(0.1), L.BF16, st))
     chk('bn_train_bwd dtype=9', lib.yolo_bn_train_bwd(p, p, p, p, p, p, p, p, p, p, C.c_longlong(64), 8, f(0.1), 9, st))
     chk('bn_train_bwd_pp ws == zero_next', lib.yolo_bn_train_bwd_pp(p, p, p, p, p, p, p, p, p, p, p, 16, C.c_longlong(64), 8, f(0.1), L.BF16, st))
+    # the fused (two-launch) forward does not work in place: every block re-reads y at pixel 0 while another block writes z there
+    q = p + 4096
+    chk('bn_train_fwd_pp z == y', lib.yolo_bn_train_fwd_pp(p, p, p, None, p, p, p, p, p, q, q + 4096, 16, C.c_longlong(64), 8, f(1e-5), f(0.9), f(0.1), L.BF16, st))
     chk('conv_wgrad k=5', lib.yolo_conv_wgrad(p, p, p, 1, 8, 8, 8, 32, 5, 1, 0, L.BF16, p, st))
     chk('conv_wgrad N=0', lib.yolo_conv_wgrad(p, p, p, 0, 8, 8, 8, 32, 3, 1, 0, L.BF16, p, st))
     chk('conv_wgrad_algo algo=77', lib.yolo_conv_wgrad_algo(p, p, p, 1, 8, 8, 64, 64, 3, 1, 0, L.BF16, p, 77, st))

@@ -390,7 +390,7 @@ def test_bench_two_ranks_sharing_the_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     env.update(YOLO_BENCH_BACKEND='gloo', YOLO_BENCH_SHARED_GPU='1')
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--no-northstar',
-                        '--no-roofline', '--no-repeats', '--train-timeout', '900'], env=env, capture_output=True, text=True, timeout=1500)
+                        '--no-roofline', '--no-repeats', '--sustain-steps', '0', '--train-timeout', '900'], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     d = json.loads(lines[-1])                                                          # the JSON line is the LAST line
@@ -400,3 +400,7 @@ def test_bench_two_ranks_sharing_the_gpu():
     assert t['n_gpus'] == 2 and t['global_batch'] == 128 and t['exchange']['rccl_world'] == 2 and t['exchange']['buckets'] >= 2
     assert t['exchange']['allreduce_ms_per_step_standalone'] > 0 and all(np.isfinite(t['final_losses']))
     assert 'cpu_baseline' not in d and 'f32_path' not in d                              # rank-0-only extras of the N = 1 line
+    # rank 0 measured the kernel variants, rank 1 adopted its choices: the same launch plan and the same training-step
+    # variants on both ranks (tune='measure' is box- and rank-dependent when left alone), and every rank's own time is in the line
+    assert d['plans_identical_across_ranks'] is True and t['tuning_identical_across_ranks'] is True
+    assert len(d['per_rank_ms_per_step']) == 2 and len(t['per_rank_ms_per_step']) == 2 and 'errors' not in d

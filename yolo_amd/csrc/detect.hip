@@ -2,6 +2,7 @@
 // Compiled with -ffp-contract=off so fp32 arithmetic follows the reference's op-by-op NDArray
 // evaluation (no fused multiply-add), which is what makes index parity exact.
 #include "common.h"
+#include <atomic>
 #include <float.h>
 #include <string.h>
 
@@ -360,6 +361,8 @@ __global__ __launch_bounds__(kDecBoxes) void decode_scores_kernel(const float* _
     }
 }
 
+constexpr int kMaxDev = 64;
+
 extern "C" int yolo_decode_scores(const float* out, float* rows, float* scores, int B, int C, const yolo_grid_desc* g,
                                   int mode, void* stream) {
     if (!out || !rows || !scores || B <= 0 || C < 6 || (mode != 0 && mode != 1)) return YOLO_EINVAL;
@@ -371,24 +374,29 @@ extern "C" int yolo_decode_scores(const float* out, float* rows, float* scores, 
     const long long nboxes = (long long)B * nbox;
     if ((C * kDecBoxes) % 4) return YOLO_EUNSUPPORTED;         // 16-byte copies: a tile's rows start on a 16-byte boundary
     const size_t lds = (size_t)(((kDecBoxes * C + 3) & ~3) + kDecBoxes * ((mode == 1 ? C - 6 : 1) | 1)) * sizeof(float);
-    static int cus = 0;
+    // per-DEVICE launch state (a process may switch the current device; hipFuncSetAttribute applies to the current one only):
+    // CU count and "opted in to > 64 KiB of dynamic LDS", indexed by device id; relaxed atomics -- two host threads racing
+    // here both write the same values
+    static std::atomic<int> cu_of[kMaxDev];
+    static std::atomic<int> opted_of[kMaxDev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return YOLO_EUNSUPPORTED;
+    int cus = cu_of[dev].load(std::memory_order_relaxed);
     if (!cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess
-            || n <= 0) n = 256;
-        cus = n;
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cu_of[dev].store(cus = n, std::memory_order_relaxed);
     }
     long long per_cu = (long long)(160 * 1024 / lds);          // persistent blocks: as many as a CU's LDS holds
     if (per_cu > 8) per_cu = 8;
     const long long ntiles = (nboxes + kDecBoxes - 1) / kDecBoxes;
     const dim3 grid((unsigned)(ntiles < cus * per_cu ? ntiles : cus * per_cu));
-    if (lds > 65536) {                                         // (C + classes > 128: the block opts in to more than 64 KiB, once)
-        static bool opted = false;
-        if (!opted) {
-            const hipError_t e = hipFuncSetAttribute((const void*)decode_scores_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return (int)e;
-            opted = true;
+    if (lds > 65536 && !opted_of[dev].load(std::memory_order_relaxed)) {     // (C + classes > 128: more than 64 KiB, once per device)
+        if (hipFuncSetAttribute((const void*)decode_scores_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            return YOLO_EUNSUPPORTED;                          // (a negative status like every other refusal, not a raw hipError_t)
         }
+        opted_of[dev].store(1, std::memory_order_relaxed);
     }
     if (C <= 32)
         YOLO_LAUNCH(decode_scores_kernel<8>, grid, dim3(kDecBoxes), lds, (hipStream_t)stream, out, rows, scores, C,

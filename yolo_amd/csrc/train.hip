@@ -465,6 +465,10 @@ extern "C" int yolo_bn_train_fwd_pp(const void* y, const float* gamma, const flo
                                     double* workspace, double* zero_next, int zero_next_count, long long npix, int C,
                                     float eps, float momentum, float slope, int dtype, void* stream) {
     if (!y || !gamma || !beta || !z || !mean || !invstd || !workspace || npix <= 0 || C <= 0 || workspace == zero_next || zero_next_count < 0) return YOLO_EINVAL;
+    // no aliasing: EVERY block of the fused apply pass re-reads y at pixel 0 (the pivot of the shifted sums) to rebuild the mean
+    // while the block that owns pixel 0 writes z -- with z == y that is a cross-block race (the three-launch yolo_bn_train_fwd
+    // reads the pivot in its finalize launch, before the apply pass, and is safe in place)
+    if (z == y) return YOLO_EINVAL;
     if (C % 8) return YOLO_EUNSUPPORTED;
     if (dtype == YOLO_BF16)
         return bn_fwd_t<bf16_t>((const bf16_t*)y, gamma, beta, (const bf16_t*)residual, (bf16_t*)z, mean, invstd,

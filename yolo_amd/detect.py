@@ -43,9 +43,10 @@ class Detector(object):
         if list(sp[:4]) != [1, 3, 5, 6]:
             raise ValueError('decode expects slice_point [1,3,5,6,C]')
         self.C = sp[-1]
-        self.device = torch.device(device)
+        self.device = L.resolve_device(device)
         self._lib = L.load()
         self._nms_ws = {}
+        self._host = {}
 
     def _merged(self, outs):
         """Accepts the list of per-scale outputs (fine->coarse) or an already merged (B,N,A,C) tensor."""
@@ -97,6 +98,21 @@ class Detector(object):
         """YOLO.predict: np.float32 (B, 6+ncls) rows [score, y, x, h, w, rot, cls...] (D2H here)."""
         pred, _ = self.predict_device(outs)
         return pred.cpu().numpy()
+
+    def predict_async(self, outs, slot=0):
+        """predict() without the host stall: the (B, 6+ncls) rows are copied into a pinned host buffer by an asynchronous
+        copy ordered behind the kernels on the current stream.  -> (rows, event): `rows` is a np.float32 view of the pinned
+        buffer of `slot`, valid once `event.synchronize()` returned and until the next call with the same slot.  Two slots
+        let the copy of frame i overlap the launches of frame i + 1 (bench.py's step)."""
+        pred, _ = self.predict_device(outs)
+        key = (slot, tuple(pred.shape))
+        host = self._host.get(key)
+        if host is None:
+            host = self._host[key] = torch.empty(pred.shape, dtype=torch.float32, pin_memory=True)
+        host.copy_(pred, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return host.numpy(), ev
 
     def nms_scores(self, rows, mode='class'):
         B, nbox, Cc = rows.shape

@@ -145,6 +145,16 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+def resolve_device(device):
+    """torch.device with an explicit index: 'cuda' means the CURRENT device at construction time (resolved once -- an
+    object built after torch.cuda.set_device(1) with device='cuda' lives on cuda:1, not cuda:0)."""
+    import torch
+    d = torch.device(device)
+    if d.type == 'cuda' and d.index is None:
+        d = torch.device('cuda', torch.cuda.current_device())
+    return d
+
+
 def require_current_device(device, what):
     """The library launches on the CURRENT device's current stream (one process per GPU: `torch.cuda.set_device(LOCAL_RANK)`
     first, as bench.py does).  An object living on another GPU than the current one would have its kernels launched on the

@@ -43,7 +43,7 @@ class CarNet(object):
             raise ValueError('dtype must be bf16 or f32')
         self.graph = NetGraph(spec)
         self.dtype = dtype
-        self.device = torch.device(device)
+        self.device = L.resolve_device(device)
         # tune: 'auto' = the library's heuristic picks the conv tile variant; 'measure' = time every
         # variant once per distinct layer shape when a plan is built (HIP events) and pin the fastest
         if tune not in ('auto', 'measure'):
@@ -157,6 +157,7 @@ class CarNet(object):
 
     # ---- one-off preparation: BN folding + weight packing (all on device, HIP kernels) ------------
     def prepare(self):
+        L.require_current_device(self.device, 'this CarNet')
         lib, st, dt = self._lib, L.stream_ptr(), _LIB_DT[self.dtype]
         for c in self.graph.convs():
             w = self.params[c.name + '.weight']
@@ -250,6 +251,21 @@ class CarNet(object):
         self._algo_cache[key] = int(use)
         self._save_tune_cache()
         return use
+
+    # ---- measured kernel choices as a value (N > 1: rank 0 measures, every rank runs rank 0's plan) ----------------
+    def tuning_state(self):
+        """The measured per-shape kernel choices (tune='measure') as a picklable dict."""
+        return {'algo': dict(self._algo_cache)}
+
+    def load_tuning_state(self, state):
+        """Adopt another rank's choices: shapes found here are not measured again, so a plan built afterwards launches the
+        same kernel instantiations as on the rank the state came from (parallel.share_tuning)."""
+        self._algo_cache.update(state['algo'])
+        return self
+
+    def plan_signature(self, B, H, W):
+        """[(op, kernel instantiation)] of the launch plan for one input shape -- what must agree across ranks."""
+        return [(n, k) for n, k, _ in self.plan_kernels(B, H, W)]
 
     def _save_tune_cache(self):
         if self._tune_cache:

@@ -59,6 +59,29 @@ def global_batch_size(local_batch, device=None):
     return int(t.item())
 
 
+def share_tuning(obj, src=0):
+    """COLLECTIVE: rank `src`'s measured kernel choices (CarNet / Trainer .tuning_state()) -> every rank, so that all ranks
+    launch the SAME kernel instantiations (tune='measure' times variants per box: left alone, N ranks pick N plans, and a
+    rank on a slower variant is the straggler every all-reduce waits for).  Call it after rank `src` has built its plan
+    (CarNet.plan_signature / Trainer.tune) and before the others build theirs.  Returns the state in force."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return obj.tuning_state()
+    box = [obj.tuning_state() if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    if dist.get_rank() != src:
+        obj.load_tuning_state(box[0])
+    return box[0]
+
+
+def same_on_all_ranks(value):
+    """COLLECTIVE: True when every rank holds an equal `value` (any picklable object)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return True
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, value)
+    return all(g == got[0] for g in got)
+
+
 def checkpoint_params(params):
     """The parameter dict a checkpoint holds: `.running_mean` / `.running_var` averaged over the ranks (copies; the
     live statistics stay local to a GPU: no SyncBN) -- what gluon's Parameter._reduce() does with the per-device

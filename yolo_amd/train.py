@@ -688,6 +688,7 @@ class Trainer(object):
         of 3 d(loss)/d(logits) tensors, shaped like forward()'s outputs (or ONE merged (B, sum HiWi, A, C) tensor);
         CarLPNet: lp_grads = d(loss)/d(LP_output).  Fills grads() and -- with a process group -- starts the bucketed
         SUM all-reduce of the gradient buffer (exchange=False: local gradients only)."""
+        L.require_current_device(self.dev, 'this Trainer')
         if self._fwd_B is None:
             raise L.YoloError('backward() without a training-mode forward()')
         P = self._plans[self._fwd_B]
@@ -713,6 +714,7 @@ class Trainer(object):
         """`trainer.step(batch_size)` (car/YOLO.py:396): joins the gradient exchange, rescales by 1/batch_size and applies
         the MXNet Adam update on every rank.  batch_size=None: the SUM of the ranks' shard sizes of the last backward,
         taken from the slot the exchange itself reduced (no collective of its own, no host read)."""
+        L.require_current_device(self.dev, 'this Trainer')
         lib, st = self.lib, L.stream_ptr()
         self.buckets.wait()                                    # KVStore sum-reduce of trainer.step (RCCL), bucketed
         self.t += 1
@@ -786,6 +788,29 @@ class Trainer(object):
 
     def grads(self):
         return self.gview
+
+    # ---- measured kernel choices as a value (N > 1: rank 0 measures, every rank runs rank 0's plan) -----------------
+    def tuning_state(self):
+        return {'algo': dict(self.net._algo_cache), 'dgrad': dict(self._dgrad_algo), 'wgrad': dict(self._wgrad_algo)}
+
+    def load_tuning_state(self, state):
+        self.net._algo_cache.update(state['algo'])
+        self._dgrad_algo.update(state['dgrad'])
+        self._wgrad_algo.update(state['wgrad'])
+        return self
+
+    def tune(self, images, labels, lp_labels=None):
+        """One LOCAL step (no exchange, no update) whose only lasting effect is the measured kernel choices of every layer
+        shape of this batch -- forward variants, data- and weight-gradient variants: what rank 0 runs before
+        parallel.share_tuning() hands its choices to the other ranks.  The BatchNorm running statistics the forward
+        moved are put back."""
+        keep = {n: t.clone() for n, t in self.net.params.items() if n.endswith(('.running_mean', '.running_var'))}
+        self.train_step(images, labels, update=False, lp_labels=lp_labels)
+        for n, t in keep.items():
+            self.net.params[n].copy_(t)
+        self.net._version += 1
+        torch.cuda.synchronize()
+        return self.tuning_state()
 
     def merged_logits(self):
         P = self._last[0]
