@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import torch
-from util import run_conv, ref_conv, to_nhwc, from_nhwc
+from util import run_conv, ref_conv, to_nhwc, from_nhwc, eligible_pairs, conv_variant
 from yolo_amd import lib as L
 
 pytestmark = pytest.mark.gpu
@@ -105,22 +105,15 @@ PIPE_CASES = [
 ]
 
 
-@pytest.mark.parametrize('algo', [2, 3, 4, 5, 6, 7, 8, 11, 12, 19, 20, 21, 22, 23, 24, 25, 26, 30, 31, 32, 33, 35, 36, 37, 38, 39])
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
-@pytest.mark.parametrize('case', PIPE_CASES)
+PIPE_ALGOS = [2, 3, 4, 5, 6, 7, 8, 11, 12, 19, 20, 21, 22, 23, 24, 25, 26, 30, 31, 32, 33, 35, 36, 37, 38, 39]
+
+
+# only the (shape, dtype, variant) pairs the library accepts (tests/util.py:eligible_pairs; the refusal rules are asserted
+# on the CPU by tests/test_host.py::test_conv_variant_eligibility_rules)
+@pytest.mark.parametrize('case,dtype,algo', eligible_pairs(PIPE_CASES, ['f32', 'bf16'], PIPE_ALGOS))
 def test_conv_pipe(lib, cuda, case, dtype, algo):
-    if (algo in (6, 7, 26) and case[5] != 3) or (algo in (12, 19, 20, 21, 22, 23, 24, 25, 36, 37, 38, 39) and case[5] != 1) or (algo == 26 and dtype != 'bf16'):
-        pytest.skip('variant not defined for this kernel size')
-    if algo >= 30 and case[5] != 1:
-        pytest.skip('split-K-in-block variants (conv_sk.hip): 1x1 only')
     x, w, scale, bias, r = _mk(case, 4)
-    # (the in-block split-K variants need the K chunks to divide by their group count: EUNSUPPORTED otherwise, asserted below)
-    y = run_conv(lib, cuda, x, w, scale, bias, case[6], 0.1, dtype, residual=r, algo=algo, expect_rc=None if algo >= 30 else 0)
-    if y is None:
-        es, kg = (4 if dtype == 'f32' else 2), (4 if algo in (30, 35) else 2)
-        nch = case[1] * es // 64
-        assert nch % kg or nch // kg < 3, 'a split-K variant refused a shape it should take'
-        pytest.skip('K chunks do not divide by the group count')
+    y = run_conv(lib, cuda, x, w, scale, bias, case[6], 0.1, dtype, residual=r, algo=algo, expect_rc=0)
     ref = ref_conv(x, w, scale, bias, case[6], 0.1, residual=r, bf16=(dtype == 'bf16'))
     assert not np.isnan(y).any()
     if dtype == 'f32':
@@ -145,14 +138,13 @@ S2_CASES = [
 ]
 
 
-@pytest.mark.parametrize('algo', [9, 10, 16, 17, 18])
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
-@pytest.mark.parametrize('case', S2_CASES)
+S2_ALGOS = [9, 10, 16, 17, 18]
+
+
+@pytest.mark.parametrize('case,dtype,algo', eligible_pairs(S2_CASES, ['f32', 'bf16'], S2_ALGOS))
 def test_conv_pipe_stride2(lib, cuda, case, dtype, algo):
     x, w, scale, bias, r = _mk(case, 6)
-    y = run_conv(lib, cuda, x, w, scale, bias, 2, 0.1, dtype, algo=algo, expect_rc=None if algo >= 16 else 0)
-    if y is None:
-        pytest.skip('halo tile of this shape does not fit the smaller buffer of this variant')
+    y = run_conv(lib, cuda, x, w, scale, bias, 2, 0.1, dtype, algo=algo, expect_rc=0)
     ref = ref_conv(x, w, scale, bias, 2, 0.1, bf16=(dtype == 'bf16'))
     assert not np.isnan(y).any()
     if dtype == 'f32':
@@ -179,14 +171,10 @@ STREAM_CASES = [
 ]
 
 
-@pytest.mark.parametrize('algo', [13, 14])
-@pytest.mark.parametrize('case', STREAM_CASES)
-def test_conv_stream(lib, cuda, case, algo):
+@pytest.mark.parametrize('case,dtype,algo', eligible_pairs(STREAM_CASES, ['bf16'], [13, 14]))
+def test_conv_stream(lib, cuda, case, dtype, algo):
     x, w, scale, bias, r = _mk(case, 7)
-    y = run_conv(lib, cuda, x, w, scale, bias, case[6], 0.1, 'bf16', residual=r, algo=algo, expect_rc=None)
-    if y is None:
-        assert algo == 14 and (case[6] == 2 or case[4] == 32)     # the wide variant is not instantiated there
-        pytest.skip('variant not instantiated for this shape')
+    y = run_conv(lib, cuda, x, w, scale, bias, case[6], 0.1, 'bf16', residual=r, algo=algo, expect_rc=0)
     ref = ref_conv(x, w, scale, bias, case[6], 0.1, residual=r, bf16=True)
     assert not np.isnan(y).any()
     np.testing.assert_allclose(y, ref, rtol=1.6e-2, atol=2e-2)
@@ -257,10 +245,12 @@ def test_stem_down_rejects(lib, cuda):
     assert lib.yolo_stem_down_fwd(*args(32, 64, L.BF16, 1.5)) == L.EINVAL
 
 
-@pytest.mark.parametrize('case,algo', [((2, 128, 26, 26, 256, 3, 1, True), 0), ((2, 128, 26, 26, 256, 3, 1, True), 4),
-                                       ((3, 256, 13, 13, 88, 1, 1, False), 1), ((2, 64, 40, 40, 128, 3, 1, True), 13),
-                                       ((2, 64, 26, 26, 128, 3, 2, False), 0), ((1, 256, 13, 13, 512, 1, 1, True), 11)])
-@pytest.mark.parametrize('dtype', ['bf16', 'f32'])
+IDENT_CASES = [((2, 128, 26, 26, 256, 3, 1, True), 0), ((2, 128, 26, 26, 256, 3, 1, True), 4),
+               ((3, 256, 13, 13, 88, 1, 1, False), 1), ((2, 64, 40, 40, 128, 3, 1, True), 13),
+               ((2, 64, 26, 26, 128, 3, 2, False), 0), ((1, 256, 13, 13, 512, 1, 1, True), 11)]
+
+
+@pytest.mark.parametrize('case,algo,dtype', [(c, a, dt) for c, a in IDENT_CASES for dt in ('bf16', 'f32') if conv_variant(c, dt, a) is not None])
 def test_identity_epilogue(lib, cuda, case, algo, dtype):
     """scale == bias == NULL (the training step's raw convolutions / data gradients): bit-identical to scale 1, bias 0,
     slope 1 through every epilogue path; exactly one of the two NULL is an argument error."""
@@ -269,8 +259,6 @@ def test_identity_epilogue(lib, cuda, case, algo, dtype):
     from yolo_amd import lib as L
     from util import to_nhwc, LDT, TDT
     N, Cin, H, W, Cout, k, stride, with_res = case
-    if algo == 13 and dtype != 'bf16':
-        pytest.skip('the streaming kernel is bf16 only')
     x, w, _, _, r = _mk(case, 21)
     st = torch.cuda.current_stream().cuda_stream
     dt = LDT[dtype]
@@ -435,9 +423,12 @@ STATS_CASES = [(2, 32, 40, 70, 64, 3, 1), (3, 32, 33, 50, 64, 3, 2), (2, 64, 21,
                (4, 256, 13, 13, 512, 1, 1), (2, 64, 26, 26, 128, 3, 2), (5, 32, 7, 9, 16, 1, 1), (2, 128, 19, 19, 72, 3, 1)]
 
 
-@pytest.mark.parametrize('mode', [1, 2])
-@pytest.mark.parametrize('algo', [0, 1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 16, 17, 18, 22, 23, 26])
-@pytest.mark.parametrize('case', STATS_CASES)
+STATS_ALGOS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 16, 17, 18, 22, 23, 26]
+
+
+@pytest.mark.parametrize('case,algo,mode', [pytest.param(c, a, m, id='%s-a%d-m%d' % ('x'.join(map(str, c)), a, m))
+                                            for c in STATS_CASES for a in STATS_ALGOS for m in (1, 2)
+                                            if conv_variant(c, 'bf16', a, stats_mode=m) is not None])
 def test_conv_statistics_epilogue(lib, cuda, case, algo, mode):
     """yolo_conv_desc.stats: Gluon BatchNorm's batch sums taken in the convolution's epilogue (per pixel-tile partial rows,
     summed in double by yolo_bn_train_*_partials).  Mode 1: sum(y), sum(y^2) of the stored bf16 output; mode 2 (a data
@@ -446,8 +437,6 @@ def test_conv_statistics_epilogue(lib, cuda, case, algo, mode):
     reduces the stored tensor itself."""
     import ctypes as C
     N, Cin, H, W, Cout, k, stride = case
-    if mode == 2 and stride != 1:
-        pytest.skip('data-gradient sums: stride-1 kernels')
     rng = np.random.default_rng(7)
     x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
     w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
@@ -470,8 +459,6 @@ def test_conv_statistics_epilogue(lib, cuda, case, algo, mode):
     if mode == 1:
         d.stats, d.stats_mode = 1, 1
         rows = lib.yolo_conv_stats_rows(C.byref(d))
-        if rows == L.EUNSUPPORTED:
-            pytest.skip('variant not eligible for this shape')
         assert rows > 0
         part = torch.full((rows, 2, cp), float('nan'), device=cuda)
         d.stats = part.data_ptr()
@@ -503,8 +490,6 @@ def test_conv_statistics_epilogue(lib, cuda, case, algo, mode):
     d.stats_mean, d.stats_invstd, d.stats_gamma, d.stats_beta, d.stats_slope = (mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                                                                                beta.data_ptr(), 0.1)
     rows = lib.yolo_conv_stats_rows(C.byref(d))
-    if rows == L.EUNSUPPORTED:
-        pytest.skip('variant not eligible for this shape')
     assert rows > 0
     part = torch.full((rows, 2, cp), float('nan'), device=cuda)
     d.stats = part.data_ptr()

@@ -1,0 +1,276 @@
+"""Multi-step parity of the training loop (car/YOLO.py:350-399 run K = 5 times on changing batches), the reference's one
+quality metric (`_valid_iou`, car/YOLO.py:501-534) as a composition of the parts, and the run-to-run spread of a gradient.
+
+Why two kinds of bars.  A randomly initialised net is chaotic in its weights: a forward difference of 1e-6 flips a few LeakyReLU
+kink decisions and, through Adam's first steps (|step| = lr whatever the gradient's size), moves isolated weights by up to 2 lr
+(tests/test_gpu_train.py::test_train_step_losses_and_grads).  So
+  * TEACHER-FORCED, strict: every step is checked against the oracle started from the state the HIP path had BEFORE that step
+    (weights, Adam moments, update count, running statistics) -- losses, logits, running mean / variance and, on the gradient the
+    HIP path itself produced, the MXNet Adam update with non-zero moments and t > 1, to 1e-4 or better;
+  * FREE-RUNNING, bounded: the oracle's own K-step trajectory from the initial state; the HIP weights may leave it only in a small
+    fraction of the elements and never by more than Adam can move a weight (bars below, observed values in the messages)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import graph as og, train as ot, detect as od, forward as of
+
+pytestmark = pytest.mark.gpu
+K = 5
+LR = 1e-3
+
+
+def _batches(k, B, size):
+    """K different batches (images and labels), seeded."""
+    xs = [np.random.default_rng(20 + i).random((B, 3) + size, dtype=np.float32) for i in range(k)]
+    labs = [ot.synthetic_labels(B, seed=40 + i, render_rate=0.25, num_class=4) for i in range(k)]
+    return xs, labs
+
+
+def _state(net, tr):
+    P = {n: t.detach().cpu().numpy().copy() for n, t in net.params.items()}
+    return P, tr.mflat.cpu().numpy().copy(), tr.vflat.cpu().numpy().copy()
+
+
+def _views(tr, flat):
+    """name -> view of a flat host copy laid out like the Trainer's buffers."""
+    out = {}
+    base = tr.wflat.data_ptr()
+    for n in tr.names:
+        o = (tr.pview[n].data_ptr() - base) // 4
+        out[n] = flat[o:o + tr.pview[n].numel()].reshape(tuple(tr.pview[n].shape))
+    return out
+
+
+def _oracle_step(g, P, m, v, t, x, lab, spec, size, batch):
+    """One reference step from (P, m, v, t-1): -> losses, grads, new running statistics; P / m / v updated in place."""
+    st = {}
+    rl, rg, merged = ot.train_step_reference(g, P, x, lab, spec, size)
+    of.forward_torch(g, P, x, training=True, bn_stats=st)
+    for cname, (mean, var) in st.items():
+        P[cname + '.running_mean'] = (0.9 * P[cname + '.running_mean'] + 0.1 * mean.numpy()).astype(np.float32)
+        P[cname + '.running_var'] = (0.9 * P[cname + '.running_var'] + 0.1 * var.numpy()).astype(np.float32)
+    for n in rg:
+        ot.adam_step(P[n], rg[n], m[n], v[n], t, lr=LR, rescale=1.0 / batch)
+    return np.stack(rl), rg, merged
+
+
+def test_five_steps_teacher_forced_and_free_running(cuda):
+    from yolo_amd.net import CarNet
+    from yolo_amd.train import Trainer
+    spec, size, B = og.spec_micro(), (64, 96), 3
+    g = og.build_graph(spec)
+    P0 = og.init_params(g, seed=0, bn='random')
+    xs, labs = _batches(K, B, size)
+    net = CarNet(spec, dtype='f32', device=cuda).load_params(P0)
+    tr = Trainer(net, size, learning_rate=LR)
+    # the free-running oracle
+    Pf = {n: a.copy() for n, a in P0.items()}
+    mf = {n: np.zeros_like(a) for n, a in P0.items()}
+    vf = {n: np.zeros_like(a) for n, a in P0.items()}
+    report = []
+    for k in range(K):
+        Pb, mb_flat, vb_flat = _state(net, tr)
+        mb, vb = _views(tr, mb_flat), _views(tr, vb_flat)
+        losses = tr.train_step(torch.from_numpy(xs[k]).to(cuda), torch.from_numpy(labs[k]).to(cuda))
+        torch.cuda.synchronize()
+        assert tr.t == k + 1                                                    # Adam's update count
+        Pa, ma_flat, va_flat = _state(net, tr)
+        ma, va = _views(tr, ma_flat), _views(tr, va_flat)
+        g_hip = {n: t.cpu().numpy() for n, t in tr.grads().items()}             # (stays in the bucket until the next backward)
+        # ---- teacher-forced: the oracle from the state BEFORE this step --------------------------------------------------
+        Pt = {n: a.copy() for n, a in Pb.items()}
+        mt = {n: mb[n].copy() for n in g_hip}
+        vt = {n: vb[n].copy() for n in g_hip}
+        rl, rg, merged = _oracle_step(g, Pt, mt, vt, k + 1, xs[k], labs[k], spec, size, B)
+        np.testing.assert_allclose(losses.cpu().numpy(), rl, rtol=1e-3, atol=1e-7, err_msg='losses, step %d' % (k + 1))
+        lg = tr.merged_logits().cpu().numpy()
+        assert np.abs(lg - merged).max() <= 1e-4 * max(1.0, np.abs(merged).max()), 'train-mode logits, step %d' % (k + 1)
+        for n in Pa:
+            if n.endswith(('.running_mean', '.running_var')):
+                np.testing.assert_allclose(Pa[n], Pt[n], rtol=1e-4, atol=1e-6, err_msg='%s, step %d' % (n, k + 1))
+        rel = sorted(np.linalg.norm(g_hip[n].astype(np.float64) - rg[n]) / (np.linalg.norm(rg[n]) + 1e-30) for n in rg)
+        assert rel[len(rel) // 2] < 2e-3 and rel[-1] < 0.15, ('gradients, step %d' % (k + 1), rel[len(rel) // 2], rel[-1])
+        # Adam with non-zero moments and t > 1, exactly: the oracle's formula on the gradient the HIP path produced
+        for n in g_hip:
+            w, m, v = Pb[n].copy(), mb[n].copy(), vb[n].copy()
+            ot.adam_step(w, g_hip[n], m, v, k + 1, lr=LR, rescale=1.0 / B)
+            np.testing.assert_allclose(ma[n], m, rtol=1e-5, atol=1e-12, err_msg='m %s step %d' % (n, k + 1))
+            np.testing.assert_allclose(va[n], v, rtol=1e-5, atol=1e-20, err_msg='v %s step %d' % (n, k + 1))
+            np.testing.assert_allclose(Pa[n], w, rtol=1e-5, atol=2e-7, err_msg='w %s step %d' % (n, k + 1))
+        # ---- free-running oracle ----------------------------------------------------------------------------------------
+        fl, _, _ = _oracle_step(g, Pf, mf, vf, k + 1, xs[k], labs[k], spec, size, B)
+        dw = np.concatenate([np.abs(Pa[n] - Pf[n]).ravel() for n in g_hip])
+        far = float(np.mean(dw > 1e-4))
+        stats = [n for n in Pa if n.endswith(('.running_mean', '.running_var'))]
+        ds = max(float(np.abs(Pa[n] - Pf[n]).max() / (np.abs(Pf[n]).max() + 1e-12)) for n in stats)
+        dl = float(np.abs(losses.cpu().numpy() - fl).max() / (np.abs(fl).max() + 1e-12))
+        report.append((k + 1, far, float(dw.max()), ds, dl))
+        # nobody can leave the trajectory by more than Adam moves a weight: |step| <= lr * (1 - b1^t)^-1 ... < 3.2 lr early on
+        assert dw.max() <= 2 * 3.2 * LR * (k + 1), report
+        assert far < 0.02 and ds < 2e-2 and dl < 5e-2, report
+    print('free-running (step, fraction of weights off by > 1e-4, max |dw|, running stats rel, losses rel):', report)
+
+
+# ---- the same K steps between two REAL ranks with uneven shards ---------------------------------------------------------------
+def _traj_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from yolo_amd.net import CarNet
+    from yolo_amd.train import Trainer
+    from yolo_amd import parallel
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        cuda = torch.device('cuda:0')
+        spec, size, B = og.spec_micro(), (64, 96), 5
+        P0 = og.init_params(og.build_graph(spec), seed=0, bn='random')
+        xs, labs = _batches(K, B, size)
+        a, b = parallel.shard_bounds(B, rank, world)                  # 2 + 3 images (yolo_gluon.py:118-119)
+        net = CarNet(spec, dtype='f32', device=cuda).load_params(P0)
+        tr = Trainer(net, size, learning_rate=LR)
+        rec = []
+        for k in range(K):
+            losses = tr.train_step(torch.from_numpy(xs[k][a:b]).to(cuda), torch.from_numpy(labs[k][a:b]).to(cuda))
+            torch.cuda.synchronize()
+            P, m, v = _state(net, tr)
+            rec.append((losses.cpu().numpy(), tr.wflat.cpu().numpy(), m, v, tr.gflat.cpu().numpy(),
+                        {n: t for n, t in P.items() if n.endswith(('.running_mean', '.running_var'))}, tr.t))
+        q.put((rank, rec))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_five_steps_two_real_ranks_uneven_shards(cuda):
+    """configs[3] over K = 5 steps with two PROCESSES (uneven shards 2 + 3, per-rank batch statistics, the Trainer's bucketed
+    all-reduce, identical Adam on both ranks): after EVERY step both ranks hold the same weights / moments / update count, and
+    the single-process emulation started from the ranks' state before that step -- the two shards run one after the other, their
+    gradient buffers added by hand, step(5), each shard on its rank's own running statistics -- reproduces the step."""
+    import socket
+    import torch.multiprocessing as mp
+    from yolo_amd.net import CarNet
+    from yolo_amd.train import Trainer
+    from yolo_amd import parallel
+    so = socket.socket(); so.bind(('127.0.0.1', 0)); port = so.getsockname()[1]; so.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_traj_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    out = dict(q.get(timeout=900) for _ in range(2))
+    [p.join(timeout=120) for p in ps]
+    spec, size, B = og.spec_micro(), (64, 96), 5
+    g = og.build_graph(spec)
+    P0 = og.init_params(g, seed=0, bn='random')
+    xs, labs = _batches(K, B, size)
+    net = CarNet(spec, dtype='f32', device=cuda).load_params(P0)
+    tr = Trainer(net, size, learning_rate=LR)
+    n = tr.nparam
+    stats0 = {k_: v_.copy() for k_, v_ in P0.items() if k_.endswith(('.running_mean', '.running_var'))}
+    prev = [(None, tr.wflat.cpu().numpy(), tr.mflat.cpu().numpy(), tr.vflat.cpu().numpy(), None, stats0, 0)] * 2
+    for k in range(K):
+        r0, r1 = out[0][k], out[1][k]
+        assert r0[6] == r1[6] == k + 1
+        for i in (1, 2, 3, 4):                                        # weights, m, v, reduced gradient buffer: identical on both ranks
+            np.testing.assert_array_equal(r0[i], r1[i], err_msg='rank 0 vs rank 1, buffer %d, step %d' % (i, k + 1))
+        assert r0[4][n] == 5.0                                        # the slot: SUM of the shard sizes
+        # ---- single-process emulation of this step from the ranks' state before it
+        gsum, ls = None, []
+        for r in range(2):
+            a, b = parallel.shard_bounds(B, r, 2)
+            tr.wflat.copy_(torch.from_numpy(prev[r][1]))
+            for sn, sv in prev[r][5].items():
+                net.params[sn].copy_(torch.from_numpy(sv))
+            net._version += 1
+            ls.append(tr.train_step(torch.from_numpy(xs[k][a:b]).to(cuda), torch.from_numpy(labs[k][a:b]).to(cuda), update=False).cpu().numpy())
+            gsum = tr.gflat.clone() if gsum is None else gsum + tr.gflat
+            for sn in prev[r][5]:                                     # each rank's running statistics moved on its own shard
+                np.testing.assert_allclose(net.params[sn].cpu().numpy(), out[r][k][5][sn], rtol=1e-5, atol=1e-7, err_msg='%s rank %d step %d' % (sn, r, k + 1))
+        np.testing.assert_allclose(np.concatenate([r0[0], r1[0]], axis=1), np.concatenate(ls, axis=1), rtol=1e-5, atol=1e-8)
+        g_ref, g_got = gsum.cpu().numpy(), r0[4]
+        assert np.abs(g_got - g_ref).max() <= 1e-5 * np.abs(g_ref).max() + 1e-9, 'summed gradient, step %d' % (k + 1)
+        # Adam from the ranks' moments on the ranks' own reduced gradient: exact
+        w, m, v = prev[0][1][:n].copy(), prev[0][2][:n].copy(), prev[0][3][:n].copy()
+        ot.adam_step(w, g_got[:n], m, v, k + 1, lr=LR, rescale=1.0 / 5)
+        np.testing.assert_allclose(r0[2][:n], m, rtol=1e-5, atol=1e-12)
+        np.testing.assert_allclose(r0[3][:n], v, rtol=1e-5, atol=1e-20)
+        np.testing.assert_allclose(r0[1][:n], w, rtol=1e-5, atol=2e-7)
+        prev = [r0, r1]
+
+
+# ---- _valid_iou (car/YOLO.py:501-534): predict -> ltrb -> get_iou(mode=2) -> mean ----------------------------------------
+def test_valid_iou_composition_vs_oracle(cuda):
+    """The reference's validation metric is a composition: `predict` rows [score, y, x, h, w, ...] of every image -> the box
+    as ltrb -> `get_iou(box, label, mode=2)` against the image's label [c, y, x, h, w] -> the mean over the batch.  The HIP parts
+    (CarNet.forward, Detector.predict, yolo_amd.get_iou) composed the same way must give the oracle's number."""
+    from yolo_amd.net import CarNet
+    from yolo_amd.detect import Detector, get_iou
+    spec, size, B = og.spec_micro(), (64, 96), 6
+    g = og.build_graph(spec)
+    P = og.init_params(g, seed=0, bn='random')
+    x = np.random.default_rng(5).random((B, 3) + size, dtype=np.float32)
+    lab = ot.synthetic_labels(B, seed=11, render_rate=0.0, num_class=4)
+    steps = od.init_steps(spec['layers'], spec['all_anchors'])
+    syxhw = od.init_syxhw(size, steps, spec['all_anchors'])
+    # oracle
+    ref_outs = of.forward_torch(g, P, x)
+    rpred, ridx = od.predict([o.numpy() for o in ref_outs], spec['slice_point'], size, syxhw)
+    ref_ious = []
+    for b in range(B):
+        _, y, xx, h, w = rpred[b, :5]
+        ltrb = np.array([xx - w / 2, y - h / 2, xx + w / 2, y + h / 2], np.float32)
+        ref_ious.append(float(od.get_iou(ltrb[None], lab[b, 0, :5], mode=2).reshape(-1)[0]))
+    # HIP path
+    net = CarNet(spec, dtype='f32', device=cuda).load_params(P)
+    det = Detector(spec, size, steps, device=cuda)
+    pred = det.predict(net(torch.from_numpy(x).to(cuda)))
+    np.testing.assert_allclose(pred, rpred, rtol=1e-3, atol=1e-4)
+    ious = []
+    for b in range(B):
+        _, y, xx, h, w = pred[b, :5]
+        ltrb = torch.tensor([[xx - w / 2, y - h / 2, xx + w / 2, y + h / 2]], dtype=torch.float32, device=cuda)
+        ious.append(float(get_iou(ltrb, torch.from_numpy(lab[b, 0, :5]), mode=2).reshape(-1)[0]))
+    np.testing.assert_allclose(ious, ref_ious, rtol=1e-3, atol=1e-5)
+    assert abs(np.mean(ious) - np.mean(ref_ious)) < 1e-4
+    assert 0.0 <= min(ious) and max(ious) <= 1.0 and max(ious) > 0.0
+
+
+# ---- run-to-run spread of a gradient ----------------------------------------------------------------------------------------
+def test_gradient_run_to_run_spread_bs64(cuda):
+    """The weight gradients accumulate with fp32 atomics (wgrad_walk / wgrad_gemm epilogues, split pixel ranges): the order of
+    the additions is not fixed, so two identical steps need not be bit-identical.  This test makes the nondeterminism a number:
+    two identical bs-64 bf16 steps of the D53 spec at 416x416 from the same state -- the activations (logits, losses) must be
+    bit-identical, every weight gradient within 1e-5 of its own largest element and 1e-4 in relative L2 (fp32 summation-order
+    noise; observed values are printed)."""
+    from yolo_amd.net import CarNet
+    from yolo_amd.train import Trainer
+    from yolo_amd.spec import darknet53_spec
+    spec, size, B = darknet53_spec(), (416, 416), 64
+    net = CarNet(spec, dtype='bf16', device=cuda).initialize(seed=1234)
+    tr = Trainer(net, size)
+    x = torch.rand((B, 3) + size, generator=torch.Generator().manual_seed(7)).to(cuda)
+    lab = torch.from_numpy(ot.synthetic_labels(B, seed=3, render_rate=0.5, num_class=24)).to(cuda)
+    runs = []
+    for _ in range(2):
+        losses = tr.train_step(x, lab, update=False)
+        torch.cuda.synchronize()
+        runs.append((losses.clone(), tr.merged_logits().clone(), tr.gflat.clone()))
+        # (update=False still moves the running statistics: put the forward's inputs back exactly)
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][0], runs[1][0])       # no atomics on the forward path
+    worst_max, worst_l2, nz = 0.0, 0.0, 0
+    base = tr.gflat.data_ptr()
+    for n in tr.names:
+        o = (tr.gview[n].data_ptr() - base) // 4
+        a, b = runs[0][2][o:o + tr.gview[n].numel()].double(), runs[1][2][o:o + tr.gview[n].numel()].double()
+        scale = float(b.abs().max())
+        if scale == 0.0:
+            assert float(a.abs().max()) == 0.0
+            continue
+        d = (a - b).abs()
+        nz += int((d > 0).sum())
+        worst_max = max(worst_max, float(d.max()) / scale)
+        worst_l2 = max(worst_l2, float((a - b).norm() / (b.norm() + 1e-300)))
+    print('run-to-run gradient spread: max |d| / max |g| = %.3g, worst relative L2 = %.3g, elements that differ: %d of %d'
+          % (worst_max, worst_l2, nz, tr.nparam))
+    assert worst_max < 1e-5 and worst_l2 < 1e-4, (worst_max, worst_l2)

@@ -69,3 +69,40 @@ def ref_conv(x, w, scale, bias, stride, slope, residual=None, bf16=False):
     if bf16:
         y = rb(y)
     return y.numpy()
+
+
+def conv_variant(case, dtype, algo, stats_mode=0, residual=None):
+    """Which kernel instantiation `algo` runs for a conv case (N, Cin, H, W, Cout, k, stride[, residual]) -- None when the library
+    refuses the pair.  A host-side query (yolo_conv_kernel_name / yolo_conv_stats_rows: no launch, no GPU), so the GPU tests
+    are parametrised over the ELIGIBLE (shape, variant) pairs only and a skip means something again; the refusal rules
+    themselves are asserted by tests/test_host.py::test_conv_variant_eligibility_rules."""
+    lib = L.load()
+    N, Cin, H, W, Cout, k, stride = case[:7]
+    d = L.ConvDesc()
+    d.x = d.w_packed = d.y = 4096                       # (never dereferenced by the queries)
+    if (case[7] if (residual is None and len(case) > 7) else residual):
+        d.residual = 4096
+    d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride = N, H, W, Cin, Cout, k, stride
+    d.dtype, d.slope, d.algo = LDT[dtype], (1.0 if stats_mode else 0.1), algo
+    if stats_mode:
+        d.stats, d.stats_mode = 4096, stats_mode
+        if stats_mode == 2:
+            d.residual = d.stats_y = d.stats_mean = d.stats_invstd = d.stats_gamma = d.stats_beta = 4096
+            d.stats_slope = 0.1
+        rows = lib.yolo_conv_stats_rows(C.byref(d))
+        return None if rows <= 0 else 'stats rows %d' % rows
+    buf = C.create_string_buffer(256)
+    rc = lib.yolo_conv_kernel_name(C.byref(d), buf, 256)
+    return buf.value.decode() if rc == 0 else None
+
+
+def eligible_pairs(cases, dtypes, algos, **kw):
+    """[(case, dtype, algo)] the library accepts, as pytest params with readable ids."""
+    import pytest
+    out = []
+    for case in cases:
+        for dtype in dtypes:
+            for algo in algos:
+                if conv_variant(case, dtype, algo, **kw) is not None:
+                    out.append(pytest.param(case, dtype, algo, id='%s-%s-a%d' % ('x'.join(str(int(v)) for v in case), dtype, algo)))
+    return out
