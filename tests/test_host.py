@@ -131,3 +131,47 @@ def test_objects_refuse_a_foreign_current_device(monkeypatch):
     L.require_current_device(torch.device('cuda'), 'x')
     with pytest.raises(L.YoloError, match='set_device'):
         L.require_current_device(torch.device('cuda:1'), 'this CarNet')
+
+
+def test_conv_variant_eligibility_rules():
+    """The GPU convolution tests are parametrised over the (shape, dtype, variant) pairs the library ACCEPTS
+    (tests/util.py:eligible_pairs, a host-side query).  This test pins the other half on the CPU: which pairs are refused, and
+    why -- a variant that starts refusing a shape it used to take (or the reverse) fails here instead of silently leaving the
+    GPU parametrisation."""
+    import test_gpu_conv as T
+    from util import conv_variant
+    sk = {30: (4, 3), 31: (2, 4), 32: (2, 3), 33: (2, 4), 35: (4, 4)}        # conv_sk.hip: (K groups, ring depth)
+    n_ok = 0
+    for case in T.PIPE_CASES:
+        for dt in ('f32', 'bf16'):
+            for a in T.PIPE_ALGOS:
+                k = case[5]
+                exp = True
+                if a in (6, 7, 26) and k != 3:
+                    exp = False                                               # 192-pixel and 128x128-wave tiles: 3x3 only
+                if a == 26 and dt != 'bf16':
+                    exp = False
+                if a in (12, 19, 20, 21, 22, 23, 24, 25, 36, 37, 38, 39) and k != 1:
+                    exp = False                                               # 1x1-only tiles / ring depths
+                if a in sk:
+                    kg, r = sk[a]
+                    nch = case[1] * (4 if dt == 'f32' else 2) // 64
+                    exp = k == 1 and nch % kg == 0 and nch // kg >= r - 1   # the K chunks divide over the wave groups
+                got = conv_variant(case, dt, a) is not None
+                assert got == exp, (case, dt, a, 'expected eligible' if exp else 'expected refused')
+                n_ok += got
+    assert n_ok == 255                                                        # (the GPU run exercises exactly these)
+    # stride 2: every variant takes every test shape; streaming kernel: the wide variant (14) exists for stride 1, Cout >= 64
+    assert all(conv_variant(c, dt, a) for c in T.S2_CASES for dt in ('f32', 'bf16') for a in T.S2_ALGOS)
+    for c in T.STREAM_CASES:
+        assert conv_variant(c, 'bf16', 13) is not None and conv_variant(c, 'f32', 13) is None
+        assert (conv_variant(c, 'bf16', 14) is not None) == (c[6] == 1 and c[4] != 32), c
+    # statistics epilogue: mode 2 (data-gradient sums) only on stride-1 shapes; the count is the GPU parametrisation's size
+    n_stats = 0
+    for c in T.STATS_CASES:
+        for a in T.STATS_ALGOS:
+            for m in (1, 2):
+                ok = conv_variant(c, 'bf16', a, stats_mode=m) is not None
+                assert not (ok and m == 2 and c[6] != 1), (c, a, m)
+                n_stats += ok
+    assert n_stats == 181
