@@ -409,8 +409,7 @@ def timed_pass(net, det, x, post, steps, warmup, fence, preheat_s=0.0, telemetry
         if post == 'none':
             return outs
         if post == 'nms':
-            rows, scores = det.decode_scores(outs, mode='class')
-            kept, ks, cnt = det.nms(rows, mode='class', scores=scores)
+            rows, scores, kept, ks, cnt = det.decode_nms(outs, mode='class')
             return kept, cnt
         if post == 'top1_blocking':
             return det.predict(outs)

@@ -229,6 +229,13 @@ int yolo_nms_from_scores(const float* rows, const float* scores, int B, int nbox
 int yolo_nms(const float* rows, int B, int nbox, int C, int mode, float valid_thresh,
              float iou_thresh, int topk, int post_nms, int* kept, float* kept_scores,
              int* kept_count, void* workspace, void* stream);
+/* yolo_decode_scores + yolo_nms_from_scores as ONE call -- the post-processing of BASELINE configs[4] (608x608 inference incl.
+ * anchor decode + NMS; no counterpart in the reference): the decode pass takes the selection's first
+ * radix histogram from the scores it holds in LDS, so the score array is streamed twice instead of three times.  Identical
+ * rows, scores and kept ids to the two calls.  select_workspace: yolo_nms_select_workspace_bytes(B), REQUIRED here. */
+int yolo_decode_nms(const float* out, float* rows, float* scores, int B, int C, const yolo_grid_desc* g, int mode,
+                    float valid_thresh, float iou_thresh, int topk, int post_nms, int* kept, float* kept_scores,
+                    int* kept_count, void* select_workspace, void* stream);
 
 /* ---- training step (fp32 parity path) ------------------------------------------------------- */
 

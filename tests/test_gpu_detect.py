@@ -264,3 +264,49 @@ def test_decode_scores_fused_is_bit_identical(cuda, mode, size, B):
     b = det.nms(rows2, mode, scores=scores2)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('mode', ['obj', 'class'])
+@pytest.mark.parametrize('size,B,kw', [((416, 416), 3, {}), ((608, 608), 2, {}), ((320, 512), 5, dict(valid_thresh=0.0)),
+                                       ((160, 224), 7, dict(valid_thresh=0.3, topk=50)), ((416, 416), 2, dict(valid_thresh=0.999))])
+def test_decode_nms_one_call_equals_the_two_calls(cuda, mode, size, B, kw):
+    """yolo_decode_nms (the decode pass takes the selection's first histogram from the scores it holds in LDS) against
+    yolo_decode_scores + yolo_nms_from_scores: identical rows, scores, kept ids / scores / counts -- also where a 128-box tile
+    straddles two images (10 647 or 22 743 boxes per image are not multiples of 128), with every score valid and
+    with none -- and against the oracle's greedy NMS on the same scores."""
+    det, outs, syxhw, _ = _setup(size, B, 77, cuda, scale=2.0)
+    dev = [torch.from_numpy(o).to(cuda) for o in outs]
+    rows, scores = det.decode_scores(dev, mode)
+    a = det.nms(rows, mode, scores=scores, **kw)
+    rows2, scores2, kept, ks, cnt = det.decode_nms(dev, mode, **kw)
+    assert torch.equal(rows.view(torch.int32), rows2.view(torch.int32))
+    assert torch.equal(scores.view(torch.int32), scores2.view(torch.int32))
+    for x, y in zip(a, (kept, ks, cnt)):
+        assert torch.equal(x, y)
+    rows_h, scores_h = rows.cpu().numpy(), scores.cpu().numpy()
+    for b in range(B):
+        rk, _ = od.nms(rows_h[b], mode, scores=scores_h[b], **kw)
+        assert kept[b, :int(cnt[b])].cpu().tolist() == rk.tolist()
+    # the histogram the decode pass took IS the selection pass's: counts of valid scores by their top 11 bits, per image
+    ws = det._nms_ws[B]
+    hist = ws[:B * 2 * 2048 * 4].view(torch.int32).view(B, 2, 2048)[:, 0].cpu().numpy()
+    vt = np.float32(max(kw.get('valid_thresh', 0.01), 0.0))
+    for b in range(B):
+        u = scores_h[b].view(np.uint32)
+        ok = (u >= vt.view(np.uint32)) & (u <= 0x7f800000)
+        want = np.bincount((u[ok] >> 21).astype(np.int64), minlength=2048)
+        assert np.array_equal(hist[b], want), b
+
+
+def test_decode_nms_rejects(cuda):
+    from yolo_amd import lib as L
+    import ctypes as C
+    det, outs, _, _ = _setup((416, 416), 1, 3, cuda)
+    lib = L.load()
+    p = torch.zeros(1 << 16, device=cuda).data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    f = C.c_float
+    assert lib.yolo_decode_nms(p, p, p, 1, 30, C.byref(det.grid), 1, f(0.01), f(0.45), 400, 100, p, p, p, None, st) == -1      # no workspace
+    assert lib.yolo_decode_nms(p, p, p, 1, 30, C.byref(det.grid), 1, f(0.01), f(0.45), 600, 100, p, p, p, p, st) == -2       # top-k beyond the sort
+    assert lib.yolo_decode_nms(p, p, p, 0, 30, C.byref(det.grid), 1, f(0.01), f(0.45), 400, 100, p, p, p, p, st) == -1
+    assert lib.yolo_decode_nms(p, p, p, 1, 30, None, 1, f(0.01), f(0.45), 400, 100, p, p, p, p, st) == -1

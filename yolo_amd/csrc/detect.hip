@@ -264,14 +264,53 @@ extern "C" int yolo_nms_scores(const float* rows, float* scores, int B, int nbox
 // 24-float rows put every fourth lane on the same bank; the exponentials are kept there between the sum and the division.
 constexpr int kDecBoxes = 128;
 
-template <int NV>                                          // 16-byte loads per thread and tile: kDecBoxes * C / 4 / kDecBoxes
+// HIST (round 4, yolo_decode_nms): the first radix histogram of the NMS selection (nms_hist_kernel pass 0: valid scores by their
+// top 11 bits, per image) is taken HERE, from the scores the block holds in LDS, instead of in a pass of its own over the
+// score array.  A thread counts runs of equal bins over its box's scores, adds them to a 1024-bin block histogram (a valid
+// score's bit pattern is <= 0x7f800000: bins 0..1020) and the block flushes the non-empty bins -- two or three -- to the
+// image's global histogram once per tile; a tile that straddles two images is flushed once per image.
+constexpr int kDecHistBins = 1024;
+
+template <int NV, int HIST>                                // NV: 16-byte loads per thread and tile: kDecBoxes * C / 4 / kDecBoxes
 __global__ __launch_bounds__(kDecBoxes) void decode_scores_kernel(const float* __restrict__ out, float* __restrict__ rows,
                                                                   float* __restrict__ scores, int C, int ncls, int mode,
-                                                                  int nbox, long long nboxes, GridDev g) {
+                                                                  int nbox, long long nboxes, GridDev g, unsigned vbits,
+                                                                  unsigned* __restrict__ ghist) {
     extern __shared__ float4 sm4[];                      // kDecBoxes rows of C floats, then the score rows of SP floats
     float* sm = reinterpret_cast<float*>(sm4);
     float* so = sm + ((kDecBoxes * C + 3) & ~3);
     const int per = mode == 1 ? ncls : 1, SP = per | 1;
+    unsigned* lh = reinterpret_cast<unsigned*>(so + kDecBoxes * SP);         // HIST: the block's histogram
+    if (HIST) {
+        for (int i = threadIdx.x; i < kDecHistBins; i += kDecBoxes) lh[i] = 0;
+        __syncthreads();
+    }
+    // HIST: this thread's runs of equal bins over its box's scores -> the block histogram
+    auto hist_add = [&](const float* e) {
+        unsigned cur = 0xffffffffu, run = 0;
+        for (int c = 0; c < per; ++c) {
+            const unsigned u = __float_as_uint(e[c]);
+            if (u >= vbits && u <= 0x7f800000u) {
+                const unsigned bin = u >> 21;
+                if (bin != cur) {
+                    if (run) atomicAdd(&lh[cur], run);
+                    cur = bin;
+                    run = 0;
+                }
+                ++run;
+            }
+        }
+        if (run) atomicAdd(&lh[cur], run);
+    };
+    auto hist_flush = [&](int img) {
+        unsigned* gh = ghist + (long long)img * 2 * 2048;                  // (pass 0 section of the image's two histograms)
+#pragma unroll
+        for (int q = 0; q < kDecHistBins / kDecBoxes; ++q) {
+            const int bin = threadIdx.x + q * kDecBoxes;
+            const unsigned v = lh[bin];
+            if (v) { atomicAdd(&gh[bin], v); lh[bin] = 0; }
+        }
+    };
     const long long ntiles = (nboxes + kDecBoxes - 1) / kDecBoxes;
     float4 v[NV];
     float vt = 0.f;                                        // (tile floats % 4: only a last, ragged tile has them)
@@ -342,8 +381,19 @@ __global__ __launch_bounds__(kDecBoxes) void decode_scores_kernel(const float* _
             } else {
                 so[threadIdx.x * SP] = obj;
             }
+            if (HIST && (int)((k0 + threadIdx.x) / nbox) == (int)(k0 / nbox)) hist_add(so + threadIdx.x * SP);
         }
         __syncthreads();
+        if (HIST) {
+            const int b_first = (int)(k0 / nbox), b_last = (int)((k0 + nb - 1) / nbox);
+            hist_flush(b_first);
+            for (int img = b_first + 1; img <= b_last; ++img) {      // (a tile that straddles images: rare, block-uniform)
+                __syncthreads();
+                if ((int)threadIdx.x < nb && (int)((k0 + threadIdx.x) / nbox) == img) hist_add(so + threadIdx.x * SP);
+                __syncthreads();
+                hist_flush(img);
+            }
+        }
         {
             float4* dst = reinterpret_cast<float4*>(rows + k0 * C);
             for (int i = threadIdx.x; i < n4; i += kDecBoxes) dst[i] = sm4[i];
@@ -363,8 +413,9 @@ __global__ __launch_bounds__(kDecBoxes) void decode_scores_kernel(const float* _
 
 constexpr int kMaxDev = 64;
 
-extern "C" int yolo_decode_scores(const float* out, float* rows, float* scores, int B, int C, const yolo_grid_desc* g,
-                                  int mode, void* stream) {
+// ghist != nullptr: also take the NMS selection's first histogram (decode_scores_kernel<.., HIST = 1>)
+static int launch_decode_scores(const float* out, float* rows, float* scores, int B, int C, const yolo_grid_desc* g, int mode,
+                                hipStream_t st, unsigned vbits, unsigned* ghist) {
     if (!out || !rows || !scores || B <= 0 || C < 6 || (mode != 0 && mode != 1)) return YOLO_EINVAL;
     if (mode == 1 && C <= 6) return YOLO_EINVAL;
     if (C > 96) return YOLO_EUNSUPPORTED;                      // LDS staging: kDecBoxes boxes x (C + ncls) floats
@@ -373,7 +424,8 @@ extern "C" int yolo_decode_scores(const float* out, float* rows, float* scores, 
     if (rc) return rc;
     const long long nboxes = (long long)B * nbox;
     if ((C * kDecBoxes) % 4) return YOLO_EUNSUPPORTED;         // 16-byte copies: a tile's rows start on a 16-byte boundary
-    const size_t lds = (size_t)(((kDecBoxes * C + 3) & ~3) + kDecBoxes * ((mode == 1 ? C - 6 : 1) | 1)) * sizeof(float);
+    const size_t lds = (size_t)(((kDecBoxes * C + 3) & ~3) + kDecBoxes * ((mode == 1 ? C - 6 : 1) | 1)) * sizeof(float) +
+                       (ghist ? kDecHistBins * sizeof(unsigned) : 0);
     // per-DEVICE launch state (a process may switch the current device; hipFuncSetAttribute applies to the current one only):
     // CU count and "opted in to > 64 KiB of dynamic LDS", indexed by device id; relaxed atomics -- two host threads racing
     // here both write the same values
@@ -392,20 +444,26 @@ extern "C" int yolo_decode_scores(const float* out, float* rows, float* scores, 
     const long long ntiles = (nboxes + kDecBoxes - 1) / kDecBoxes;
     const dim3 grid((unsigned)(ntiles < cus * per_cu ? ntiles : cus * per_cu));
     if (lds > 65536 && !opted_of[dev].load(std::memory_order_relaxed)) {     // (C + classes > 128: more than 64 KiB, once per device)
-        if (hipFuncSetAttribute((const void*)decode_scores_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)decode_scores_kernel<24, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)decode_scores_kernel<24, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             (void)hipGetLastError();
             return YOLO_EUNSUPPORTED;                          // (a negative status like every other refusal, not a raw hipError_t)
         }
         opted_of[dev].store(1, std::memory_order_relaxed);
     }
-    if (C <= 32)
-        YOLO_LAUNCH(decode_scores_kernel<8>, grid, dim3(kDecBoxes), lds, (hipStream_t)stream, out, rows, scores, C,
-                    C - 6, mode, nbox, nboxes, d);
-    else
-        YOLO_LAUNCH(decode_scores_kernel<24>, grid, dim3(kDecBoxes), lds, (hipStream_t)stream, out, rows, scores, C,
-                C - 6, mode, nbox, nboxes, d);
+#define YOLO_DEC_LAUNCH(NV, H)                                                                                          \
+    YOLO_LAUNCH((decode_scores_kernel<NV, H>), grid, dim3(kDecBoxes), lds, st, out, rows, scores, C, C - 6, mode, nbox, \
+                nboxes, d, vbits, ghist)
+    if (C <= 32) { if (ghist) YOLO_DEC_LAUNCH(8, 1); else YOLO_DEC_LAUNCH(8, 0); }
+    else { if (ghist) YOLO_DEC_LAUNCH(24, 1); else YOLO_DEC_LAUNCH(24, 0); }
+#undef YOLO_DEC_LAUNCH
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
+}
+
+extern "C" int yolo_decode_scores(const float* out, float* rows, float* scores, int B, int C, const yolo_grid_desc* g,
+                                  int mode, void* stream) {
+    return launch_decode_scores(out, rows, scores, B, C, g, mode, (hipStream_t)stream, 0u, nullptr);
 }
 
 // ---- NMS ---------------------------------------------------------------------------------------
@@ -764,16 +822,15 @@ extern "C" long long yolo_nms_workspace_bytes(int B, int nbox, int ncls, int mod
     return ((long long)B * nbox * (mode == 1 ? ncls : 1) * 4 + 15) / 16 * 16 + yolo_nms_select_workspace_bytes(B);
 }
 
-extern "C" int yolo_nms_from_scores(const float* rows, const float* scores, int B, int nbox, int C,
-                                    int cand_per_box, float valid_thresh, float iou_thresh, int topk, int post_nms,
-                                    int* kept, float* kept_scores, int* kept_count, void* select_workspace,
-                                    void* stream) {
+// hist0_taken: the selection workspace was zeroed and its pass-0 histograms filled by the caller (yolo_decode_nms)
+static int nms_from_scores_impl(const float* rows, const float* scores, int B, int nbox, int C, int cand_per_box,
+                                float valid_thresh, float iou_thresh, int topk, int post_nms, int* kept, float* kept_scores,
+                                int* kept_count, void* select_workspace, hipStream_t st, bool hist0_taken) {
     if (!rows || !scores || !kept || !kept_scores || !kept_count) return YOLO_EINVAL;
     if (B <= 0 || nbox <= 0 || C < 5 || cand_per_box < 1 || post_nms < 1) return YOLO_EINVAL;
     if (topk < 1 || topk > NMS_MAXK) return YOLO_EUNSUPPORTED;
     const long long ncand = (long long)nbox * cand_per_box;
     if (ncand > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
     const unsigned long long* list = nullptr;
     unsigned* sel = nullptr;
     if (select_workspace) {
@@ -781,7 +838,7 @@ extern "C" int yolo_nms_from_scores(const float* rows, const float* scores, int 
         sel = hist + (long long)B * 2 * 2048;
         list = (const unsigned long long*)(sel + (long long)B * 16);
         (void)hipGetLastError();
-        (void)hipMemsetAsync(select_workspace, 0, (size_t)B * (2 * 2048 + 16) * 4, st);
+        if (!hist0_taken) (void)hipMemsetAsync(select_workspace, 0, (size_t)B * (2 * 2048 + 16) * 4, st);
         float vt = valid_thresh > 0.f ? valid_thresh : 0.f;
         unsigned vbits;
         memcpy(&vbits, &vt, 4);
@@ -791,7 +848,8 @@ extern "C" int yolo_nms_from_scores(const float* rows, const float* scores, int 
         long long per = (ncand + G - 1) / G;
         per = (per + 255) / 256 * 256;
         G = (int)((ncand + per - 1) / per);
-        YOLO_LAUNCH(nms_hist_kernel, dim3(G, B), dim3(256), 0, st, scores, ncand, vbits, 0, hist, (const unsigned*)sel, per);
+        if (!hist0_taken)
+            YOLO_LAUNCH(nms_hist_kernel, dim3(G, B), dim3(256), 0, st, scores, ncand, vbits, 0, hist, (const unsigned*)sel, per);
         YOLO_LAUNCH(nms_pick_kernel, dim3(B), dim3(64), 0, st, (const unsigned*)hist, sel, 0, topk);
         YOLO_LAUNCH(nms_hist_kernel, dim3(G, B), dim3(256), 0, st, scores, ncand, vbits, 1, hist, (const unsigned*)sel, per);
         YOLO_LAUNCH(nms_pick_kernel, dim3(B), dim3(64), 0, st, (const unsigned*)hist, sel, 1, topk);
@@ -802,6 +860,39 @@ extern "C" int yolo_nms_from_scores(const float* rows, const float* scores, int 
                 iou_thresh, topk, post_nms, kept, kept_scores, kept_count, list, (const unsigned*)sel);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
+}
+
+extern "C" int yolo_nms_from_scores(const float* rows, const float* scores, int B, int nbox, int C,
+                                    int cand_per_box, float valid_thresh, float iou_thresh, int topk, int post_nms,
+                                    int* kept, float* kept_scores, int* kept_count, void* select_workspace,
+                                    void* stream) {
+    return nms_from_scores_impl(rows, scores, B, nbox, C, cand_per_box, valid_thresh, iou_thresh, topk, post_nms, kept,
+                                kept_scores, kept_count, select_workspace, (hipStream_t)stream, false);
+}
+
+// yolo_decode_scores + yolo_nms_from_scores as ONE entry (BASELINE configs[4]'s post-processing): the decode pass takes the
+// selection's first histogram from the scores it holds in LDS, so the score array is streamed twice (second histogram,
+// collect) instead of three times.  Same rows, scores and kept ids as the two calls (tests/test_gpu_detect.py).
+// select_workspace: yolo_nms_select_workspace_bytes(B), required here.
+extern "C" int yolo_decode_nms(const float* out, float* rows, float* scores, int B, int C, const yolo_grid_desc* g, int mode,
+                               float valid_thresh, float iou_thresh, int topk, int post_nms, int* kept, float* kept_scores,
+                               int* kept_count, void* select_workspace, void* stream) {
+    if (!select_workspace || !kept || !kept_scores || !kept_count || !g) return YOLO_EINVAL;
+    if (B <= 0 || C < 6 || post_nms < 1 || (mode != 0 && mode != 1)) return YOLO_EINVAL;
+    if (topk < 1 || topk > NMS_MAXK) return YOLO_EUNSUPPORTED;
+    GridDev d; int nbox;
+    int rc = make_grid(g, d, &nbox);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipGetLastError();
+    (void)hipMemsetAsync(select_workspace, 0, (size_t)B * (2 * 2048 + 16) * 4, st);
+    float vt = valid_thresh > 0.f ? valid_thresh : 0.f;
+    unsigned vbits;
+    memcpy(&vbits, &vt, 4);
+    rc = launch_decode_scores(out, rows, scores, B, C, g, mode, st, vbits, (unsigned*)select_workspace);
+    if (rc) return rc;
+    return nms_from_scores_impl(rows, scores, B, nbox, C, mode == 1 ? C - 6 : 1, valid_thresh, iou_thresh, topk, post_nms, kept,
+                                kept_scores, kept_count, select_workspace, st, true);
 }
 
 extern "C" int yolo_nms(const float* rows, int B, int nbox, int C, int mode, float valid_thresh, float iou_thresh,

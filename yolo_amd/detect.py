@@ -85,6 +85,25 @@ class Detector(object):
                                              L.stream_ptr()), 'decode_scores')
         return rows, scores
 
+    def decode_nms(self, outs, mode='class', valid_thresh=0.01, iou_thresh=0.45, topk=400, post_nms=100):
+        """decode_scores() + nms() as one library call (yolo_decode_nms): the decode pass also takes the selection's first
+        histogram.  -> (rows, scores, kept ids, kept scores, kept count); identical to the two calls."""
+        m = self._merged(outs)
+        B = m.shape[0]
+        md = 1 if mode == 'class' else 0
+        rows = torch.empty((B, self.nbox, self.C), dtype=torch.float32, device=m.device)
+        scores = torch.empty((B, self.nbox * ((self.C - 6) if md else 1)), dtype=torch.float32, device=m.device)
+        ws = self._nms_ws.get(B)
+        if ws is None:
+            ws = self._nms_ws[B] = torch.empty(self._lib.yolo_nms_select_workspace_bytes(B), dtype=torch.uint8, device=m.device)
+        kept = torch.empty((B, post_nms), dtype=torch.int32, device=m.device)
+        ks = torch.empty((B, post_nms), dtype=torch.float32, device=m.device)
+        cnt = torch.empty((B,), dtype=torch.int32, device=m.device)
+        L.check(self._lib.yolo_decode_nms(L.ptr(m), L.ptr(rows), L.ptr(scores), B, self.C, C.byref(self.grid), md, valid_thresh,
+                                          iou_thresh, topk, post_nms, L.ptr(kept), L.ptr(ks), L.ptr(cnt), L.ptr(ws),
+                                          L.stream_ptr()), 'decode_nms')
+        return rows, scores, kept, ks, cnt
+
     def predict_device(self, outs):
         m = self._merged(outs)
         B = m.shape[0]

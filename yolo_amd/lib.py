@@ -70,6 +70,7 @@ SIGNATURES = {
     'yolo_nms_scores': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'yolo_nms_select_workspace_bytes': (_ll, [_i]),
     'yolo_nms_from_scores': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'yolo_decode_nms': (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(GridDesc), _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'yolo_nms': (_i, [_vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'yolo_pack_conv_weights_dgrad': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'yolo_pack_conv_weights_dgrad_s2': (_i, [_vp, _vp, _i, _i, _i, _vp]),
