@@ -50,12 +50,18 @@ class Telemetry(object):
         import glob
         self.period, self.index = period, index
         self.freq_file = self.power_file = None
-        cards = sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*'))
-        if index < len(cards):
-            hw = cards[index]
-            for name in ('freq1_input',):
-                if os.path.exists(os.path.join(hw, name)):
-                    self.freq_file = os.path.join(hw, name)
+        # the hwmon directory of THIS device: by its PCI address (a box lists more DRM cards than the GPUs a job may see)
+        hw = None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            bdf = '%04x:%02x:%02x.0' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            found = sorted(glob.glob('/sys/bus/pci/devices/%s/hwmon/hwmon*' % bdf))
+            hw = found[0] if found else None
+        except Exception:
+            hw = None
+        if hw is not None:
+            if os.path.exists(os.path.join(hw, 'freq1_input')):
+                self.freq_file = os.path.join(hw, 'freq1_input')
             for name in ('power1_average', 'power1_input'):
                 if os.path.exists(os.path.join(hw, name)):
                     self.power_file = os.path.join(hw, name)
@@ -409,6 +415,10 @@ def timed_pass(net, det, x, post, steps, warmup, fence, preheat_s=0.0, telemetry
         if post == 'none':
             return outs
         if post == 'nms':
+            if os.environ.get('YOLO_BENCH_NMS_TWO_CALLS'):          # (A/B knob: yolo_decode_scores + yolo_nms_from_scores)
+                rows, scores = det.decode_scores(outs, mode='class')
+                kept, ks, cnt = det.nms(rows, mode='class', scores=scores)
+                return kept, cnt
             rows, scores, kept, ks, cnt = det.decode_nms(outs, mode='class')
             return kept, cnt
         if post == 'top1_blocking':

@@ -144,8 +144,11 @@ def loss_and_grad_wrt_output(merged_out, labels, spec, size, scale=DEFAULT_SCALE
 def adam_step(w, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, rescale=1.0):
     """mxnet Adam.  t is the 1-based update count.  In-place on numpy fp32 arrays."""
     g = (g * f32(rescale)).astype(f32)
-    m[...] = f32(beta1) * m + f32(1 - beta1) * g
-    v[...] = f32(beta2) * v + f32(1 - beta2) * g * g
+    # (1 - beta) is taken in fp32 FROM the fp32 beta, as MXNet's adam_update kernel does (`scalar<DType>(1.f - param.beta1)`
+    # [recalled: src/operator/optimizer_op-inl.h]): 1.f - 0.999f = 0.00099998713, not float(0.001) -- a 1.3e-5 relative
+    # difference in v that the K-step trajectory test (tests/test_gpu_trajectory.py) is tight enough to see
+    m[...] = f32(beta1) * m + (f32(1) - f32(beta1)) * g
+    v[...] = f32(beta2) * v + (f32(1) - f32(beta2)) * g * g
     lr_t = f32(lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t))
     w[...] = w - lr_t * m / (np.sqrt(v) + f32(eps))
     return w, m, v

@@ -266,10 +266,11 @@ constexpr int kDecBoxes = 128;
 
 // HIST (round 4, yolo_decode_nms): the first radix histogram of the NMS selection (nms_hist_kernel pass 0: valid scores by their
 // top 11 bits, per image) is taken HERE, from the scores the block holds in LDS, instead of in a pass of its own over the
-// score array.  A thread counts runs of equal bins over its box's scores, adds them to a 1024-bin block histogram (a valid
-// score's bit pattern is <= 0x7f800000: bins 0..1020) and the block flushes the non-empty bins -- two or three -- to the
-// image's global histogram once per tile; a tile that straddles two images is flushed once per image.
-constexpr int kDecHistBins = 1024;
+// score array.  A thread counts runs of equal bins over its box's scores, adds them to a 1024-bin block histogram (2 KiB: one
+// more KiB and a CU holds four of these blocks instead of five) and the block flushes the non-empty bins -- two or three -- to the
+// image's global histogram once per tile; a tile that straddles two images is flushed once per image.  512 bins: the scores
+// made here are sigmoid x softmax <= 1.0 = bin 508 (a larger value -- impossible -- would go straight to the global histogram).
+constexpr int kDecHistBins = 512;
 
 template <int NV, int HIST>                                // NV: 16-byte loads per thread and tile: kDecBoxes * C / 4 / kDecBoxes
 __global__ __launch_bounds__(kDecBoxes) void decode_scores_kernel(const float* __restrict__ out, float* __restrict__ rows,
@@ -286,12 +287,14 @@ __global__ __launch_bounds__(kDecBoxes) void decode_scores_kernel(const float* _
         __syncthreads();
     }
     // HIST: this thread's runs of equal bins over its box's scores -> the block histogram
+    long long k0h = 0;                                     // (first box of the tile in flight, for hist_add's slow path)
     auto hist_add = [&](const float* e) {
         unsigned cur = 0xffffffffu, run = 0;
         for (int c = 0; c < per; ++c) {
             const unsigned u = __float_as_uint(e[c]);
             if (u >= vbits && u <= 0x7f800000u) {
                 const unsigned bin = u >> 21;
+                if (bin >= kDecHistBins) { atomicAdd(&ghist[(long long)((k0h + threadIdx.x) / nbox) * 2 * 2048 + bin], 1u); continue; }
                 if (bin != cur) {
                     if (run) atomicAdd(&lh[cur], run);
                     cur = bin;
@@ -329,6 +332,7 @@ __global__ __launch_bounds__(kDecBoxes) void decode_scores_kernel(const float* _
     if (tile < ntiles) fetch(tile);
     for (; tile < ntiles; tile += gridDim.x) {
         const long long k0 = tile * kDecBoxes;
+        k0h = k0;
         const int nb = (int)min((long long)kDecBoxes, nboxes - k0), n = nb * C, n4 = n >> 2;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
