@@ -33,6 +33,7 @@ struct ConvArgs {
     int halo_strict;        // conv_pipe.hip launch_pipe: leave one slot of the staged halo unused (the 2x2-window 4-wave tile)
     int tile_px;            // conv_igemm.hip: strip pixels a tile covers (= its 128 unless the shape needs row-limited tiles); 0 elsewhere
     int nchunks, tiles_c;
+    int vblocks;            // conv_pipe.hip: number of (pixel tile, cout tile) units = the grid size unless the blocks are persistent
     int out_f32;
     int x_ps;       // elements between input pixels (>= Cin: x may be a channel slice of a wider NHWC buffer)
     int up2;        // 1: every output pixel is stored to its 2x2 patch of the (N,2Ho,2Wo) map (nearest 2x up-sampling)
