@@ -151,16 +151,20 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     __shared__ __attribute__((aligned(16))) char smem[PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)smem;
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wave_p = wave % WAVES_P, wave_c = wave / WAVES_P;
-
     STAMP(0); STAMP_ID();
     // a.vblocks tiles over gridDim.x blocks: a resident grid walks them (launch_pipe: one round of blocks, persistent), or one
     // block per tile when the launch has no more tiles than that
     for (int vb = blockIdx.x; vb < a.vblocks; vb += gridDim.x) {
+    // The per-thread constants are derived from a LAUNDERED thread id inside the tile loop: as loop invariants the compiler
+    // hoists them -- and every address built from them -- out of the loop and keeps them in registers across the K loop
+    // (+40-50 VGPRs: the 4-wave 192 x 128 tile lost its second wave per SIMD, the 8-wave 256 x 256 tile spilled: -10 % on the
+    // whole pass, measured).
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wave_p = wave % WAVES_P, wave_c = wave / WAVES_P;
     const int lid = xcd_remap(vb, a.vblocks);
     const int tile_p = fdiv(lid, a.d_tc);
     const int tile_c = lid - tile_p * a.tiles_c;
