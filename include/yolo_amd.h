@@ -104,6 +104,23 @@ typedef struct yolo_conv_desc {
     const float* stats_gamma;
     const float* stats_beta;
     float stats_slope;
+    /* A 1x1 convolution fused BEHIND this one (the "tail"): tail_y = act(conv1x1(y)) -- the next DarknetBasicBlockV3's first
+     * _conv2d (basic_yolo.py:26), a YOLODetectionBlockV3's 1x1 after its 3x3 (basic_yolo.py:118), or YOLOOutput after the tip
+     * (basic_yolo.py:98-105, tail_out_f32 = 1) -- computed by the same kernel from the output tile it has just stored: no second
+     * launch, no HBM read of y; y is still written.  tail_w_packed: yolo_pack_conv_weights image of the (tail_cout, Cout, 1, 1)
+     * weights; tail_scale / tail_bias padded like scale / bias; tail_y (N,Ho,Wo,tail_cout) dtype or float32; strides as for y.
+     * Bit-identical to the separate 1x1 launch.  Needs: bf16, ksize 3, Cout <= 256 and a multiple of 32, tail_cout <= 128, no
+     * out_f32 / upsample2x / stats on this convolution, and a pipelined variant with 256-cout tiles (algo 2, 6; stride 2: 10, 16,
+     * 18; algo 0 picks one) -- YOLO_EUNSUPPORTED otherwise (run the two launches). */
+    const void* tail_w_packed;
+    const float* tail_scale;
+    const float* tail_bias;
+    void* tail_y;
+    int tail_cout;
+    int tail_out_f32;
+    float tail_slope;
+    long long tail_y_batch_stride;
+    long long tail_y_pixel_stride;
 } yolo_conv_desc;
 
 int yolo_conv_fwd(const yolo_conv_desc* d, void* stream);

@@ -545,3 +545,122 @@ def test_stem_statistics(lib, cuda, shape):
     np.testing.assert_allclose(m1.cpu().numpy(), m2.cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(i1.cpu().numpy(), i2.cpu().numpy(), rtol=1e-5)
     assert float((z1.float() - z2.float()).abs().max()) <= 1e-2 * float(z2.float().abs().max())
+
+
+# ---- fused tail 1x1 (yolo_conv_desc.tail_*): a 3x3 convolution + the 1x1 that follows it in ONE kernel ---------------------
+TAIL_CASES = [
+    # (N, Cin, H, W, Cout, stride, residual, tail_cout, tail_f32, strided y)
+    (2, 128, 26, 26, 256, 1, True, 128, False, False),      # a stage-2 residual block's 3x3 + the next block's 1x1
+    (3, 128, 19, 31, 256, 1, False, 128, False, True),      # main output into a channel slice of a wider buffer
+    (2, 64, 40, 24, 128, 1, True, 64, False, False),        # Cout < 256: the tile's upper couts are padding
+    (5, 128, 13, 13, 256, 1, False, 90, True, False),       # tip + YOLOOutput: fp32 logits, Cout 90, strided rows
+    (2, 128, 52, 52, 256, 2, False, 128, False, False),     # the stage's down-sampling conv + the first block's 1x1
+    (1, 256, 9, 70, 224, 1, True, 96, False, False),        # ragged counts: 224 = 7 chunks, 96 couts
+    (33, 128, 8, 8, 256, 1, True, 128, False, False),       # tiles that cross image boundaries
+]
+
+
+@pytest.mark.parametrize('case,algo', [(c, a) for c in TAIL_CASES for a in [0] + ([10, 16, 18] if c[5] == 2 else [2, 6])])
+def test_conv_tail_1x1_fused_is_bit_identical(lib, cuda, case, algo):
+    """yolo_conv_desc.tail_*: the 1x1 convolution behind a 3x3 one computed by the same kernel from the output tile it has just
+    stored.  Against the two separate launches on the same buffers: the main output and the tail output must be bit-identical
+    (same operands -- the stored bf16 outputs --, same K order), and the tail against torch on the rounded operands."""
+    import ctypes as C
+    from util import LDT, TDT
+    N, Cin, H, W, Cout, stride, with_res, tcout, tf32, strided = case
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)
+    w1 = (rng.standard_normal((tcout, Cout, 1, 1)) / np.sqrt(Cout)).astype(np.float32)
+    st = torch.cuda.current_stream().cuda_stream
+    dt = L.BF16
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    xd = to_nhwc(x, 'bf16', cuda)
+    r = rng.standard_normal((N, Cout, Ho, Wo)).astype(np.float32) if with_res else None
+    rd = to_nhwc(r, 'bf16', cuda) if with_res else None
+
+    def packed(wt, co, ci, k):
+        wp = torch.empty(lib.yolo_packed_weight_bytes(co, ci, k, dt), dtype=torch.uint8, device=cuda)
+        L.check(lib.yolo_pack_conv_weights(torch.from_numpy(wt).to(cuda).data_ptr(), wp.data_ptr(), co, ci, k, dt, st), 'pack')
+        return wp
+
+    def sb(co, seed):
+        g = np.random.default_rng(seed)
+        cp = lib.yolo_padded_channels(co)
+        s_, b_ = torch.zeros(cp, device=cuda), torch.zeros(cp, device=cuda)
+        s_[:co] = torch.from_numpy(g.uniform(.5, 1.5, co).astype(np.float32)).to(cuda)
+        b_[:co] = torch.from_numpy((0.1 * g.standard_normal(co)).astype(np.float32)).to(cuda)
+        return s_, b_
+
+    wp, wp1 = packed(w, Cout, Cin, 3), packed(w1, tcout, Cout, 1)
+    (sc, bi), (sc1, bi1) = sb(Cout, 1), sb(tcout, 2)
+    ych = Cout + 64 if strided else Cout                      # (strided: y is the upper channel slice of a wider buffer)
+    outs = []
+    for fused in (False, True):
+        ybuf = torch.full((N, Ho, Wo, ych), float('nan'), dtype=torch.bfloat16, device=cuda)
+        y = ybuf[..., ych - Cout:]
+        tpitch = tcout + 6 if tf32 else tcout                 # (fp32 logits: rows of a wider merged buffer)
+        z = torch.full((N, Ho, Wo, tpitch), float('nan'), dtype=torch.float32 if tf32 else torch.bfloat16, device=cuda)
+        d = L.ConvDesc()
+        d.x, d.w_packed, d.scale, d.bias, d.y = xd.data_ptr(), wp.data_ptr(), sc.data_ptr(), bi.data_ptr(), y.data_ptr()
+        d.residual = rd.data_ptr() if with_res else None
+        d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.dtype, d.slope, d.algo = N, H, W, Cin, Cout, 3, stride, dt, 0.1, algo
+        d.y_pixel_stride, d.y_batch_stride = ych, Ho * Wo * ych
+        if fused:
+            d.tail_w_packed, d.tail_scale, d.tail_bias, d.tail_y = wp1.data_ptr(), sc1.data_ptr(), bi1.data_ptr(), z.data_ptr()
+            d.tail_cout, d.tail_out_f32, d.tail_slope = tcout, int(tf32), (1.0 if tf32 else 0.1)
+            d.tail_y_pixel_stride, d.tail_y_batch_stride = tpitch, Ho * Wo * tpitch
+            assert lib.yolo_conv_fwd(C.byref(d), st) == 0
+        else:
+            # the same tile variant as the fused call (kernel families differ in their K order, i.e. in the last bit)
+            for cand in ([algo] if algo else ([18, 16, 10] if stride == 2 else [6, 2])):
+                d.algo = cand
+                if lib.yolo_conv_fwd(C.byref(d), st) == 0:
+                    break
+            else:
+                raise AssertionError('no 256-cout variant takes the plain convolution')
+            d1 = L.ConvDesc()
+            d1.x, d1.w_packed, d1.scale, d1.bias, d1.y = y.data_ptr(), wp1.data_ptr(), sc1.data_ptr(), bi1.data_ptr(), z.data_ptr()
+            d1.N, d1.H, d1.W, d1.Cin, d1.Cout, d1.ksize, d1.stride, d1.dtype = N, Ho, Wo, Cout, tcout, 1, 1, dt
+            d1.out_f32, d1.slope = int(tf32), (1.0 if tf32 else 0.1)
+            d1.x_pixel_stride = ych
+            d1.y_pixel_stride, d1.y_batch_stride = tpitch, Ho * Wo * tpitch
+            assert lib.yolo_conv_fwd(C.byref(d1), st) == 0
+        torch.cuda.synchronize()
+        outs.append((y.contiguous().clone(), z[..., :tcout].contiguous().clone()))
+    (y0, z0), (y1, z1) = outs
+    assert not torch.isnan(y1.float()).any() and not torch.isnan(z1.float()).any()
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))                     # the main output is unchanged ...
+    it = torch.int32 if tf32 else torch.int16
+    assert torch.equal(z0.view(it), z1.view(it))                                       # ... and the tail is the separate launch's, bit for bit
+    # the tail against torch on the rounded operands
+    yin = y1.float().permute(0, 3, 1, 2).cpu()
+    ref = torch.nn.functional.conv2d(yin, torch.from_numpy(w1).to(torch.bfloat16).float())
+    ref = ref * sc1[:tcout].cpu().view(1, -1, 1, 1) + bi1[:tcout].cpu().view(1, -1, 1, 1)
+    if not tf32:
+        ref = torch.where(ref > 0, ref, ref * 0.1).to(torch.bfloat16).float()
+    got = z1.float().permute(0, 3, 1, 2).cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1.6e-2, atol=2e-2)
+
+
+def test_conv_tail_rejects(lib, cuda):
+    import ctypes as C
+    p = torch.zeros(1 << 16, device=cuda).data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def desc(**kw):
+        d = L.ConvDesc()
+        d.x = d.w_packed = d.y = d.tail_w_packed = d.tail_y = p
+        d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.dtype, d.slope = 1, 8, 8, 64, 256, 3, 1, L.BF16, 0.1
+        d.tail_cout, d.tail_slope = 128, 0.1
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+    assert lib.yolo_conv_fwd(C.byref(desc(Cout=512)), st) == -2               # two cout tiles: no block holds a pixel's channels
+    assert lib.yolo_conv_fwd(C.byref(desc(tail_cout=256)), st) == -2
+    assert lib.yolo_conv_fwd(C.byref(desc(ksize=1)), st) == -2
+    assert lib.yolo_conv_fwd(C.byref(desc(dtype=L.F32)), st) == -2
+    assert lib.yolo_conv_fwd(C.byref(desc(algo=8)), st) == -2                 # a 128-cout tile variant
+    assert lib.yolo_conv_fwd(C.byref(desc(tail_y=None)), st) == -1
+    assert lib.yolo_conv_fwd(C.byref(desc(tail_slope=2.0)), st) == -1
+    assert lib.yolo_conv_fwd(C.byref(desc(upsample2x=1)), st) == -2

@@ -49,6 +49,14 @@ struct ConvArgs {
     const char* s_y;        // mode 2: that layer's raw convolution output (same shape as the output here), dense
     const float* s_mean; const float* s_invstd; const float* s_gamma; const float* s_beta;
     float s_slope;
+    // A 1x1 convolution fused BEHIND this one (yolo_conv_desc.tail_*; conv_pipe.hip, kernel flag 3): computed by the same block
+    // from the output tile it has just stored.  t_wp == nullptr: none.
+    const char* t_wp;       // packed 1x1 weights (Cin = this conv's Cout)
+    const float* t_scale; const float* t_bias;
+    char* t_y;
+    int t_cout, t_out_f32;
+    float t_slope;
+    long long t_y_bs, t_y_ps;
 };
 
 static inline void conv_args_fastdiv(ConvArgs& a) {

@@ -427,6 +427,25 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     a.stats = (float*)d->stats; a.stats_mode = d->stats_mode;
     a.s_y = (const char*)d->stats_y; a.s_mean = d->stats_mean; a.s_invstd = d->stats_invstd;
     a.s_gamma = d->stats_gamma; a.s_beta = d->stats_beta; a.s_slope = d->stats_slope;
+    a.t_wp = (const char*)d->tail_w_packed; a.t_scale = d->tail_scale; a.t_bias = d->tail_bias; a.t_y = (char*)d->tail_y;
+    a.t_cout = d->tail_cout; a.t_out_f32 = d->tail_out_f32; a.t_slope = d->tail_slope;
+    a.t_y_ps = d->tail_y_pixel_stride ? d->tail_y_pixel_stride : d->tail_cout;
+    a.t_y_bs = d->tail_y_batch_stride ? d->tail_y_batch_stride : (long long)a.Ho * a.Wo * a.t_y_ps;
+    if (a.t_wp) {
+        // fused tail 1x1: pipelined 3x3 variants with 256-cout tiles only (conv_pipe.hip)
+        if (!d->tail_y || (!d->tail_scale != !d->tail_bias) || d->tail_cout <= 0 || !(d->tail_slope >= 0.f && d->tail_slope <= 1.f)) return YOLO_EINVAL;
+        if (a.stats || d->dtype != YOLO_BF16 || d->ksize != 3) return YOLO_EUNSUPPORTED;
+        if (!d->tail_out_f32 && (d->tail_cout % 4)) return YOLO_EUNSUPPORTED;
+        if (d->algo) return conv_pipe_dispatch(a, d->ksize, d->stride, d->dtype, d->algo, st, nm);
+        static const int s1[] = {6, 2}, s2[] = {18, 16, 10};
+        const int* cand = d->stride == 2 ? s2 : s1;
+        for (int k = 0; k < (d->stride == 2 ? 3 : 2); ++k) {
+            ConvArgs b = a;
+            const int rc = conv_pipe_dispatch(b, d->ksize, d->stride, d->dtype, cand[k], st, nm);
+            if (rc != YOLO_EUNSUPPORTED) return rc;
+        }
+        return YOLO_EUNSUPPORTED;
+    }
     if (a.stats) {
         // BatchNorm statistics in the epilogue: the pipelined kernels only (yolo_conv_stats_rows tells the caller beforehand)
         if (a.stats_mode != 1 && a.stats_mode != 2) return YOLO_EINVAL;
@@ -493,6 +512,7 @@ extern "C" int yolo_conv_dgrad_s2(const yolo_conv_desc* d, void* stream) {
     a.out_f32 = 0; a.d2s = 1; a.up2 = 0; a.x_ps = d->Cin; a.slope = d->slope;
     a.halo_strict = 0;
     a.stats = nullptr; a.stats_mode = 0;
+    a.t_wp = nullptr;
     if (d->x_pixel_stride || d->upsample2x || d->stats) return YOLO_EUNSUPPORTED;
     a.y_ps = d->Cout / 4;
     a.y_bs = (long long)a.Ho * a.Wo * d->Cout;

@@ -557,9 +557,102 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     }
     STAMP(3);
     // (STATS: one partial row of BatchNorm sums per (pixel tile, pixel wave))
-    float* srow = STATS ? a.stats + ((size_t)tile_p * WAVES_P + wave_p) * 2 * a.Cout_pad : nullptr;
-    conv_epilogue<T, MI, NI, STATS>(acc, yoff, smem + wave * YOLO_EPI_WAVE_BYTES_MI(MI), a, co0 + wave_c * MI * 32, lane, roff, srow);
+    constexpr int ESTATS = STATS == 3 ? 0 : STATS;       // (3 = the fused tail 1x1 below, not a statistics mode)
+    float* srow = ESTATS ? a.stats + ((size_t)tile_p * WAVES_P + wave_p) * 2 * a.Cout_pad : nullptr;
+    conv_epilogue<T, MI, NI, ESTATS>(acc, yoff, smem + wave * YOLO_EPI_WAVE_BYTES_MI(MI), a, co0 + wave_c * MI * 32, lane, roff, srow);
     STAMP(4);
+    if constexpr (STATS == 3) {
+        // ---- TAIL (round 4): the 1x1 convolution that follows this one in the network -- the next residual block's first conv
+        //      (basic_yolo.py:26, darknet.py DarknetBasicBlockV3), a detection block's 1x1 after its 3x3, YOLOOutput after the
+        //      tip (basic_yolo.py:98-105) -- computed HERE from the output tile this block has just stored: z = act(W1 . y) over
+        //      the tile's pixels, K = this conv's Cout (one 256-cout tile holds every channel of a pixel).  The tile is read back
+        //      through L2 by LDS-DMA, chunk by chunk, exactly as a 1x1 kernel would stage it (same operands, same K order:
+        //      bit-identical to the separate launch), but without a second kernel, its boundary, or the HBM read of y. ------
+        static_assert(KS == 3 && WAVES_C * MI * 32 == 256 && WAVES_C == 4 && sizeof(T) == 2, "tail: 3x3, bf16, 256-cout tiles of 4 cout waves");
+        constexpr int BPX = (BP + NT / 4 - 1) / (NT / 4) * (NT / 4);        // X slots per phase (whole DMAs; the surplus reads zeros)
+        constexpr int X2_STAGE = BPX * 64, W2_STAGE = 128 * 64, S2 = X2_STAGE + W2_STAGE, R2 = 3;
+        constexpr int XL2 = X2_STAGE / (NT * 16), WL2 = W2_STAGE / (NT * 16), ND2 = XL2 + WL2;
+        static_assert(W2_STAGE % (NT * 16) == 0 && R2 * S2 <= (PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES), "tail: LDS");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's output stores have reached L2 ...
+        __syncthreads();                                                    // ... and everyone's; the epilogue's scratch is free
+        unsigned xs2[XL2];
+#pragma unroll
+        for (int j = 0; j < XL2; ++j) {
+            const int u = tid + j * NT;
+            const int slot = u >> 2, part = u & 3;
+            const int i = i0 + slot;
+            const bool valid = slot < BP && i < a.total_i;
+            const int ic = min(i, a.total_i - 1);
+            const int r = fdiv(ic, a.d_TWt);
+            const int tx = ic - r * TWt;
+            const int n = fdiv(r, a.d_Ho);
+            const int pix = (r - n * Ho) * Wo + strip * TWt + tx;
+            const long long off = ((long long)n * a.y_bs + (long long)pix * a.y_ps) * 2;
+            xs2[j] = valid ? (unsigned)(off + ((part ^ ((slot >> 2) & 3)) * 16)) : 0xffffffffu;
+        }
+        const int nph2 = a.Cout >> 5;                                       // K chunks of 32 channels (the host checks Cout % 32 == 0)
+        const long long wplane2 = (long long)round_up(a.t_cout, YOLO_COUT_PAD) * 64;
+        const char* zp2 = (const char*)yolo_zero_page;
+        auto issue2 = [&](int c) {
+            const int cc = min(c, nph2 - 1);                                // (tail phases re-load the last chunk into a dead slot)
+            const uint32_t base = wave_lds + (c % R2) * S2;
+#pragma unroll
+            for (int j = 0; j < XL2; ++j)
+                glds16(xs2[j] != 0xffffffffu ? a.y + ((size_t)xs2[j] + (size_t)cc * 64) : zp2, base + j * NT * 16);
+#pragma unroll
+            for (int j = 0; j < WL2; ++j)
+                glds16(a.t_wp + (long long)cc * wplane2 + (long long)(tid + j * NT) * 16, base + X2_STAGE + j * NT * 16);
+        };
+        f32x16 acc2[1][NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[0][ni][r] = 0.f;
+        issue2(0);
+        issue2(1);
+        const int aoff2 = (wave_c * 32 + l31) * 64 + ((h ^ ((l31 >> 2) & 3)) << 4);
+        int bx2[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int slot = (wave_p * NI + ni) * 32 + l31;
+            bx2[ni] = slot * 64 + ((h ^ ((slot >> 2) & 3)) << 4);
+        }
+        wait_vmcnt<ND2>();
+        __builtin_amdgcn_s_barrier();
+        for (int c = 0; c < nph2; ++c) {
+            issue2(c + 2);
+            const char* X2l = smem + (c % R2) * S2;
+            const char* W2l = X2l + X2_STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint4 af = *(const uint4*)(W2l + (aoff2 ^ (ks * 32)));
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const uint4 bf = *(const uint4*)(X2l + (bx2[ni] ^ (ks * 32)));
+                    FragP<T>::mma(af, bf, acc2[0][ni]);
+                }
+            }
+            wait_vmcnt<ND2>();
+            __builtin_amdgcn_s_barrier();
+        }
+        wait_vmcnt<0>();
+        __syncthreads();                                                    // everyone is done with the ring: it becomes the scratch
+        long long yoff2[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int i = i0 + (wave_p * NI + ni) * 32 + l31;
+            const int ic = min(i, a.total_i - 1);
+            const int r = fdiv(ic, a.d_TWt);
+            const int tx = ic - r * TWt;
+            const int n = fdiv(r, a.d_Ho);
+            const int pix = (r - n * Ho) * Wo + strip * TWt + tx;
+            yoff2[ni] = (i < a.total_i) ? (long long)n * a.t_y_bs + (long long)pix * a.t_y_ps : -1;
+        }
+        ConvArgs b = a;
+        b.scale = a.t_scale; b.bias = a.t_bias; b.res = nullptr; b.y = a.t_y; b.Cout = a.t_cout; b.out_f32 = a.t_out_f32;
+        b.up2 = 0; b.d2s = 0; b.slope = a.t_slope; b.y_bs = a.t_y_bs; b.y_ps = a.t_y_ps; b.stats = nullptr;
+        conv_epilogue<T, 1, NI, 0>(acc2, yoff2, smem + wave * YOLO_EPI_WAVE_BYTES_MI(1), b, wave_c * 32, lane, nullptr, nullptr);
+    }
 #if defined(YOLO_STAMP) && YOLO_PIPE_PART == 0
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(5);
@@ -629,12 +722,27 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     const bool stats_ok = kStats && !a.out_f32 && !a.d2s && !a.up2 && (a.Cout % 8) == 0 && (a.y_ps % 8) == 0 && (a.y_bs % 8) == 0 &&
                           (a.stats_mode == 1 || (a.stats_mode == 2 && S == 1 && a.y_ps == a.Cout));
     if (a.stats && !stats_ok) return YOLO_EUNSUPPORTED;
+    // fused tail 1x1 (kernel flag 3): bf16 3x3 tiles that hold all the channels of a pixel (256 couts over 4 cout waves)
+    constexpr bool kTail = sizeof(T) == 2 && KS == 3 && WAVES_C == 4 && WAVES_C * MI * 32 == 256 && RD == 0 && KC == 1 && LEAN == 0;
+    if (a.t_wp) {
+        if (!kTail || a.stats || a.out_f32 || a.up2 || a.d2s || a.tiles_c != 1 || (a.Cout % 32) || a.t_cout < 1 || a.t_cout > 128)
+            return YOLO_EUNSUPPORTED;
+        if ((long long)a.N * a.y_bs * 2 >= 0xffffff00LL) return YOLO_EUNSUPPORTED;         // 32-bit DMA source offsets into y
+    }
     if (name) {
         snprintf(name->buf, name->len, "void conv_pipe_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d>(ConvArgs)",
                  sizeof(T) == 2 ? "bf16_t" : "float", KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC, LEAN,
-                 (a.stats && stats_ok) ? a.stats_mode : 0);
+                 a.t_wp ? 3 : (a.stats && stats_ok) ? a.stats_mode : 0);
         if (name->stats_rows) *name->stats_rows = (a.stats && stats_ok) ? a.nstrips * a.tiles_per_strip * WAVES_P : -1;
         return YOLO_OK;
+    }
+    if constexpr (kTail) {
+        if (a.t_wp) {
+            YOLO_LAUNCH((conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC, LEAN, 3>), dim3((unsigned)grid),
+                        dim3(WAVES_P * WAVES_C * 64), 0, st, a);
+            YOLO_LAUNCH_CHECK();
+            return YOLO_OK;
+        }
     }
     if constexpr (kStats) {
         if (a.stats && a.stats_mode == 1) {

@@ -28,7 +28,11 @@ class ConvDesc(C.Structure):
                 ('algo', C.c_int), ('x_pixel_stride', C.c_longlong), ('upsample2x', C.c_int),
                 ('stats', C.c_void_p), ('stats_mode', C.c_int), ('stats_y', C.c_void_p), ('stats_mean', C.c_void_p),
                 ('stats_invstd', C.c_void_p), ('stats_gamma', C.c_void_p), ('stats_beta', C.c_void_p),
-                ('stats_slope', C.c_float)]
+                ('stats_slope', C.c_float),
+                # fused tail 1x1 (include/yolo_amd.h: tail_*)
+                ('tail_w_packed', C.c_void_p), ('tail_scale', C.c_void_p), ('tail_bias', C.c_void_p), ('tail_y', C.c_void_p),
+                ('tail_cout', C.c_int), ('tail_out_f32', C.c_int), ('tail_slope', C.c_float),
+                ('tail_y_batch_stride', C.c_longlong), ('tail_y_pixel_stride', C.c_longlong)]
 
 
 class GridDesc(C.Structure):
