@@ -461,6 +461,7 @@ def main():
     ap.add_argument('--no-fuse-stem', action='store_true', help='run the stem and the first down-sampling conv as two kernels (A/B)')
     ap.add_argument('--no-fuse-concat', action='store_true', help='up-sample + concat as a copy kernel instead of strided conv outputs (A/B)')
     ap.add_argument('--no-fuse-res', action='store_true', help='never use the fused residual-block kernel (A/B)')
+    ap.add_argument('--no-fuse-tail', action='store_true', help='never fuse a 1x1 convolution into the 3x3 in front of it (A/B)')
     ap.add_argument('--no-side-stream', action='store_true', help='run the head tip/output convolutions on the main stream (A/B)')
     ap.add_argument('--tune-cache', default=None, help='JSON file remembering the measured per-layer kernel choices')
     ap.add_argument('--post', default='top1', choices=['top1', 'nms', 'none'],
@@ -532,7 +533,7 @@ def main():
         return bench_train(args, spec, size, B, rank, world, dev, dist)
     net = CarNet(spec, dtype=args.dtype, device=dev, tune='measure', tune_cache=args.tune_cache,
                  fuse_stem=not args.no_fuse_stem, side_stream=not args.no_side_stream, fuse_concat=not args.no_fuse_concat,
-                 fuse_res=not args.no_fuse_res).initialize(seed=1234)
+                 fuse_res=not args.no_fuse_res, fuse_tail=not args.no_fuse_tail).initialize(seed=1234)
     net.prepare()
     det = Detector(spec, size, net.graph.steps(), device=dev)
     gen = torch.Generator(device='cpu').manual_seed(100 + rank)

@@ -303,3 +303,30 @@ def test_two_nets_on_two_streams_and_two_threads(cuda):
     [t.start() for t in threads]
     [t.join() for t in threads]
     assert not errs, errs
+
+
+def test_fused_tail_1x1_through_the_net(cuda):
+    """CarNet(fuse_tail=...): every eligible (3x3, following 1x1) pair of the D53 spec -- stage 2's down-sampling conv and the
+    3x3 of each of its residual blocks but the last, each with the next block's 1x1: the only 3x3 layers of the spec whose 256
+    output channels fit one tile and are followed by a 1x1 -- run as ONE launch each (yolo_conv_desc.tail_*).  The logits must be those of the unfused net bit for bit (same operands, same K order), and the
+    plan must really hold the fused launches."""
+    from yolo_amd.net import CarNet
+    from yolo_amd.spec import darknet53_spec
+    spec, size = darknet53_spec(), (224, 160)
+    x = torch.rand((3, 3) + size, generator=torch.Generator().manual_seed(5)).to(cuda)
+    nets = {}
+    for mode in (False, 'force'):
+        net = CarNet(spec, dtype='bf16', device=cuda, fuse_tail=mode).initialize(seed=11)
+        outs = [o.clone() for o in net(x)]
+        torch.cuda.synchronize()
+        nets[mode] = (net, outs)
+    fused_ops = [n for n, k, f in nets['force'][0].plan_kernels(3, *size) if '+' in n]
+    assert len(fused_ops) == 8, fused_ops                    # down + 7 residual 3x3 of stage 2
+    assert not any('+' in n for n, k, f in nets[False][0].plan_kernels(3, *size))
+    for a, b in zip(nets[False][1], nets['force'][1]):
+        assert torch.equal(a, b)
+    # the half-width maps the fused launches wrote are the parity taps of the 1x1 layers
+    for name in ('stages.2.res.0.c1', 'stages.2.res.3.c1', 'stages.2.res.7.c2'):
+        a = nets[False][0].activation_nchw(name)
+        b = nets['force'][0].activation_nchw(name)
+        assert torch.equal(a, b), name

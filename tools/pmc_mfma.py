@@ -21,11 +21,21 @@ for k, c in agg.items():
     t_ns = sum(dur[k]) / max(len(dur[k]), 1)
     gui = m.get('GRBM_GUI_ACTIVE', 0.0)
     e = dict(launches=len(next(iter(c.values()))), duration_us=t_ns / 1e3, **{n: v for n, v in m.items()})
-    if gui > 0:
+    # GRBM_GUI_ACTIVE counts from the command processor's point of view: for a kernel of a few tens of microseconds it holds
+    # launch / drain time that is not shader time, so GUI / duration is not a clock there ("3.1-3.6 GHz", 13 GHz for a copy)
+    # and the utilisation derived from it is meaningless.  Both are only reported for kernels of >= 50 us; below that the
+    # MFMA-busy fraction is given against the waves' own cycles (SQ_WAVE_CYCLES, no clock involved).
+    if gui > 0 and t_ns >= 50e3:
         e['mfma_util'] = m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui / 8.0 * 1024.0)
-        e['clock_ghz'] = (gui / 8.0) / t_ns if t_ns > 0 else None
+        e['clock_ghz'] = (gui / 8.0) / t_ns
+    elif gui > 0:
+        e['short_kernel'] = 'under 50 us: no clock / mfma_util from GRBM_GUI_ACTIVE'
+    wc = m.get('SQ_WAVE_CYCLES', 0.0)
+    if wc > 0:
+        e['mfma_busy_per_wave_cycle'] = m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / wc
     res[k] = e
 json.dump(dict(note='means per launch; counters are sums over XCDs / SEs / SIMDs as rocprofv3 reports them', kernels=res),
           open(out, 'w'), indent=1)
 for k, e in sorted(res.items(), key=lambda kv: -kv[1]['launches'] * kv[1]['duration_us'])[:8]:
-    print('%-70s %4d x %8.1f us  mfma_util %.3f  clock %.2f GHz' % (k[:70], e['launches'], e['duration_us'], e.get('mfma_util', 0), e.get('clock_ghz') or 0))
+    print('%-70s %4d x %8.1f us  mfma_util %s  clock %s' % (k[:70], e['launches'], e['duration_us'],
+          '%.3f' % e['mfma_util'] if 'mfma_util' in e else '  n/a', '%.2f GHz' % e['clock_ghz'] if 'clock_ghz' in e else 'n/a (short kernel)'))

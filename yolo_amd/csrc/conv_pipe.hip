@@ -570,9 +570,13 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         //      bit-identical to the separate launch), but without a second kernel, its boundary, or the HBM read of y. ------
         static_assert(KS == 3 && WAVES_C * MI * 32 == 256 && WAVES_C == 4 && sizeof(T) == 2, "tail: 3x3, bf16, 256-cout tiles of 4 cout waves");
         constexpr int BPX = (BP + NT / 4 - 1) / (NT / 4) * (NT / 4);        // X slots per phase (whole DMAs; the surplus reads zeros)
-        constexpr int X2_STAGE = BPX * 64, W2_STAGE = 128 * 64, S2 = X2_STAGE + W2_STAGE, R2 = 3;
+        constexpr int X2_STAGE = BPX * 64, W2_STAGE = 128 * 64, S2 = X2_STAGE + W2_STAGE;
+        // ring depth: as many K chunks in flight as the block's LDS holds (<= 8 = every chunk of a 256-channel tile): the tail
+        // is a chain of L2 round trips -- six to eight MFMAs per wave and chunk -- so its time is the latency it cannot overlap
+        constexpr int LDS_ALL = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
+        constexpr int R2 = LDS_ALL / S2 > 8 ? 8 : LDS_ALL / S2;
         constexpr int XL2 = X2_STAGE / (NT * 16), WL2 = W2_STAGE / (NT * 16), ND2 = XL2 + WL2;
-        static_assert(W2_STAGE % (NT * 16) == 0 && R2 * S2 <= (PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES), "tail: LDS");
+        static_assert(W2_STAGE % (NT * 16) == 0 && R2 >= 3, "tail: LDS");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's output stores have reached L2 ...
         __syncthreads();                                                    // ... and everyone's; the epilogue's scratch is free
         unsigned xs2[XL2];
@@ -608,8 +612,8 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[0][ni][r] = 0.f;
-        issue2(0);
-        issue2(1);
+#pragma unroll
+        for (int c = 0; c < R2 - 1; ++c) issue2(c);
         const int aoff2 = (wave_c * 32 + l31) * 64 + ((h ^ ((l31 >> 2) & 3)) << 4);
         int bx2[NI];
 #pragma unroll
@@ -617,10 +621,10 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
             const int slot = (wave_p * NI + ni) * 32 + l31;
             bx2[ni] = slot * 64 + ((h ^ ((slot >> 2) & 3)) << 4);
         }
-        wait_vmcnt<ND2>();
+        wait_vmcnt<(R2 - 2) * ND2>();
         __builtin_amdgcn_s_barrier();
         for (int c = 0; c < nph2; ++c) {
-            issue2(c + 2);
+            issue2(c + R2 - 1);
             const char* X2l = smem + (c % R2) * S2;
             const char* W2l = X2l + X2_STAGE;
 #pragma unroll
@@ -632,7 +636,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
                     FragP<T>::mma(af, bf, acc2[0][ni]);
                 }
             }
-            wait_vmcnt<ND2>();
+            wait_vmcnt<(R2 - 2) * ND2>();
             __builtin_amdgcn_s_barrier();
         }
         wait_vmcnt<0>();

@@ -36,7 +36,7 @@ class CarNet(object):
     ALGOS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 30, 31, 32, 33, 35, 36, 37, 38, 39)     # yolo_conv_desc.algo ids tried by tune='measure'
 
     def __init__(self, spec, num_sync_bn_devices=-1, dtype='bf16', device='cuda:0', tune='auto', tune_cache=None,
-                 fuse_stem=True, side_stream=True, fuse_res=True, fuse_concat=True):
+                 fuse_stem=True, side_stream=True, fuse_res=True, fuse_concat=True, fuse_tail=True):
         # num_sync_bn_devices is accepted for signature parity; the reference always passes -1
         # (no SyncBN, car/YOLO.py:94-96).
         if dtype not in _TORCH_DT:
@@ -66,6 +66,14 @@ class CarNet(object):
         # stores every output pixel to its 2x2 patch of the other half (yolo_conv_desc.upsample2x), and the route's other
         # reader -- the next stage's down-sampling conv -- reads it with an input pixel stride
         self.fuse_concat = bool(fuse_concat)
+        # fuse_tail: a 3x3 convolution whose 256-cout tile holds every channel of a pixel also computes the 1x1 convolution that
+        # follows it (yolo_conv_desc.tail_*: the next residual block's first conv, a detection block's 1x1, YOLOOutput after the
+        # tip) from the output tile it has just stored -- one launch instead of two, no HBM read of the 3x3's output by the 1x1.
+        # bf16, Cout <= 256, 1x1 Cout <= 128; with tune='measure' the fused launch is timed against the two separate ones.
+        # (measured, round 4: -3..-16 us per pair in isolation, nothing in the whole pass -- so it is only considered where the
+        #  tuner can check it, i.e. with tune='measure')
+        self._force_tail = fuse_tail == 'force'
+        self.fuse_tail = bool(fuse_tail) and (tune == 'measure' or fuse_tail == 'force')      # ('force': tests -- every eligible pair)
         self._algo_cache = {}
         # optional JSON file remembering measured choices (so a profiled run launches only the chosen kernels)
         self._tune_cache = tune_cache
@@ -188,20 +196,101 @@ class CarNet(object):
             self.prepare()
 
     # ---- plan construction --------------------------------------------------------------------------
-    def _conv_op(self, plan, c, x, xshape, residual=None, out=None, out_f32=False, y_bs=0, y_ps=0, cin=None, x_ps=0, up2=False):
+    def _conv_op(self, plan, c, x, xshape, residual=None, out=None, out_f32=False, y_bs=0, y_ps=0, cin=None, x_ps=0, up2=False,
+                 tail=None):
+        """tail: (1x1 conv spec, its output tensor or pointer, out_f32, batch stride, pixel stride) computed by the same launch
+        (yolo_conv_desc.tail_*); the caller has checked _tail_eligible and decided (_use_tail)."""
         N, H, W, _ = xshape
         ho, wo = c.out_hw(H, W)
         if out is None:
             out = torch.empty((N, ho, wo, c.cout), dtype=_TORCH_DT[self.dtype], device=self.device)
             plan.buffers.append(out)
         d = self._conv_desc(c, x, xshape, out, residual, out_f32, y_bs, y_ps, cin, x_ps, up2)
-        if self.tune == 'measure':
-            d.algo = self._measure_algo(d)
-        plan.ops.append(('conv', d, c.name))
+        if tail is not None:
+            self._set_tail(d, *tail)
+            d.algo = self._tail_algo(d)
+            plan.ops.append(('conv', d, c.name + '+' + tail[0].name))
+        else:
+            if self.tune == 'measure':
+                d.algo = self._measure_algo(d)
+            plan.ops.append(('conv', d, c.name))
         oshape = (N, 2 * ho, 2 * wo, c.cout) if up2 else (N, ho, wo, c.cout)
         if not isinstance(out, int):
             plan.act[c.name] = (out, oshape)
+        if tail is not None and not isinstance(tail[1], int):
+            plan.act[tail[0].name] = (tail[1], (N, ho, wo, tail[0].cout))
         return out, oshape
+
+    # ---- fused tail 1x1 ---------------------------------------------------------------------------------------------
+    TAIL_ALGOS = {1: (6, 2), 2: (18, 16, 10)}                # 3x3 variants with 256-cout tiles, by stride
+
+    def _tail_eligible(self, c3, c1):
+        return (self.fuse_tail and self.dtype == 'bf16' and c3.k == 3 and c3.bn and c3.cout <= 256 and c3.cout % 32 == 0
+                and c1.k == 1 and c1.stride == 1 and c1.cin == c3.cout and c1.cout <= 128 and (c1.bn or c1.cout % 2 == 0))
+
+    def _set_tail(self, d, c1, out1, out1_f32=False, t_bs=0, t_ps=0):
+        wp1, s1, b1 = self._prepared[c1.name]
+        d.tail_w_packed, d.tail_scale, d.tail_bias = L.ptr(wp1), L.ptr(s1), L.ptr(b1)
+        d.tail_y = out1 if isinstance(out1, int) else L.ptr(out1)
+        d.tail_cout, d.tail_out_f32 = c1.cout, 1 if out1_f32 else 0
+        d.tail_slope = LEAKY_SLOPE if c1.bn else 1.0
+        d.tail_y_batch_stride, d.tail_y_pixel_stride = t_bs, t_ps
+
+    def _tail_key(self, d):
+        return ('tail', d.N, d.H, d.W, d.Cin, d.Cout, d.stride, bool(d.residual), d.tail_cout, d.tail_out_f32, int(d.y_pixel_stride))
+
+    def _tail_algo(self, d):
+        """The 256-cout tile variant of a fused launch: the first the library takes, or (tune='measure') the fastest."""
+        cands = self.TAIL_ALGOS[d.stride]
+        if self.tune != 'measure':
+            return 0
+        return self._measure_algo(d, algos=cands, key_extra=('tail', d.tail_cout, d.tail_out_f32))
+
+    def _use_tail(self, c3, c1, x, xshape, residual, out, out1, out1_f32=False, t_bs=0, t_ps=0, y_bs=0, y_ps=0):
+        """Whether (3x3 c3, then 1x1 c1 on its output) runs as ONE fused launch.  tune='auto': whenever the library takes it;
+        tune='measure': when the fused launch is faster than the two separate ones with their own best variants."""
+        if not self._tail_eligible(c3, c1):
+            return False
+        lib, st = self._lib, L.stream_ptr()
+        N, H, W, _ = xshape
+        ho, wo = c3.out_hw(H, W)
+        d = self._conv_desc(c3, x, xshape, out, residual, False, y_bs, y_ps)
+        self._set_tail(d, c1, out1, out1_f32, t_bs, t_ps)
+        buf = C.create_string_buffer(256)
+        if lib.yolo_conv_kernel_name(C.byref(d), buf, 256) != 0:
+            return False
+        if self.tune != 'measure' or self._force_tail:
+            return True
+        key = self._tail_key(d)
+        if key in self._algo_cache:
+            return bool(self._algo_cache[key])
+        d3 = self._conv_desc(c3, x, xshape, out, residual, False, y_bs, y_ps)
+        d3.algo = self._measure_algo(d3)
+        d1 = self._conv_desc(c1, out, (N, ho, wo, c3.cout), out1, None, out1_f32, t_bs, t_ps)
+        d1.algo = self._measure_algo(d1)
+        d.algo = self._tail_algo(d)
+
+        def timed(fn, n=20):
+            best = float('inf')
+            for _ in range(3):
+                fn(); fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n):
+                    fn()
+                e1.record()
+                e1.synchronize()
+                best = min(best, e0.elapsed_time(e1) / n)
+            return best
+
+        def separate():
+            L.check(lib.yolo_conv_fwd(C.byref(d3), st), 'conv')
+            L.check(lib.yolo_conv_fwd(C.byref(d1), st), 'conv')
+
+        use = lib.yolo_conv_fwd(C.byref(d), st) == 0 and timed(lambda: lib.yolo_conv_fwd(C.byref(d), st)) < timed(separate)
+        self._algo_cache[key] = int(use)
+        self._save_tune_cache()
+        return use
 
     def _res_block_payload(self, c1, c2, x, out, shp):
         wp1, s1, b1 = self._prepared[c1.name]
@@ -296,13 +385,14 @@ class CarNet(object):
         d.x_pixel_stride, d.upsample2x = x_ps, 1 if up2 else 0
         return d
 
-    def _measure_algo(self, d, iters=5, fn=None, algos=None):
+    def _measure_algo(self, d, iters=5, fn=None, algos=None, key_extra=()):
         """Fastest conv variant for this layer shape (cached).  Outputs are overwritten while timing,
         which is harmless: the plan has not run yet.  fn / algos: another entry point taking the same descriptor
         (yolo_conv_dgrad_s2, with d.ksize = 2 as the cache key's mark) and its variant ids; 1 = none ran."""
         key = (d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.out_f32, bool(d.residual), d.dtype)
         if d.x_pixel_stride or d.upsample2x or (d.y_pixel_stride and not d.out_f32):
             key = key + (int(d.x_pixel_stride), int(d.upsample2x), int(d.y_pixel_stride))
+        key = key + tuple(key_extra)
         if key in self._algo_cache:
             return self._algo_cache[key]
         lib, st = self._lib, L.stream_ptr()
@@ -389,22 +479,44 @@ class CarNet(object):
                 plan.buffers.append(cat)
                 cats[i] = (cat, up_ch)
                 cat_view = cat[..., up_ch:]
+            # fused tail: the conv in front of a residual block's 1x1 (the stage's down-sampling conv, or the block before's 3x3)
+            # also computes that 1x1 -> `pre_mid` is the block's half-width map, already made
+            pre_mid = None
+
+            def tail_for(c3, xin, xshp, resid, j_next, out=None):
+                """(tail tuple, mid tensor) when conv c3 should also compute res[j_next]'s 1x1, else (None, None)."""
+                if j_next >= len(res) or self._res_block_eligible(res[j_next][0], res[j_next][1]):
+                    return None, None
+                c1n = res[j_next][0]
+                if not self._tail_eligible(c3, c1n):
+                    return None, None
+                ho_, wo_ = c3.out_hw(xshp[1], xshp[2])
+                o3 = out if out is not None else torch.empty((xshp[0], ho_, wo_, c3.cout), dtype=tdt, device=self.device)
+                m = torch.empty((xshp[0], ho_, wo_, c1n.cout), dtype=tdt, device=self.device)
+                if not self._use_tail(c3, c1n, xin, xshp, resid, o3, m):
+                    return None, None
+                plan.buffers.append(m)
+                return (c1n, m, False, 0, 0), m
+
             if down is not fused_down:
-                x, shp = self._conv_op(plan, down, x, shp, out=cat_view if not res else None)
+                dout = cat_view if not res else None
+                tl, pre_mid = tail_for(down, x, shp, None, 0) if res else (None, None)
+                x, shp = self._conv_op(plan, down, x, shp, out=dout, tail=tl)
             for j, (c1, c2) in enumerate(res):
-                if cat_view is not None and j == len(res) - 1:
-                    mid, mshp = self._conv_op(plan, c1, x, shp)
-                    x, shp = self._conv_op(plan, c2, mid, mshp, residual=x, out=cat_view)
-                    continue
-                if self._use_res_block(c1, c2, x, shp):
+                last = cat_view is not None and j == len(res) - 1
+                if not last and pre_mid is None and self._use_res_block(c1, c2, x, shp):
                     out = torch.empty(shp, dtype=tdt, device=self.device)
                     plan.buffers.append(out)
                     plan.ops.append(('res_block', self._res_block_payload(c1, c2, x, out, shp), c2.name))
                     plan.act[c2.name] = (out, shp)
                     x = out
                     continue
-                mid, mshp = self._conv_op(plan, c1, x, shp)
-                x, shp = self._conv_op(plan, c2, mid, mshp, residual=x)
+                if pre_mid is not None:
+                    mid, mshp = pre_mid, shp[:3] + (c1.cout,)
+                else:
+                    mid, mshp = self._conv_op(plan, c1, x, shp)
+                tl, pre_mid = tail_for(c2, mid, mshp, x, j + 1, out=cat_view if last else None)
+                x, shp = self._conv_op(plan, c2, mid, mshp, residual=x, out=cat_view if last else None, tail=tl)
             if i >= nst - g.num_pyramid:
                 routes.append((x, shp, cats.get(i)))
         # merged head buffer (B, sum HW, A*C) float32, scales fine->coarse (car/utils.py:95, car/YOLO.py:841)
@@ -426,14 +538,37 @@ class CarNet(object):
                         t, tshp = self._conv_op(plan, c, t, tshp)
                 plan.lp = torch.empty((tshp[0], tshp[1], tshp[2], g.lp_out.cout), dtype=torch.float32, device=self.device)
                 self._conv_op(plan, g.lp_out, t, tshp, out=plan.lp.data_ptr(), out_f32=True)
-            for c in body:
+            bi_ = 0
+            while bi_ < len(body):
+                c = body[bi_]
+                nxt = body[bi_ + 1] if bi_ + 1 < len(body) else None
+                if nxt is not None and self._tail_eligible(c, nxt):
+                    ho_, wo_ = c.out_hw(shp[1], shp[2])
+                    o3 = torch.empty((shp[0], ho_, wo_, c.cout), dtype=tdt, device=self.device)
+                    m = torch.empty((shp[0], ho_, wo_, nxt.cout), dtype=tdt, device=self.device)
+                    if self._use_tail(c, nxt, x, shp, None, o3, m):
+                        plan.buffers += [o3, m]
+                        _, s3 = self._conv_op(plan, c, x, shp, out=o3, tail=(nxt, m, False, 0, 0))
+                        x, shp = m, s3[:3] + (nxt.cout,)
+                        bi_ += 2
+                        continue
                 x, shp = self._conv_op(plan, c, x, shp)
+                bi_ += 1
             route, rshp = x, shp
             first_side = len(plan.ops)
-            t, tshp = self._conv_op(plan, tip, route, rshp)
             k = len(g.heads) - 1 - i                        # position of this scale in fine->coarse order
             yptr = plan.merged.data_ptr() + offs[k] * AC * 4
-            self._conv_op(plan, outc, t, tshp, out=yptr, out_f32=True, y_bs=tot * AC, y_ps=AC)
+            tip_fused = False
+            if self._tail_eligible(tip, outc):
+                ho_, wo_ = tip.out_hw(rshp[1], rshp[2])
+                o3 = torch.empty((rshp[0], ho_, wo_, tip.cout), dtype=tdt, device=self.device)
+                if self._use_tail(tip, outc, route, rshp, None, o3, yptr, True, tot * AC, AC):
+                    plan.buffers.append(o3)
+                    self._conv_op(plan, tip, route, rshp, out=o3, tail=(outc, yptr, True, tot * AC, AC))
+                    tip_fused = True
+            if not tip_fused:
+                t, tshp = self._conv_op(plan, tip, route, rshp)
+                self._conv_op(plan, outc, t, tshp, out=yptr, out_f32=True, y_bs=tot * AC, y_ps=AC)
             if i >= len(g.heads) - 1:
                 break
             if self.side_stream:
@@ -589,9 +724,13 @@ class CarNet(object):
                 out.append((name, kind, 0))
                 continue
             L.check(self._lib.yolo_conv_kernel_name(C.byref(payload), buf, 256), 'kernel_name')
-            c = by_name[name]
-            ho, wo = c.out_hw(payload.H, payload.W)
-            out.append((name, buf.value.decode(), 2 * c.cin * c.k * c.k * c.cout * ho * wo * payload.N))
+            fl = 0
+            for part in name.split('+'):                     # ('a+b': conv a with conv b as its fused tail 1x1, same output map)
+                c = by_name[part]
+                if part == name.split('+')[0]:
+                    ho, wo = c.out_hw(payload.H, payload.W)
+                fl += 2 * c.cin * c.k * c.k * c.cout * ho * wo * payload.N
+            out.append((name, buf.value.decode(), fl))
         return out
 
     def forward_timed(self, x, events):
