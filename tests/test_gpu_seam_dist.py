@@ -379,28 +379,30 @@ def test_two_real_ranks_exchange_on_one_gpu(cuda):
     assert np.mean(np.abs(w_got - w_ref) > 1e-6) < 1e-3, float(np.mean(np.abs(w_got - w_ref) > 1e-6))
 
 
-def test_bench_two_ranks_sharing_the_gpu():
-    """`bench.py --gpus 2` end to end on a one-GPU box (TEST-ONLY switch YOLO_BENCH_SHARED_GPU + gloo): the launcher starts two
-    ranks, both run the sharded inference passes and the training pass with the real exchange, rank 0 prints ONE JSON line
-    last on stdout with n_gpus = 2, the training key with its exchange block, and the test-only marker."""
+@pytest.mark.parametrize('world', [2, 8])
+def test_bench_two_ranks_sharing_the_gpu(world):
+    """`bench.py --gpus N` (N = 2, and N = 8 = BASELINE configs[3] / [4]'s world) end to end on a one-GPU box (TEST-ONLY switch
+    YOLO_BENCH_SHARED_GPU + gloo): the launcher starts N ranks, all run the sharded inference passes and the training pass with
+    the real exchange, rank 0 prints ONE JSON line last on stdout with n_gpus = N, the training key with its exchange block,
+    and the test-only marker."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     env.update(YOLO_BENCH_BACKEND='gloo', YOLO_BENCH_SHARED_GPU='1')
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--no-northstar',
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', '3', '--warmup', '1', '--no-northstar',
                         '--no-roofline', '--no-repeats', '--sustain-steps', '0', '--train-timeout', '900'], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     d = json.loads(lines[-1])                                                          # the JSON line is the LAST line
-    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 64 and 'shared_gpu_test' in d
+    assert d['n_gpus'] == world and d['config']['global_batch'] == 32 * world and 'shared_gpu_test' in d
     t = d['train_416_bs64']
     assert 'error' not in t, t
-    assert t['n_gpus'] == 2 and t['global_batch'] == 128 and t['exchange']['rccl_world'] == 2 and t['exchange']['buckets'] >= 2
+    assert t['n_gpus'] == world and t['global_batch'] == 64 * world and t['exchange']['rccl_world'] == world and t['exchange']['buckets'] >= 2
     assert t['exchange']['allreduce_ms_per_step_standalone'] > 0 and all(np.isfinite(t['final_losses']))
     assert 'cpu_baseline' not in d and 'f32_path' not in d                              # rank-0-only extras of the N = 1 line
     # rank 0 measured the kernel variants, rank 1 adopted its choices: the same launch plan and the same training-step
     # variants on both ranks (tune='measure' is box- and rank-dependent when left alone), and every rank's own time is in the line
     assert d['plans_identical_across_ranks'] is True and t['tuning_identical_across_ranks'] is True
-    assert len(d['per_rank_ms_per_step']) == 2 and len(t['per_rank_ms_per_step']) == 2 and 'errors' not in d
+    assert len(d['per_rank_ms_per_step']) == world and len(t['per_rank_ms_per_step']) == world and 'errors' not in d
