@@ -86,7 +86,14 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         double* __restrict__ sums, int C, long long npix,
                                                         int pix_per_block, float slope, int shift = 0) {
-    constexpr int U = MODE == 0 ? 8 : 4;
+    // (loads in flight per thread.  Round 4: the backward reduction 4 -> 3 and the apply passes 4 -> 2 (forward) / 3 (backward):
+    //  fewer registers -- 186-204 -> 114-132 for the apply kernels -- and twice the waves per SIMD; the whole training step
+    //  -1.2 % in same-box A/B runs (the isolated passes do not change: the gain is in how these HBM-bound kernels share the
+    //  CUs with the side stream's weight gradients); 6 in flight: +3 %)
+#ifndef YOLO_BNR_U1
+#define YOLO_BNR_U1 3
+#endif
+    constexpr int U = MODE == 0 ? 8 : YOLO_BNR_U1;
     __shared__ float red[2][256][8];
     const int noct = C >> 3;
     const int goct = BN_CG / 8;                                 // octets of a channel group
@@ -217,7 +224,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
                                                        const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                        float inv_n, T* __restrict__ out, int C, long long npix,
                                                        int pix_per_block, float slope, BnFused f) {
-    constexpr int U = 4;
+    #ifndef YOLO_BN_U0
+#define YOLO_BN_U0 2
+#endif
+#ifndef YOLO_BN_U1
+#define YOLO_BN_U1 3
+#endif
+    constexpr int U = MODE == 0 ? YOLO_BN_U0 : YOLO_BN_U1;
     const int noct = C >> 3;
     const int per = noct < 256 ? noct : 256;
     const int lanes = 256 / per;
