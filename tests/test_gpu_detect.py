@@ -310,3 +310,24 @@ def test_decode_nms_rejects(cuda):
     assert lib.yolo_decode_nms(p, p, p, 1, 30, C.byref(det.grid), 1, f(0.01), f(0.45), 600, 100, p, p, p, p, st) == -2       # top-k beyond the sort
     assert lib.yolo_decode_nms(p, p, p, 0, 30, C.byref(det.grid), 1, f(0.01), f(0.45), 400, 100, p, p, p, p, st) == -1
     assert lib.yolo_decode_nms(p, p, p, 1, 30, None, 1, f(0.01), f(0.45), 400, 100, p, p, p, p, st) == -1
+
+
+def test_predict_async_equals_predict(cuda):
+    """Detector.predict_async (the rows copied into a pinned host buffer behind the kernels, two slots) returns predict()'s rows;
+    a slot's buffer is stable until the slot is used again, and alternating slots keeps two frames apart."""
+    det, outs, syxhw, _ = _setup((416, 416), 3, 51, cuda, scale=2.0)
+    dev = [torch.from_numpy(o).to(cuda) for o in outs]
+    want = det.predict(dev)
+    h0, e0 = det.predict_async(dev, slot=0)
+    dev2 = [d * 0.5 for d in dev]
+    want2 = det.predict(dev2)
+    h1, e1 = det.predict_async(dev2, slot=1)
+    e0.synchronize(); e1.synchronize()
+    assert h0.dtype == np.float32 and h0.shape == want.shape
+    np.testing.assert_array_equal(h0, want)
+    np.testing.assert_array_equal(h1, want2)
+    assert not np.array_equal(h0, h1)
+    h0b, e0b = det.predict_async(dev2, slot=0)              # the slot's buffer is re-used
+    e0b.synchronize()
+    assert h0b.ctypes.data == h0.ctypes.data
+    np.testing.assert_array_equal(h0b, want2)
