@@ -110,8 +110,8 @@ typedef struct yolo_conv_desc {
      * launch, no HBM read of y; y is still written.  tail_w_packed: yolo_pack_conv_weights image of the (tail_cout, Cout, 1, 1)
      * weights; tail_scale / tail_bias padded like scale / bias; tail_y (N,Ho,Wo,tail_cout) dtype or float32; strides as for y.
      * Bit-identical to the separate 1x1 launch.  Needs: bf16, ksize 3, Cout <= 256 and a multiple of 32, tail_cout <= 128, no
-     * out_f32 / upsample2x / stats on this convolution, and a pipelined variant with 256-cout tiles (algo 2, 6; stride 2: 10, 16,
-     * 18; algo 0 picks one) -- YOLO_EUNSUPPORTED otherwise (run the two launches). */
+     * out_f32 / upsample2x / stats on this convolution, and an 8-wave pipelined variant whose tile holds every channel of a pixel
+     * (256-cout tiles: algo 2, 6; stride 2: 10, 16, 18; Cout <= 128 also the 128-cout tiles 7; 9, 17; algo 0 picks one) -- YOLO_EUNSUPPORTED otherwise (run the two launches). */
     const void* tail_w_packed;
     const float* tail_scale;
     const float* tail_bias;

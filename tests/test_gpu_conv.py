@@ -552,7 +552,8 @@ TAIL_CASES = [
     # (N, Cin, H, W, Cout, stride, residual, tail_cout, tail_f32, strided y)
     (2, 128, 26, 26, 256, 1, True, 128, False, False),      # a stage-2 residual block's 3x3 + the next block's 1x1
     (3, 128, 19, 31, 256, 1, False, 128, False, True),      # main output into a channel slice of a wider buffer
-    (2, 64, 40, 24, 128, 1, True, 64, False, False),        # Cout < 256: the tile's upper couts are padding
+    (2, 64, 40, 24, 128, 1, True, 64, False, False),        # Cout = 128: a 128-cout tile, or a 256-cout one whose upper couts are padding
+    (3, 64, 52, 36, 128, 2, False, 64, False, False),       # stage 1's down-sampling conv + its first block's 1x1 (128-cout stride-2 tiles)
     (5, 128, 13, 13, 256, 1, False, 90, True, False),       # tip + YOLOOutput: fp32 logits, Cout 90, strided rows
     (2, 128, 52, 52, 256, 2, False, 128, False, False),     # the stage's down-sampling conv + the first block's 1x1
     (1, 256, 9, 70, 224, 1, True, 96, False, False),        # ragged counts: 224 = 7 chunks, 96 couts
@@ -560,7 +561,7 @@ TAIL_CASES = [
 ]
 
 
-@pytest.mark.parametrize('case,algo', [(c, a) for c in TAIL_CASES for a in [0] + ([10, 16, 18] if c[5] == 2 else [2, 6])])
+@pytest.mark.parametrize('case,algo', [(c, a) for c in TAIL_CASES for a in [0] + ([10, 16, 18] + ([9, 17] if c[4] <= 128 else []) if c[5] == 2 else [2, 6] + ([7] if c[4] <= 128 else []))])
 def test_conv_tail_1x1_fused_is_bit_identical(lib, cuda, case, algo):
     """yolo_conv_desc.tail_*: the 1x1 convolution behind a 3x3 one computed by the same kernel from the output tile it has just
     stored.  Against the two separate launches on the same buffers: the main output and the tail output must be bit-identical
@@ -613,7 +614,7 @@ def test_conv_tail_1x1_fused_is_bit_identical(lib, cuda, case, algo):
             assert lib.yolo_conv_fwd(C.byref(d), st) == 0
         else:
             # the same tile variant as the fused call (kernel families differ in their K order, i.e. in the last bit)
-            for cand in ([algo] if algo else ([18, 16, 10] if stride == 2 else [6, 2])):
+            for cand in ([algo] if algo else (([17, 9] if Cout <= 128 else []) + [18, 16, 10] if stride == 2 else ([7] if Cout <= 128 else []) + [6, 2])):
                 d.algo = cand
                 if lib.yolo_conv_fwd(C.byref(d), st) == 0:
                     break
@@ -660,7 +661,8 @@ def test_conv_tail_rejects(lib, cuda):
     assert lib.yolo_conv_fwd(C.byref(desc(tail_cout=256)), st) == -2
     assert lib.yolo_conv_fwd(C.byref(desc(ksize=1)), st) == -2
     assert lib.yolo_conv_fwd(C.byref(desc(dtype=L.F32)), st) == -2
-    assert lib.yolo_conv_fwd(C.byref(desc(algo=8)), st) == -2                 # a 128-cout tile variant
+    assert lib.yolo_conv_fwd(C.byref(desc(algo=8)), st) == -2                 # a 4-wave tile variant
+    assert lib.yolo_conv_fwd(C.byref(desc(algo=7)), st) == -2                 # a 128-cout tile for 256 couts
     assert lib.yolo_conv_fwd(C.byref(desc(tail_y=None)), st) == -1
     assert lib.yolo_conv_fwd(C.byref(desc(tail_slope=2.0)), st) == -1
     assert lib.yolo_conv_fwd(C.byref(desc(upsample2x=1)), st) == -2

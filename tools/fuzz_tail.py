@@ -46,7 +46,7 @@ while time.time() - t0 < budget:
     ych = cout + 32 if strided else cout
     tpitch = tcout + 6 if tf32 else tcout
     ncase += 1
-    for algo in ((10, 16, 18) if stride == 2 else (2, 6)):
+    for algo in ((10, 16, 18, 9, 17) if stride == 2 else (2, 6, 7)):
         outs = []
         ok = True
         for fused in (False, True):

@@ -57,7 +57,7 @@ def probe(N, hw, cin, cout, stride, res, tcout, tf32):
     d.tail_w_packed, d.tail_scale, d.tail_bias, d.tail_y = wp1.data_ptr(), sc1.data_ptr(), bi1.data_ptr(), z.data_ptr()
     d.tail_cout, d.tail_out_f32, d.tail_slope = tcout, int(tf32), (1.0 if tf32 else 0.1)
     tf = {}
-    for a in ((2, 6) if stride == 1 else (10, 16, 18)):
+    for a in ((2, 6, 7) if stride == 1 else (10, 16, 18, 9, 17)):
         d.algo = a
         if lib.yolo_conv_fwd(C.byref(d), st) == 0:
             tf[a] = timed(lambda: lib.yolo_conv_fwd(C.byref(d), st))
@@ -67,6 +67,8 @@ def probe(N, hw, cin, cout, stride, res, tcout, tf32):
 
 
 for N, s in ((32, 416), (64, 608)):
+    probe(N, s // 2, 64, 128, 2, 0, 64, 0)            # stage-1 down-sampling conv + the first block's 1x1
+    probe(N, s // 4, 64, 128, 1, 1, 64, 0)            # stage-1 residual 3x3 + the next block's 1x1
     probe(N, s // 8, 128, 256, 1, 1, 128, 0)          # stage-2 residual 3x3 + the next block's 1x1
     probe(N, s // 4, 128, 256, 2, 0, 128, 0)          # stage-2 down-sampling conv + the first block's 1x1
     probe(N, s // 8, 128, 256, 1, 0, 128, 0)          # heads.2 body 3x3 + 1x1

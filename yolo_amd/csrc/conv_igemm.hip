@@ -437,9 +437,12 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
         if (a.stats || d->dtype != YOLO_BF16 || d->ksize != 3) return YOLO_EUNSUPPORTED;
         if (!d->tail_out_f32 && (d->tail_cout % 4)) return YOLO_EUNSUPPORTED;
         if (d->algo) return conv_pipe_dispatch(a, d->ksize, d->stride, d->dtype, d->algo, st, nm);
-        static const int s1[] = {6, 2}, s2[] = {18, 16, 10};
-        const int* cand = d->stride == 2 ? s2 : s1;
-        for (int k = 0; k < (d->stride == 2 ? 3 : 2); ++k) {
+        // (tiles that hold every channel of a pixel: 128-cout tiles first when Cout <= 128, else the 256-cout ones)
+        static const int s1a[] = {7, 6, 2}, s2a[] = {17, 9, 18, 16, 10}, s1b[] = {6, 2, 0}, s2b[] = {18, 16, 10, 0, 0};
+        const bool small = d->Cout <= 128;
+        const int* cand = d->stride == 2 ? (small ? s2a : s2b) : (small ? s1a : s1b);
+        const int ncand = d->stride == 2 ? (small ? 5 : 3) : (small ? 3 : 2);
+        for (int k = 0; k < ncand; ++k) {
             ConvArgs b = a;
             const int rc = conv_pipe_dispatch(b, d->ksize, d->stride, d->dtype, cand[k], st, nm);
             if (rc != YOLO_EUNSUPPORTED) return rc;

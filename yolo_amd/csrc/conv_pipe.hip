@@ -568,7 +568,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         //      the tile's pixels, K = this conv's Cout (one 256-cout tile holds every channel of a pixel).  The tile is read back
         //      through L2 by LDS-DMA, chunk by chunk, exactly as a 1x1 kernel would stage it (same operands, same K order:
         //      bit-identical to the separate launch), but without a second kernel, its boundary, or the HBM read of y. ------
-        static_assert(KS == 3 && WAVES_C * MI * 32 == 256 && WAVES_C == 4 && sizeof(T) == 2, "tail: 3x3, bf16, 256-cout tiles of 4 cout waves");
+        static_assert(KS == 3 && WAVES_C == 4 && sizeof(T) == 2, "tail: 3x3, bf16, tiles of 4 cout waves (the tail's 128 couts = 4 x 32)");
         constexpr int BPX = (BP + NT / 4 - 1) / (NT / 4) * (NT / 4);        // X slots per phase (whole DMAs; the surplus reads zeros)
         constexpr int X2_STAGE = BPX * 64, W2_STAGE = 128 * 64, S2 = X2_STAGE + W2_STAGE;
         // ring depth: as many K chunks in flight as the block's LDS holds (<= 8 = every chunk of a 256-channel tile): the tail
@@ -726,8 +726,9 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     const bool stats_ok = kStats && !a.out_f32 && !a.d2s && !a.up2 && (a.Cout % 8) == 0 && (a.y_ps % 8) == 0 && (a.y_bs % 8) == 0 &&
                           (a.stats_mode == 1 || (a.stats_mode == 2 && S == 1 && a.y_ps == a.Cout));
     if (a.stats && !stats_ok) return YOLO_EUNSUPPORTED;
-    // fused tail 1x1 (kernel flag 3): bf16 3x3 tiles that hold all the channels of a pixel (256 couts over 4 cout waves)
-    constexpr bool kTail = sizeof(T) == 2 && KS == 3 && WAVES_C == 4 && WAVES_C * MI * 32 == 256 && RD == 0 && KC == 1 && LEAN == 0;
+    // fused tail 1x1 (kernel flag 3): bf16 3x3 tiles that hold all the channels of a pixel (tiles_c == 1: Cout <= the tile's 128 or
+    // 256 couts) and have four cout waves (each takes 32 of the tail's <= 128 couts)
+    constexpr bool kTail = sizeof(T) == 2 && KS == 3 && WAVES_C == 4 && RD == 0 && KC == 1 && LEAN == 0;       // (128- or 256-cout tiles of 8 waves)
     if (a.t_wp) {
         if (!kTail || a.stats || a.out_f32 || a.up2 || a.d2s || a.tiles_c != 1 || (a.Cout % 32) || a.t_cout < 1 || a.t_cout > 128)
             return YOLO_EUNSUPPORTED;

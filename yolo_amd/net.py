@@ -222,7 +222,7 @@ class CarNet(object):
         return out, oshape
 
     # ---- fused tail 1x1 ---------------------------------------------------------------------------------------------
-    TAIL_ALGOS = {1: (6, 2), 2: (18, 16, 10)}                # 3x3 variants with 256-cout tiles, by stride
+    TAIL_ALGOS = {1: (7, 6, 2), 2: (17, 9, 18, 16, 10)}      # 8-wave 3x3 variants whose tile can hold a pixel's every channel, by stride
 
     def _tail_eligible(self, c3, c1):
         return (self.fuse_tail and self.dtype == 'bf16' and c3.k == 3 and c3.bn and c3.cout <= 256 and c3.cout % 32 == 0
@@ -432,6 +432,54 @@ class CarNet(object):
         self._save_tune_cache()
         return best
 
+    def _stage_ops(self, plan, down, res, x, shp, cat_view, down_done, tdt):
+        """The launch list of one backbone stage (down-sampling conv + residual blocks) appended to `plan`: the fused
+        residual-block kernel wherever it is eligible and chosen; elsewhere a conv carries the next block's 1x1 as a fused tail
+        when the pair is measured faster (_use_tail)."""
+        pre_mid = None
+
+        def tail_for(c3, xin, xshp, resid, j_next, out=None):
+            """(tail tuple, mid tensor) when conv c3 should also compute res[j_next]'s 1x1, else (None, None)."""
+            if j_next >= len(res) or self._res_block_eligible(res[j_next][0], res[j_next][1]):
+                return None, None
+            c1n = res[j_next][0]
+            if not self._tail_eligible(c3, c1n):
+                return None, None
+            ho_, wo_ = c3.out_hw(xshp[1], xshp[2])
+            o3 = out if out is not None else torch.empty((xshp[0], ho_, wo_, c3.cout), dtype=tdt, device=self.device)
+            m = torch.empty((xshp[0], ho_, wo_, c1n.cout), dtype=tdt, device=self.device)
+            if not self._use_tail(c3, c1n, xin, xshp, resid, o3, m):
+                return None, None
+            plan.buffers.append(m)
+            return (c1n, m, False, 0, 0), m
+
+        if not down_done:
+            dout = cat_view if not res else None
+            tl, pre_mid = tail_for(down, x, shp, None, 0) if res else (None, None)
+            x, shp = self._conv_op(plan, down, x, shp, out=dout, tail=tl)
+        for j, (c1, c2) in enumerate(res):
+            last = cat_view is not None and j == len(res) - 1
+            if not last and pre_mid is None and self._use_res_block(c1, c2, x, shp):
+                out = torch.empty(shp, dtype=tdt, device=self.device)
+                plan.buffers.append(out)
+                plan.ops.append(('res_block', self._res_block_payload(c1, c2, x, out, shp), c2.name))
+                plan.act[c2.name] = (out, shp)
+                x = out
+                continue
+            if pre_mid is not None:
+                mid, mshp = pre_mid, shp[:3] + (c1.cout,)
+            else:
+                mid, mshp = self._conv_op(plan, c1, x, shp)
+            tl, pre_mid = tail_for(c2, mid, mshp, x, j + 1, out=cat_view if last else None)
+            x, shp = self._conv_op(plan, c2, mid, mshp, residual=x, out=cat_view if last else None, tail=tl)
+        return x, shp
+
+    def _build_stage(self, plan, down, res, x, shp, cat_view, down_done, tdt):
+        """One backbone stage.  (Round 4 also measured, for the stage where both fusions apply -- D53's stage 1 --, a chain of
+        fused tails INSTEAD of the residual-block kernel: 620-730 us against 448 us per 3x3 + 1x1 pair at 152x152 bs 64, because
+        the 8-wave tiles that can carry a tail are the slow ones for K = 576.  Not offered to the tuner.)"""
+        return self._stage_ops(plan, down, res, x, shp, cat_view, down_done, tdt)
+
     def _build_plan(self, B, H, W):
         g = self.graph
         plan = _Plan()
@@ -479,44 +527,7 @@ class CarNet(object):
                 plan.buffers.append(cat)
                 cats[i] = (cat, up_ch)
                 cat_view = cat[..., up_ch:]
-            # fused tail: the conv in front of a residual block's 1x1 (the stage's down-sampling conv, or the block before's 3x3)
-            # also computes that 1x1 -> `pre_mid` is the block's half-width map, already made
-            pre_mid = None
-
-            def tail_for(c3, xin, xshp, resid, j_next, out=None):
-                """(tail tuple, mid tensor) when conv c3 should also compute res[j_next]'s 1x1, else (None, None)."""
-                if j_next >= len(res) or self._res_block_eligible(res[j_next][0], res[j_next][1]):
-                    return None, None
-                c1n = res[j_next][0]
-                if not self._tail_eligible(c3, c1n):
-                    return None, None
-                ho_, wo_ = c3.out_hw(xshp[1], xshp[2])
-                o3 = out if out is not None else torch.empty((xshp[0], ho_, wo_, c3.cout), dtype=tdt, device=self.device)
-                m = torch.empty((xshp[0], ho_, wo_, c1n.cout), dtype=tdt, device=self.device)
-                if not self._use_tail(c3, c1n, xin, xshp, resid, o3, m):
-                    return None, None
-                plan.buffers.append(m)
-                return (c1n, m, False, 0, 0), m
-
-            if down is not fused_down:
-                dout = cat_view if not res else None
-                tl, pre_mid = tail_for(down, x, shp, None, 0) if res else (None, None)
-                x, shp = self._conv_op(plan, down, x, shp, out=dout, tail=tl)
-            for j, (c1, c2) in enumerate(res):
-                last = cat_view is not None and j == len(res) - 1
-                if not last and pre_mid is None and self._use_res_block(c1, c2, x, shp):
-                    out = torch.empty(shp, dtype=tdt, device=self.device)
-                    plan.buffers.append(out)
-                    plan.ops.append(('res_block', self._res_block_payload(c1, c2, x, out, shp), c2.name))
-                    plan.act[c2.name] = (out, shp)
-                    x = out
-                    continue
-                if pre_mid is not None:
-                    mid, mshp = pre_mid, shp[:3] + (c1.cout,)
-                else:
-                    mid, mshp = self._conv_op(plan, c1, x, shp)
-                tl, pre_mid = tail_for(c2, mid, mshp, x, j + 1, out=cat_view if last else None)
-                x, shp = self._conv_op(plan, c2, mid, mshp, residual=x, out=cat_view if last else None, tail=tl)
+            x, shp = self._build_stage(plan, down, res, x, shp, cat_view, down is fused_down, tdt)
             if i >= nst - g.num_pyramid:
                 routes.append((x, shp, cats.get(i)))
         # merged head buffer (B, sum HW, A*C) float32, scales fine->coarse (car/utils.py:95, car/YOLO.py:841)
