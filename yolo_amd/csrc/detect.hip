@@ -645,6 +645,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
     __shared__ unsigned hist[2048];
     __shared__ unsigned long long keys[NMS_CAP];
     __shared__ float4 cbox[NMS_MAXK];
+    __shared__ unsigned ccls[NMS_MAXK];                  // class of candidate i (its id modulo the candidates per box), taken once
     __shared__ unsigned long long supp[NMS_MAXK][NMS_MAXK / 64];
     __shared__ unsigned sh_sel, sh_above, sh_cnt, sh_eqbase;
     __shared__ unsigned wave_tot[NMS_THREADS / 64];
@@ -772,40 +773,61 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
         const unsigned id = 0xffffffffu - (unsigned)(keys[i] & 0xffffffffull);
         const float* p = rw + (long long)(id / cpb) * C + 1;
         cbox[i] = make_float4(p[0], p[1], p[2], p[3]);
+        ccls[i] = id % cpb;
     }
     __syncthreads();
     const int nwords = ((int)n + 63) / 64;
     for (int e = tid; e < (int)n * nwords; e += NMS_THREADS) {
         const int i = e / nwords, w = e - i * nwords;
-        const unsigned idi = 0xffffffffu - (unsigned)(keys[i] & 0xffffffffull);
-        const unsigned ci = idi % cpb;
+        const unsigned ci = ccls[i];
         const float4 bi = cbox[i];
         unsigned long long m = 0;
-        for (int q = 0; q < 64; ++q) {
+        // (pairs j <= i are never looked at by the walk; the class test first: an integer compare against an IoU)
+        const int q0 = max(0, i + 1 - w * 64), q1 = min(64, (int)n - w * 64);
+        for (int q = q0; q < q1; ++q) {
             const int j = w * 64 + q;
-            if (j > i && j < (int)n) {
-                const unsigned idj = 0xffffffffu - (unsigned)(keys[j] & 0xffffffffull);
-                if (idj % cpb == ci && box_iou(bi, cbox[j]) > iou_thresh) m |= 1ull << q;
-            }
+            if (ccls[j] == ci && box_iou(bi, cbox[j]) > iou_thresh) m |= 1ull << q;
         }
         supp[i][w] = m;
     }
     __syncthreads();
-    // ---- 4. greedy walk by one wavefront ---------------------------------------------------------
+    // ---- 4. greedy walk by one wavefront, 64 candidates at a time ------------------------------------
+    // (round 4) Candidate by candidate the walk is a chain of dependent LDS round trips (broadcast the removed word, test,
+    // fetch the row, OR: ~150 cycles x 400 candidates).  Here lane q holds candidate c*64+q's row for the CURRENT word, the
+    // 64 decisions of a chunk are taken on registers (v_readlane of the rows, wave-uniform), and only then the rows of the
+    // kept candidates are OR-ed into the later words -- independent LDS reads, one wait.  Same greedy order, same result.
     if (wave == 0) {
         unsigned long long removed = 0;     // lane w owns word w (nwords <= 8)
         int nk = 0;
-        for (int i = 0; i < (int)n && nk < post_nms; ++i) {
-            const unsigned long long wd = __shfl(removed, i >> 6, 64);
-            if (!((wd >> (i & 63)) & 1ull)) {
-                if (lane < nwords) removed |= supp[i][lane];
-                if (lane == 0) {
-                    const unsigned long long key = keys[i];
-                    kept[(long long)b * post_nms + nk] = (int)(0xffffffffu - (unsigned)(key & 0xffffffffull));
-                    kept_scores[(long long)b * post_nms + nk] = __uint_as_float((unsigned)(key >> 32));
+        for (int c = 0; c < nwords && nk < post_nms; ++c) {
+            unsigned long long rem = __shfl(removed, c, 64);                 // this chunk's word, final w.r.t. earlier chunks
+            const int i = c * 64 + lane;
+            const unsigned long long own = i < (int)n ? supp[i][c] : 0ull;      // candidate i's row inside its own chunk (bits j > i)
+            const int cnt = min(64, (int)n - c * 64);
+            unsigned long long keptm = 0;
+            int room = post_nms - nk;
+            for (int q = 0; q < cnt && room > 0; ++q) {
+                if (!((rem >> q) & 1ull)) {
+                    keptm |= 1ull << q;
+                    --room;
+                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)own, q), hi = __builtin_amdgcn_readlane((unsigned)(own >> 32), q);
+                    rem |= ((unsigned long long)hi << 32) | lo;
                 }
-                ++nk;
             }
+            // the kept candidates of the chunk: ids / scores in rank order, their rows into the later words
+            if ((keptm >> lane) & 1ull) {
+                const int rank = nk + __popcll(keptm & ((1ull << lane) - 1ull));
+                const unsigned long long key = keys[i];
+                kept[(long long)b * post_nms + rank] = (int)(0xffffffffu - (unsigned)(key & 0xffffffffull));
+                kept_scores[(long long)b * post_nms + rank] = __uint_as_float((unsigned)(key >> 32));
+            }
+            nk += __popcll(keptm);
+            unsigned long long add = 0;
+            for (unsigned long long m = keptm; m; m &= m - 1) {
+                const int q = __ffsll((long long)m) - 1;
+                if (lane < nwords && lane > c) add |= supp[c * 64 + q][lane];
+            }
+            removed |= add;
         }
         for (int q = nk + lane; q < post_nms; q += 64) {
             kept[(long long)b * post_nms + q] = -1;
