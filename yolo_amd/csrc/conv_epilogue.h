@@ -19,6 +19,13 @@
 // (wave tiles of more than 64 couts: the scratch row grows with MI)
 #define YOLO_EPI_WAVE_BYTES_MI(MI) ((MI) <= 2 ? YOLO_EPI_WAVE_BYTES : 32 * ((MI) * 128 + 16) + 4 * 32 * 8)
 
+// The lanes of a wave exchange data through the wave's LDS scratch (the transpose, the offset tables, the statistics
+// columns) with no barrier: LDS operations of one wave execute in order.  The COMPILER does not know that -- to it a lane
+// that did not store to a table still holds what it loaded from it before, and it forwarded slab 0's output offsets to lanes
+// 32-63 of slab 2 in the fused-tail kernels (found by test_conv_tail_1x1_fused_is_bit_identical, round 4).  This fence emits
+// no instruction; it makes every LDS write before it visible to the loads after it as far as the optimiser is concerned.
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("" ::: "memory"); }
+
 // STATS (bf16, transposed path only; the host checks): BatchNorm batch statistics of the training step taken here instead
 // of in a pass of their own over the tensor.  After the transpose a lane owns 8 channels of one pixel row, so the column
 // sums are plain per-lane accumulations over the lane's rows; the 64 / LPR lanes that share the channels are combined
@@ -65,6 +72,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                     f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
                     *(f32x4*)(wsm + l31 * RS + (mi * 32 + 8 * g + 4 * h) * 4) = v;
                 }
+            wave_lds_fence();
 #pragma unroll
             for (int k = 0; k < NPASS2; ++k) {
                 const int row = rowa + k * RPP2;
@@ -149,18 +157,11 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
 #pragma unroll
         for (int e = 0; e < 4; ++e) { sc[4 * q + e] = s4[e]; bi[4 * q + e] = b4[e]; }
     }
-    // The residual loads of slab ni+1 are issued BEFORE slab ni is processed (two register sets), so their latency
-    // hides under the previous slab's transpose/arithmetic/stores -- the phase stamps showed one exposed memory
-    // round trip per 32-pixel slab doubling the epilogue time.  (Prefetching all slabs at once spills on the
-    // 8-wave variants.)  Output offsets go through a small LDS table: the transpose changes which pixel a lane owns.
     long long* ytab = (long long*)(wsm + 32 * RS);
     long long* rtab = ytab + 64;
     const bool has_res = a.res != nullptr;
     // the residual is a dense (N,Ho,Wo,Cout) tensor; when y is a channel slice of a wider buffer its offsets differ
     const bool res_sep = has_res && roff != nullptr && (a.r_ps != a.y_ps || a.r_bs != a.y_bs);
-    long long yo[2][NPASS];
-    uint4 rv[2][NPASS];
-    uint4 sv[2][NPASS];                     // STATS == 2: the forward raw outputs under this lane's gradients
     float ssum[CPL], qsum[CPL], smu[CPL], sis[CPL], sga[CPL], sbe[CPL];
     if constexpr (STATS != 0) {
         static_assert(ES == 2, "statistics epilogue: bf16 only");
@@ -173,9 +174,128 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
             }
         }
     }
+    if (a.buf32) {
+        // ---- (round 4) every load and store of this path is UNCONDITIONAL: a buffer access whose byte offset is -1 for a lane
+        //      that has nothing to read or write (out of range: loads return zeros, stores are dropped).  With the accesses
+        //      inside `if (offset >= 0)` branches the compiler cannot count the memory operations in flight, so its
+        //      s_waitcnt for the residual it needs became vmcnt(0): EVERY pass waited for the stores of the pass before it
+        //      and for the next slab's prefetch (seen in the ISA; the epilogue ran at 2.5x its instruction-issue bound).
+        //      The host sets buf32 when the tensors' extents fit 31-bit byte offsets; the branching form below remains for
+        //      larger ones. ---------------------------------------------------------------------------------------------
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(has_res ? a.res : a.y), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)(STATS == 2 ? a.s_y : a.y), 0, 0x7fffffff, 0x00020000);
+        int yb[2][NPASS];                       // byte offset of the lane's 16-byte piece in y (-1: none)
+        u32x4_t rb[2][NPASS], sb[2][NPASS];
+        auto prefetch_b = [&](int ni) {
+            if (h == 0) ytab[(ni & 1) * 32 + l31] = yoff[ni];
+            if (res_sep && h == 1) rtab[(ni & 1) * 32 + l31] = roff[ni];
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k) {
+                const long long y_ = ytab[(ni & 1) * 32 + row0 + k * RPP];
+                const bool ok = co_ok && y_ >= 0;
+                yb[ni & 1][k] = ok ? (int)((y_ + cofs) * ES) : -1;
+                if (has_res) {
+                    const long long r_ = res_sep ? rtab[(ni & 1) * 32 + row0 + k * RPP] : y_;
+                    rb[ni & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, ok ? (int)((r_ + cofs) * ES) : -1, 0, 0);
+                }
+                if constexpr (STATS == 2) sb[ni & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(srs, yb[ni & 1][k], 0, 0);
+            }
+        };
+        const int up_a = (int)(a.y_ps * ES), up_b = (int)(2LL * a.Wo * a.y_ps * ES);      // (up2: the other pixels of the 2x2 patch)
+        prefetch_b(0);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            if (ni + 1 < NI) prefetch_b(ni + 1);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+                    *(f32x4*)(wsm + l31 * RS + (mi * 32 + 8 * g + 4 * h) * 4) = v;
+                }
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k) {
+                float v[CPL];
+#pragma unroll
+                for (int q = 0; q < CPL / 4; ++q) {
+                    const f32x4 t4 = *(const f32x4*)(wsm + (row0 + k * RPP) * RS + (col * CPL + 4 * q) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * q + e] = t4[e];
+                }
+                if (!ident) {
+#pragma unroll
+                    for (int e = 0; e < CPL; ++e) {
+                        const float t = v[e] * sc[e] + bi[e];
+                        v[e] = leaky(t, slope);
+                    }
+                }
+                const int ob = yb[ni & 1][k];
+                u32x4_t ov;
+                if constexpr (ES == 2) {
+                    if (has_res) {
+                        const uint32_t w[4] = {rb[ni & 1][k].x, rb[ni & 1][k].y, rb[ni & 1][k].z, rb[ni & 1][k].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[2 * q] += bf16_bits_to_f32(w[q] & 0xffffu);
+                            v[2 * q + 1] += bf16_bits_to_f32(w[q] >> 16);
+                        }
+                    }
+                    ov.x = pack_bf16x2(v[0], v[1]); ov.y = pack_bf16x2(v[2], v[3]);
+                    ov.z = pack_bf16x2(v[4], v[5]); ov.w = pack_bf16x2(v[6], v[7]);
+                    if constexpr (STATS != 0) {
+                        const uint32_t ow[4] = {ov.x, ov.y, ov.z, ov.w};
+                        float vr[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) vr[e] = bf16_bits_to_f32((e & 1) ? (ow[e >> 1] >> 16) : (ow[e >> 1] & 0xffffu));
+                        if constexpr (STATS == 1) {
+                            // (lanes past the end of the tensor compute a copy of the tile's first pixel: masked like the store)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float m = ob >= 0 ? vr[e] : 0.f;
+                                ssum[e] += m; qsum[e] += m * m;
+                            }
+                        } else {
+                            const uint32_t yw[4] = {sb[ni & 1][k].x, sb[ni & 1][k].y, sb[ni & 1][k].z, sb[ni & 1][k].w};
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float yv = bf16_bits_to_f32((e & 1) ? (yw[e >> 1] >> 16) : (yw[e >> 1] & 0xffffu));
+                                const float xh = (yv - smu[e]) * sis[e];
+                                const float da = (ob >= 0) ? vr[e] * ((sga[e] * xh + sbe[e]) > 0.f ? 1.f : a.s_slope) : 0.f;
+                                ssum[e] += da; qsum[e] += da * xh;
+                            }
+                        }
+                    }
+                } else {
+                    if (has_res) {
+                        v[0] += __uint_as_float(rb[ni & 1][k].x); v[1] += __uint_as_float(rb[ni & 1][k].y);
+                        v[2] += __uint_as_float(rb[ni & 1][k].z); v[3] += __uint_as_float(rb[ni & 1][k].w);
+                    }
+                    ov.x = __float_as_uint(v[0]); ov.y = __float_as_uint(v[1]); ov.z = __float_as_uint(v[2]); ov.w = __float_as_uint(v[3]);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob, 0, 0);
+                if (a.up2) {                            // the other three pixels of the 2x2 patch (row pitch 2*Wo pixels)
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_a : -1, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_b : -1, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_b + up_a : -1, 0, 0);
+                }
+            }
+        }
+    } else {
+    // The residual loads of slab ni+1 are issued BEFORE slab ni is processed (two register sets), so their latency
+    // hides under the previous slab's transpose/arithmetic/stores -- the phase stamps showed one exposed memory
+    // round trip per 32-pixel slab doubling the epilogue time.  (Prefetching all slabs at once spills on the
+    // 8-wave variants.)  Output offsets go through a small LDS table: the transpose changes which pixel a lane owns.
+    long long yo[2][NPASS];
+    uint4 rv[2][NPASS];
+    uint4 sv[2][NPASS];                     // STATS == 2: the forward raw outputs under this lane's gradients
     auto prefetch = [&](int ni) {
         if (h == 0) ytab[(ni & 1) * 32 + l31] = yoff[ni];
         if (res_sep && h == 1) rtab[(ni & 1) * 32 + l31] = roff[ni];
+        wave_lds_fence();
 #pragma unroll
         for (int k = 0; k < NPASS; ++k) yo[ni & 1][k] = co_ok ? ytab[(ni & 1) * 32 + row0 + k * RPP] : -1;
         if (has_res) {
@@ -205,6 +325,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                 f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
                 *(f32x4*)(wsm + l31 * RS + (mi * 32 + 8 * g + 4 * h) * 4) = v;
             }
+        wave_lds_fence();
 #pragma unroll
         for (int k = 0; k < NPASS; ++k) {
             float v[CPL];
@@ -275,12 +396,14 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
             }
         }
     }
+    }
     if constexpr (STATS != 0) {
         // combine the RPP lanes that share a channel run: every lane parks its 16 sums in the scratch (64 B per lane), then
         // lane o (and o + 64) of the LPR * 16 outputs adds its column and writes it into the wave's partial row
         float* sc4 = (float*)wsm;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { sc4[lane * 16 + e] = ssum[e]; sc4[lane * 16 + 8 + e] = qsum[e]; }
+        wave_lds_fence();
 #pragma unroll
         for (int o = lane; o < LPR * 16; o += 64) {
             const int cx = o >> 4, val = o & 15;

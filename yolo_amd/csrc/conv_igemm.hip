@@ -337,6 +337,12 @@ static int launch_dtype(ConvArgs& a, int ks, int stride, hipStream_t st, const N
     return launch_shape<T, 2, 2, 1, 2>(a, ks, stride, st, nm);                    // 128 px x  64 cout
 }
 
+// A/B knob: YOLO_NO_BUF32 keeps the branching epilogue (conv_epilogue.h)
+static bool conv_no_buf32() {
+    static const bool v = getenv("YOLO_NO_BUF32") != nullptr;
+    return v;
+}
+
 static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* nm);
 
 // Heuristic choice of the pipelined variant for algo == 0 (1 = stay on the generic kernel): minimise
@@ -431,6 +437,14 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     a.t_cout = d->tail_cout; a.t_out_f32 = d->tail_out_f32; a.t_slope = d->tail_slope;
     a.t_y_ps = d->tail_y_pixel_stride ? d->tail_y_pixel_stride : d->tail_cout;
     a.t_y_bs = d->tail_y_batch_stride ? d->tail_y_batch_stride : (long long)a.Ho * a.Wo * a.t_y_ps;
+    {
+        // extents in bytes of everything the epilogue addresses (conv_epilogue.h buf32)
+        const long long lim = 0x7fffffffLL;
+        const long long yb = (long long)a.N * a.y_bs * (a.out_f32 ? 4 : es);
+        const long long rbytes = a.res ? (long long)a.N * a.r_bs * es : 0;
+        const long long tb = a.t_wp ? (long long)a.N * a.t_y_bs * (a.t_out_f32 ? 4 : es) : 0;
+        a.buf32 = (!conv_no_buf32() && yb < lim && rbytes < lim && tb < lim) ? 1 : 0;
+    }
     if (a.t_wp) {
         // fused tail 1x1: pipelined 3x3 variants with 256-cout tiles only (conv_pipe.hip)
         if (!d->tail_y || (!d->tail_scale != !d->tail_bias) || d->tail_cout <= 0 || !(d->tail_slope >= 0.f && d->tail_slope <= 1.f)) return YOLO_EINVAL;
@@ -516,6 +530,7 @@ extern "C" int yolo_conv_dgrad_s2(const yolo_conv_desc* d, void* stream) {
     a.halo_strict = 0;
     a.stats = nullptr; a.stats_mode = 0;
     a.t_wp = nullptr;
+    a.buf32 = (!conv_no_buf32() && (long long)a.N * a.Ho * a.Wo * d->Cout * 2 < 0x7fffffffLL) ? 1 : 0;      // (dx: N x 2Ho x 2Wo x Cout/4, residual = dx)
     if (d->x_pixel_stride || d->upsample2x || d->stats) return YOLO_EUNSUPPORTED;
     a.y_ps = d->Cout / 4;
     a.y_bs = (long long)a.Ho * a.Wo * d->Cout;
