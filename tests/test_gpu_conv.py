@@ -420,10 +420,10 @@ def test_conv_strided_input_and_upsampled_output(lib, cuda, dtype, case):
 
 
 STATS_CASES = [(2, 32, 40, 70, 64, 3, 1), (3, 32, 33, 50, 64, 3, 2), (2, 64, 21, 37, 32, 1, 1), (2, 64, 13, 13, 128, 3, 1), (3, 64, 26, 26, 64, 1, 1), (2, 32, 16, 24, 24, 3, 1), (1, 128, 52, 52, 256, 3, 1),
-               (4, 256, 13, 13, 512, 1, 1), (2, 64, 26, 26, 128, 3, 2), (5, 32, 7, 9, 16, 1, 1), (2, 128, 19, 19, 72, 3, 1)]
+               (4, 256, 13, 13, 512, 1, 1), (2, 64, 26, 26, 128, 3, 2), (5, 32, 7, 9, 16, 1, 1), (2, 128, 19, 19, 72, 3, 1), (2, 128, 26, 26, 256, 1, 1)]
 
 
-STATS_ALGOS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 16, 17, 18, 22, 23, 26]
+STATS_ALGOS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 36, 37, 38, 39]
 
 
 @pytest.mark.parametrize('case,algo,mode', [pytest.param(c, a, m, id='%s-a%d-m%d' % ('x'.join(map(str, c)), a, m))

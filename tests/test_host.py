@@ -174,4 +174,4 @@ def test_conv_variant_eligibility_rules():
                 ok = conv_variant(c, 'bf16', a, stats_mode=m) is not None
                 assert not (ok and m == 2 and c[6] != 1), (c, a, m)
                 n_stats += ok
-    assert n_stats == 181
+    assert n_stats == 246

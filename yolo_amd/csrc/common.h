@@ -46,3 +46,10 @@ static inline int elem_size(int dtype) { return dtype == YOLO_BF16 ? 2 : 4; }
 static inline int chunk_channels(int dtype) { return 64 / elem_size(dtype); }
 // packed weights / scale / bias are padded to a multiple of this many output channels
 #define YOLO_COUT_PAD 256
+// The lanes of a wave exchange data through the wave's LDS scratch (the transpose, the offset tables, the statistics
+// columns) with no barrier: LDS operations of one wave execute in order.  The COMPILER does not know that -- to it a lane
+// that did not store to a table still holds what it loaded from it before, and it forwarded slab 0's output offsets to lanes
+// 32-63 of slab 2 in the fused-tail kernels (found by test_conv_tail_1x1_fused_is_bit_identical, round 4).  This fence emits
+// no instruction; it makes every LDS write before it visible to the loads after it as far as the optimiser is concerned.
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("" ::: "memory"); }
+

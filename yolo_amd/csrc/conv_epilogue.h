@@ -19,13 +19,7 @@
 // (wave tiles of more than 64 couts: the scratch row grows with MI)
 #define YOLO_EPI_WAVE_BYTES_MI(MI) ((MI) <= 2 ? YOLO_EPI_WAVE_BYTES : 32 * ((MI) * 128 + 16) + 4 * 32 * 8)
 
-// The lanes of a wave exchange data through the wave's LDS scratch (the transpose, the offset tables, the statistics
-// columns) with no barrier: LDS operations of one wave execute in order.  The COMPILER does not know that -- to it a lane
-// that did not store to a table still holds what it loaded from it before, and it forwarded slab 0's output offsets to lanes
-// 32-63 of slab 2 in the fused-tail kernels (found by test_conv_tail_1x1_fused_is_bit_identical, round 4).  This fence emits
-// no instruction; it makes every LDS write before it visible to the loads after it as far as the optimiser is concerned.
-__device__ __forceinline__ void wave_lds_fence() { asm volatile("" ::: "memory"); }
-
+// (wave_lds_fence(): common.h)
 // STATS (bf16, transposed path only; the host checks): BatchNorm batch statistics of the training step taken here instead
 // of in a pass of their own over the tensor.  After the transpose a lane owns 8 channels of one pixel row, so the column
 // sums are plain per-lane accumulations over the lane's rows; the 64 / LPR lanes that share the channels are combined

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
                 f32x4 v = {acc[ni][4 * g], acc[ni][4 * g + 1], acc[ni][4 * g + 2], acc[ni][4 * g + 3]};
                 *(f32x4*)(scr + l31 * 144 + (8 * g + 4 * h) * 4) = v;
             }
+            wave_lds_fence();
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 float v[8];
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
         float* sc4 = (float*)scr;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { sc4[lane * 16 + e] = ssum[e]; sc4[lane * 16 + 8 + e] = qsum[e]; }
+        wave_lds_fence();
         float* prow = a.stats + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * WAVES_P + wave_p) * 2 * a.Cout_pad;
         const int cx = lane >> 4, val = lane & 15;       // 4 octets x 16 values = 64 outputs, one per lane
         float t = 0.f;

@@ -241,6 +241,7 @@ __global__ __launch_bounds__(256) void res_block_kernel(ResArgs a) {
                 f32x4 v = {acc[ni][4 * g], acc[ni][4 * g + 1], acc[ni][4 * g + 2], acc[ni][4 * g + 3]};
                 *(f32x4*)(scr + l31 * 144 + (8 * g + 4 * h) * 4) = v;
             }
+            wave_lds_fence();
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int px = (wave_p * NI + ni) * 32 + erow0 + 16 * k;          // output pixel of the strip
@@ -481,6 +482,7 @@ __global__ __launch_bounds__(256) void res_block2_kernel(ResArgs a) {
                     f32x4 v = {acc[r][ni][4 * g], acc[r][ni][4 * g + 1], acc[r][ni][4 * g + 2], acc[r][ni][4 * g + 3]};
                     *(f32x4*)(scr + l31 * 144 + (8 * g + 4 * h) * 4) = v;
                 }
+                wave_lds_fence();
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const int px = (wave_p * NI + ni) * 32 + erow0 + 16 * k;

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
             }
         }
         uint16_t* yrow = y + (((long long)n * H + oy) * W + x0) * Cout;
+        wave_lds_fence();
         // same-wave LDS write -> read -> (next row's) write: in order.  16-byte stores where the row allows it
         // (half the store instructions of the 8-byte version: the kernel is store-issue bound)
         if ((Cout & 7) == 0) {
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
         float* sc4 = (float*)ot;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { sc4[lane * 16 + e] = ssum[e]; sc4[lane * 16 + 8 + e] = qsum[e]; }
+        wave_lds_fence();
         float* prow = part + ((long long)blockIdx.x * 4 + wave) * 2 * Cout;
         for (int o = lane; o < upp16 * 16; o += 64) {
             const int qx = o >> 4, val = o & 15;

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void stem_down_kernel(Args a) {
             f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
             *(f32x4*)(scr + l31 * 144 + (8 * g + 4 * h) * 4) = v;
         }
+        wave_lds_fence();
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             float v[8];
