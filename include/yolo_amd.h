@@ -26,6 +26,11 @@ extern "C" {
 #define YOLO_EINVAL (-1)
 #define YOLO_EUNSUPPORTED (-2)
 
+/* ABI revision = the layout of every struct and the argument list of every entry below.  A caller compiled against another
+ * revision must not call anything else: the library reads the WHOLE yolo_conv_desc on every call (revision 2 appended the
+ * tail_* fields, revision 3 added YOLO_F16), so a shorter struct from an older header would be read past its end.
+ * yolo_amd/lib.py:load() refuses a library whose yolo_version() differs from the YOLO_ABI_VERSION it was written against. */
+#define YOLO_ABI_VERSION 3
 int yolo_version(void);
 
 /* ---- parameter preparation ------------------------------------------------------------- */

@@ -36,7 +36,18 @@ def test_abi_exports_every_declared_symbol(lib):
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.yolo_version() >= 1
+    assert lib.yolo_version() == L.ABI_VERSION
+
+
+def test_shipped_library_reads_no_environment_knobs():
+    """The A/B and ablation switches of tools/ (YOLO_PIPE_PERSIST, YOLO_WW_*, ...) exist only in the lab build (`make lab`,
+    -DYOLO_LAB): the product library must not change behaviour with the environment of whoever loads it, and exports no debug
+    symbol."""
+    from yolo_amd import lib as L
+    blob = open(L.LIB_PATH, 'rb').read()
+    names = set(re.findall(rb'YOLO_[A-Z0-9_]{2,}', blob))
+    assert not names, names
+    assert b'yolo_debug_read_stamps' not in blob
 
 
 def test_abi_host_only_queries(lib):

@@ -24,6 +24,18 @@ struct bf16_t { uint16_t bits; };
         if (e__ != hipSuccess) return (int)e__;              \
     } while (0)
 
+// Lab knobs (A/B switches and ablation sweeps of tools/): the shipped library does not read its caller's environment.  `make lab`
+// builds _lab/libyolo_amd_lab.so with -DYOLO_LAB, where yolo_lab_env(name, dflt) is getenv; in the default build it IS the
+// default (tests/test_host.py checks that no YOLO_* environment name is left in libyolo_amd.so).
+#ifdef YOLO_LAB
+#include <stdlib.h>
+#define YOLO_LAB_ENV(name, dflt) (getenv(name) ? atoll(getenv(name)) : (long long)(dflt))
+#define YOLO_LAB_SET(name) (getenv(name) != nullptr)
+#else
+#define YOLO_LAB_ENV(name, dflt) ((long long)(dflt))
+#define YOLO_LAB_SET(name) (false)
+#endif
+
 __host__ __device__ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 __host__ __device__ inline long long round_up_ll(long long a, long long b) { return (a + b - 1) / b * b; }
 

@@ -339,7 +339,7 @@ static int launch_dtype(ConvArgs& a, int ks, int stride, hipStream_t st, const N
 
 // A/B knob: YOLO_NO_BUF32 keeps the branching epilogue (conv_epilogue.h)
 static bool conv_no_buf32() {
-    static const bool v = getenv("YOLO_NO_BUF32") != nullptr;
+    static const bool v = YOLO_LAB_SET("YOLO_NO_BUF32");
     return v;
 }
 

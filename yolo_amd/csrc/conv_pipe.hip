@@ -19,7 +19,6 @@
 #include "conv_args.h"
 #include "conv_epilogue.h"
 #include <stdio.h>
-#include <stdlib.h>
 #include <type_traits>
 #include <atomic>
 
@@ -668,6 +667,34 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// PERSISTENT blocks (round 4): the grid is ONE resident round -- blocks per CU of the instantiation that is launched x CUs -- and a
+// block walks tiles vb = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8: a block's tiles stay on its XCD).  No
+// workgroup dispatch between the tiles of a CU: +1.8 % on the 608x608 bs 64 pass (1444 tiles per CU slot over a launch), +0.2 % at
+// 416x416 bs 32 (about one round anyway), same-box A/B.  The resident size is cached per DEVICE and per instantiation; a failed
+// query is not cached.  Lab build: YOLO_PIPE_PERSIST=0 = one block per tile (A/B knob), n > 0 = a grid of n blocks.
+template <auto kernel>
+static long long pipe_resident_grid(int threads, long long grid) {
+    static const int persist = (int)YOLO_LAB_ENV("YOLO_PIPE_PERSIST", -1);
+    if (persist == 0) return grid;
+    if (persist > 0) return grid > persist ? persist : grid;
+    constexpr int kMaxDev = 16;
+    static std::atomic<int> resident[kMaxDev];      // (zero-initialised; a race writes the same value twice)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return grid; }
+    int res = (dev >= 0 && dev < kMaxDev) ? resident[dev].load(std::memory_order_relaxed) : 0;
+    if (!res) {
+        int n = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kernel, threads, 0) != hipSuccess || n < 1 ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) {
+            (void)hipGetLastError();
+            return grid;                                // (this launch: one block per tile; the next one asks again)
+        }
+        res = n * (cus & ~7);
+        if (dev >= 0 && dev < kMaxDev) resident[dev].store(res, std::memory_order_relaxed);
+    }
+    return grid > res ? res : grid;
+}
+
 template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1, int RD = 0, int KC = 1, int LEAN = 0>
 static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     constexpr int BP = WAVES_P * NI * 32, BC = WAVES_C * MI * 32;
@@ -696,29 +723,6 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     long long grid = (long long)a.nstrips * a.tiles_per_strip * a.tiles_c;
     if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
     a.vblocks = (int)grid;
-    {
-        // PERSISTENT blocks (round 4): the grid is ONE resident round -- blocks per CU of this instantiation x CUs -- and a block
-        // walks tiles vb = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8: a block's tiles stay on its XCD).  No
-        // workgroup dispatch between the tiles of a CU: +1.8 % on the 608x608 bs 64 pass (1444 tiles per CU slot over a launch),
-        // +0.2 % at 416x416 bs 32 (about one round anyway), same-box A/B.  YOLO_PIPE_PERSIST=0: one block per tile (A/B knob);
-        // n > 0: a grid of n blocks.
-        static const int persist = getenv("YOLO_PIPE_PERSIST") ? atoi(getenv("YOLO_PIPE_PERSIST")) : -1;
-        if (persist > 0 && grid > persist) grid = persist;
-        if (persist < 0) {
-            static std::atomic<int> resident{0};            // (per template instantiation; a race writes the same value twice)
-            int res = resident.load(std::memory_order_relaxed);
-            if (!res) {
-                int n = 0, dev = 0, cus = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC, LEAN>,
-                                                                 WAVES_P * WAVES_C * 64, 0) != hipSuccess || n < 1) n = 1;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
-                (void)hipGetLastError();
-                res = n * (cus & ~7);
-                resident.store(res, std::memory_order_relaxed);
-            }
-            if (grid > res) grid = res;
-        }
-    }
     conv_args_fastdiv(a);
     // BatchNorm statistics in the epilogue: bf16, the transposed store path (conv_epilogue.h), no sub-pixel / up-sampled
     // stores; the data-gradient sums (mode 2) only on stride-1 kernels
@@ -741,34 +745,25 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
         if (name->stats_rows) *name->stats_rows = (a.stats && stats_ok) ? a.nstrips * a.tiles_per_strip * WAVES_P : -1;
         return YOLO_OK;
     }
+#define YOLO_PIPE_LAUNCH(ST_)                                                                                      \
+    do {                                                                                                           \
+        constexpr auto kern = conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC, LEAN, ST_>;     \
+        YOLO_LAUNCH(kern, dim3((unsigned)pipe_resident_grid<kern>(WAVES_P * WAVES_C * 64, grid)),                  \
+                    dim3(WAVES_P * WAVES_C * 64), 0, st, a);                                                       \
+        YOLO_LAUNCH_CHECK();                                                                                       \
+        return YOLO_OK;                                                                                            \
+    } while (0)
     if constexpr (kTail) {
-        if (a.t_wp) {
-            YOLO_LAUNCH((conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC, LEAN, 3>), dim3((unsigned)grid),
-                        dim3(WAVES_P * WAVES_C * 64), 0, st, a);
-            YOLO_LAUNCH_CHECK();
-            return YOLO_OK;
-        }
+        if (a.t_wp) YOLO_PIPE_LAUNCH(3);
     }
     if constexpr (kStats) {
-        if (a.stats && a.stats_mode == 1) {
-            YOLO_LAUNCH((conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC, LEAN, 1>), dim3((unsigned)grid),
-                        dim3(WAVES_P * WAVES_C * 64), 0, st, a);
-            YOLO_LAUNCH_CHECK();
-            return YOLO_OK;
-        }
+        if (a.stats && a.stats_mode == 1) YOLO_PIPE_LAUNCH(1);
         if constexpr (S == 1) {
-            if (a.stats && a.stats_mode == 2) {
-                YOLO_LAUNCH((conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC, LEAN, 2>), dim3((unsigned)grid),
-                            dim3(WAVES_P * WAVES_C * 64), 0, st, a);
-                YOLO_LAUNCH_CHECK();
-                return YOLO_OK;
-            }
+            if (a.stats && a.stats_mode == 2) YOLO_PIPE_LAUNCH(2);
         }
     }
-    YOLO_LAUNCH((conv_pipe_kernel<T, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC, LEAN>), dim3((unsigned)grid),
-                dim3(WAVES_P * WAVES_C * 64), 0, st, a);
-    YOLO_LAUNCH_CHECK();
-    return YOLO_OK;
+    YOLO_PIPE_LAUNCH(0);
+#undef YOLO_PIPE_LAUNCH
 }
 
 // algo ids (yolo_conv_desc.algo): 1 = generic (conv_igemm.hip); pipelined variants:

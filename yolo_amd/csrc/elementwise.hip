@@ -1,7 +1,7 @@
 // HBM-bound plumbing kernels: layout conversion, BN folding, up-sample + concat.
 #include "common.h"
 
-extern "C" int yolo_version(void) { return 1; }
+extern "C" int yolo_version(void) { return YOLO_ABI_VERSION; }
 
 extern "C" int yolo_padded_channels(int C) { return round_up(C, YOLO_COUT_PAD); }
 

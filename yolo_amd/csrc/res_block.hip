@@ -577,11 +577,11 @@ extern "C" int yolo_res_block_fwd(const void* x, const void* w1_packed, const fl
     a.wp2 = (const char*)w2_packed; a.scale2 = scale2; a.bias2 = bias2; a.y = (char*)y;
     a.N = N; a.H = H; a.W = W; a.slope = slope;
     a.Cpad1 = round_up(C / 2, YOLO_COUT_PAD); a.Cpad2 = round_up(C, YOLO_COUT_PAD);
-    static const int dknob = getenv("YOLO_RB_D") ? atoi(getenv("YOLO_RB_D")) : 0;          // (ablation knob: rows in flight)
+    static const int dknob = (int)YOLO_LAB_ENV("YOLO_RB_D", 0);          // (ablation knob: rows in flight)
     // two output rows per step: C = 128 by default (102 against 117 us at 32 x 104 x 104, 474 against 507 at 64 x 152 x 152, same-box
     // probes; C = 64 would drop from two blocks per CU to one: 141 against 122 us).  (A/B knob YOLO_RB_R2: 0 = never, 2 / 3 = both
     // widths with that many register sets)
-    static const int r2knob = getenv("YOLO_RB_R2") ? atoi(getenv("YOLO_RB_R2")) : -1;
+    static const int r2knob = (int)YOLO_LAB_ENV("YOLO_RB_R2", -1);
     hipStream_t st = (hipStream_t)stream;
     if (r2knob == 2) return C == 64 ? launch_res_block2<64, 2>(a, st) : launch_res_block2<128, 2>(a, st);
     if (r2knob == 3) return C == 64 ? launch_res_block2<64, 3>(a, st) : launch_res_block2<128, 3>(a, st);

@@ -762,7 +762,7 @@ static void wgrad_bf16_launch(const uint16_t* dy, const uint16_t* x, float* ws, 
     const int tiles_ci = (Cin + BN - 1) / BN, tiles_co = (Cout + BM - 1) / BM, taps = ksize * ksize;
     const long long chunks = ((long long)N * Ho * Wo + WG_KC - 1) / WG_KC;
     const long long tiles = (long long)tiles_ci * tiles_co * taps;
-    static const long long target_env = getenv("YOLO_PT_TARGET") ? atoll(getenv("YOLO_PT_TARGET")) : 0;   // (ablation knob)
+    static const long long target_env = YOLO_LAB_ENV("YOLO_PT_TARGET", 0);   // (ablation knob)
     const long long target = target_env ? target_env : 768;      // the resident capacity: 3 blocks per CU
     long long slices = target / tiles;                           // rounded DOWN: 774 blocks (one over a full round) cost 212 us where 756 take 185
     // at least 16 K-chunks per slice: every slice ends with a 128x128 atomic tile, which dominated the small 1x1 layers
@@ -1010,13 +1010,13 @@ static void wgrad_strip_launch(const uint16_t* dy, const uint16_t* x, float* dwt
                                int Wo, int Cout, long long ps, hipStream_t st) {
     const int tiles_ci = (Cin + 31) / 32, tiles_co = (Cout + CO_F * 32 - 1) / (CO_F * 32), strips_w = (Wo + 31) / 32;
     const long long bx = (long long)tiles_ci * tiles_co * strips_w * N;
-    static const long long tgt = getenv("YOLO_STRIP_TARGET") ? atoll(getenv("YOLO_STRIP_TARGET")) : 1024;
+    static const long long tgt = YOLO_LAB_ENV("YOLO_STRIP_TARGET", 1024);
     long long slices = (tgt + bx / 2) / bx;                   // ~4 single-wave blocks per CU resident
     if (slices < 1) slices = 1;
     int rps = (int)((Ho + slices - 1) / slices);
     rps = (rps + TH - 1) / TH * TH;
     slices = (Ho + rps - 1) / rps;
-    static const int no_pair = getenv("YOLO_STRIP_NO_PAIR") ? 1 : 0;                                       // (ablation knob)
+    static const int no_pair = YOLO_LAB_SET("YOLO_STRIP_NO_PAIR") ? 1 : 0;                                       // (ablation knob)
     const int pair_xcd = (!no_pair && tiles_co > 1 && bx % (8 * tiles_co) == 0) ? 1 : 0;
     YOLO_LAUNCH((wgrad_strip_kernel<CO_F, S, TH>), dim3((unsigned)bx, (unsigned)slices), dim3(64), 0, st, dy, x, dwt, N, H,
                 W, Cin, Ho, Wo, Cout, ps, tiles_ci, tiles_co, strips_w, rps, pair_xcd);
@@ -1233,7 +1233,7 @@ int wgrad_gemm_dispatch(const void* dy, const void* x, float* dw, long long P, i
 extern "C" int yolo_conv_wgrad(const void* dy, const void* x, float* dw_oihw, int N, int H, int W, int Cin, int Cout,
                                int ksize, int stride, long long dy_pixel_stride, int dtype, void* workspace,
                                void* stream) {
-    static const int legacy = getenv("YOLO_WGRAD_LEGACY") ? 1 : 0;      // (A/B knob: the register-staged kernels only)
+    static const int legacy = YOLO_LAB_SET("YOLO_WGRAD_LEGACY") ? 1 : 0;      // (A/B knob: the register-staged kernels only)
     return yolo_conv_wgrad_algo(dy, x, dw_oihw, N, H, W, Cin, Cout, ksize, stride, dy_pixel_stride, dtype, workspace,
                                 legacy, stream);
 }

@@ -336,7 +336,7 @@ static int wgrad_walk_launch(const void* dy, const void* x, float* dwt, int N, i
     slices = (a.NR + Lw * NW - 1) / (Lw * NW);               // (never more than before: Lw was rounded up)
     a.L = (int)Lw;
     a.nphase = 1 + a.L / 3;
-    static const int dbg = getenv("YOLO_WW_DBG") ? atoi(getenv("YOLO_WW_DBG")) : 0;
+    static const int dbg = (int)YOLO_LAB_ENV("YOLO_WW_DBG", 0);
     a.dbg = dbg;
     const long long grid = per_slice * slices;
     if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
@@ -516,7 +516,7 @@ static int wgrad_gemm_launch(const void* dy, const void* x, float* dw, long long
     // K-slices: ONE block per CU's worth (256).  Every block ends with its 64 KiB tile of atomics onto a gradient of a
     // few MiB: at 768 blocks (what fits) the 11-GFLOP layers took 46-50 us, at 256 they take 29-32, the 45-GFLOP ones 67-72
     // either way (YOLO_WG_SLOTS: the knob of that sweep)
-    static const int slots_env = getenv("YOLO_WG_SLOTS") ? atoi(getenv("YOLO_WG_SLOTS")) : 0;
+    static const int slots_env = (int)YOLO_LAB_ENV("YOLO_WG_SLOTS", 0);
     const int resident = slots_env ? slots_env : 256;
     long long slices = resident / a.ntiles;
     if (slices < 1) slices = 1;
@@ -560,12 +560,12 @@ int wgrad_walk_dispatch(const void* dy, const void* x, float* dwt, int N, int H,
     if (variant == 0) {
         // (maps of at most 16 columns: one 16-column walker covers a row with the same K padding as four narrow ones and a
         //  quarter of the blocks -- 13x13, 1024 -> 2048: 439 -> 390 us, 512 -> 1024: a tie)
-        static const int sc = getenv("YOLO_WW_SC") ? atoi(getenv("YOLO_WW_SC")) : 0;     // (A/B knob)
+        static const int sc = (int)YOLO_LAB_ENV("YOLO_WW_SC", 0);     // (A/B knob)
         variant = sc ? (sc == 16 ? 1 : 2) : (W <= 16 ? 1 : 2);
     }
     // (ablation knobs, read once: YOLO_WW_TARGET = blocks per launch, YOLO_WW_RD = ring depth, YOLO_WW_DBG see WalkArgs)
-    static const int target = getenv("YOLO_WW_TARGET") ? atoi(getenv("YOLO_WW_TARGET")) : 512;    // two blocks per CU
-    static const int rd = getenv("YOLO_WW_RD") ? atoi(getenv("YOLO_WW_RD")) : 4;
+    static const int target = (int)YOLO_LAB_ENV("YOLO_WW_TARGET", 512);    // two blocks per CU
+    static const int rd = (int)YOLO_LAB_ENV("YOLO_WW_RD", 4);
 #define WW_CASE(SC_, RD_) if (variant == (SC_ == 16 ? 1 : 2) && rd == RD_) return wgrad_walk_launch<SC_, RD_>(dy, x, dwt, N, H, W, Cin, Cout, ps, target, st);
     WW_CASE(16, 3) WW_CASE(16, 4) WW_CASE(16, 5) WW_CASE(4, 3) WW_CASE(4, 4) WW_CASE(4, 5)
 #undef WW_CASE

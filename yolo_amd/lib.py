@@ -12,6 +12,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('YOLO_AMD_LIB') or os.path.join(CSRC, 'libyolo_amd.so')   # override: experiment builds
 
 F32, BF16 = 0, 1
+ABI_VERSION = 3            # include/yolo_amd.h: YOLO_ABI_VERSION (the struct layouts below are revision 3's)
 OK, EINVAL, EUNSUPPORTED = 0, -1, -2
 
 
@@ -131,6 +132,10 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    got = lib.yolo_version()
+    if got != ABI_VERSION:
+        raise YoloError('%s is ABI revision %d, this binding is revision %d: the struct layouts differ (rebuild the library: '
+                        'yolo_amd.lib.build())' % (LIB_PATH, got, ABI_VERSION))
     _lib = lib
     return lib
 
