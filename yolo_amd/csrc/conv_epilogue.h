@@ -12,6 +12,15 @@
 // Rounding order is unchanged: fp32 (acc*scale+bias) -> LeakyReLU -> + residual (fp32) -> round.
 #pragma once
 #include "conv_args.h"
+#include <type_traits>
+#include <utility>
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<N - 1>) -- the body's indices are constants whatever the
+// unroller's size limits say (an accumulator array indexed by a loop variable the unroller gave up on goes to scratch)
+template <typename F, int... I>
+__device__ __forceinline__ void yolo_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void yolo_static_for(F&& f) { yolo_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // bytes of LDS scratch one wave needs (max over MI in {1,2}): 32 rows x (64*4+16) + 2 x 32 x 8 (output offsets) + 2 x 32 x 8
 // (residual offsets, when the residual's strides differ from the output's)
@@ -125,6 +134,105 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
             }
         }
         return;
+    }
+
+    // ---- (round 5) bf16, no statistics: the transpose stays in REGISTERS ------------------------------------------------
+    // A lane holds couts 8g + 4h + (0..3) of its pixel for g = 0..3: the half-waves share every 8-cout run.  One
+    // v_permlane32_swap per fp32 register of a group pair (2j, 2j+1) hands the upper half's part of group 2j to the lower
+    // lane and the lower half's part of group 2j+1 to the upper lane; afterwards lane (l31, h) owns the 8 consecutive couts
+    // 16j + 8h .. + 7 of pixel l31 = 16 contiguous output bytes, exactly what the LDS transpose below produced, without the
+    // scratch round trip (8 ds_write_b128 + 8 ds_read_b128 + the offset table per 32-pixel slab and its latency chain: the
+    // phase stamps had this epilogue at 2-2.5x its issue bound, NOTES 0).  The arithmetic per value and its order are those
+    // of the transposed path (fp32 scale / bias -> LeakyReLU -> + residual -> one rounding): bit-identical outputs.  The
+    // lane keeps its own pixel, so the output offsets need no table.  Groups (mi, j) are walked outermost: scale / bias of
+    // the lane's 8 couts are loaded once per group, the residual pieces of group k + 1 are in flight under group k.
+    // (MI = 4, the one-wave-per-SIMD 128 x 128 wave tile with all 512 registers in use: this form compiled to 10 KB of scratch per
+    //  lane whatever the schedule -- it keeps the LDS transpose)
+    if constexpr (ES == 2 && STATS == 0 && MI <= 2) {
+        if (a.buf32 == 2) {
+            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, 0x7fffffff, 0x00020000);
+            const bool has_res = a.res != nullptr;
+            const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(has_res ? a.res : a.y), 0, 0x7fffffff, 0x00020000);
+            const bool res_sep = has_res && roff != nullptr && (a.r_ps != a.y_ps || a.r_bs != a.y_bs);
+            const int up_a = (int)(a.y_ps * 2), up_b = (int)(2LL * a.Wo * a.y_ps * 2);
+            constexpr int NG = MI * 2;                                  // groups of 16 couts (8 per half-wave)
+            auto group_cofs = [&](int gi, bool& ok) __attribute__((always_inline)) -> long long {
+                const int co = co_w + gi * 16 + 8 * h;
+                ok = co < a.Cout;
+                if (a.d2s) {
+                    const int C4 = a.Cout >> 2, ph = co / C4;
+                    return (long long)((ph >> 1) * 2 * a.Wo + (ph & 1)) * C4 + (co - ph * C4);
+                }
+                return co;
+            };
+            u32x4_t rb[2][NI];
+            f32x4 sb[2][4];                                             // scale (2 x 4) and bias (2 x 4) of the lane's 8 couts
+            // the loads of group gi: its scale / bias first, then its residual pieces -- issued one group ahead, so a group waits
+            // for nothing that was requested after its own operands
+            auto prefetch_g = [&](auto gi_c) __attribute__((always_inline)) {
+                constexpr int gi = decltype(gi_c)::value;
+                bool ok;
+                const long long cf = group_cofs(gi, ok);
+                const int co = co_w + gi * 16 + 8 * h;
+                if (!ident) {
+                    sb[gi & 1][0] = *(const f32x4*)(a.scale + co); sb[gi & 1][1] = *(const f32x4*)(a.scale + co + 4);     // (arrays are padded to the cout tile)
+                    sb[gi & 1][2] = *(const f32x4*)(a.bias + co); sb[gi & 1][3] = *(const f32x4*)(a.bias + co + 4);
+                }
+                if (has_res) {
+                    yolo_static_for<NI>([&](auto ni_c) __attribute__((always_inline)) {
+                        constexpr int ni = decltype(ni_c)::value;
+                        const long long r_ = res_sep ? roff[ni] : yoff[ni];
+                        rb[gi & 1][ni] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (ok && yoff[ni] >= 0) ? (int)((r_ + cf) * 2) : -1, 0, 0);
+                    });
+                }
+            };
+            prefetch_g(std::integral_constant<int, 0>{});
+            yolo_static_for<NG>([&](auto gi_c) __attribute__((always_inline)) {
+                constexpr int gi = decltype(gi_c)::value;
+                constexpr int mi = gi >> 1, j = gi & 1;
+                if constexpr (gi + 1 < NG) prefetch_g(std::integral_constant<int, gi + 1>{});
+                bool ok;
+                const long long cf = group_cofs(gi, ok);
+                const f32x4 s0 = sb[gi & 1][0], s1 = sb[gi & 1][1], b0 = sb[gi & 1][2], b1 = sb[gi & 1][3];
+                yolo_static_for<NI>([&](auto ni_c) __attribute__((always_inline)) {
+                    constexpr int ni = decltype(ni_c)::value;
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mi][ni][8 * j + e]),
+                                                                        __float_as_uint(acc[mi][ni][8 * j + 4 + e]), false, false);
+                        v[e] = __uint_as_float(r[0]); v[4 + e] = __uint_as_float(r[1]);
+                    }
+                    if (!ident) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t0 = v[e] * s0[e] + b0[e], t1 = v[4 + e] * s1[e] + b1[e];
+                            v[e] = leaky(t0, slope); v[4 + e] = leaky(t1, slope);
+                        }
+                    }
+                    if (has_res) {
+                        const uint32_t w[4] = {rb[gi & 1][ni].x, rb[gi & 1][ni].y, rb[gi & 1][ni].z, rb[gi & 1][ni].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[2 * q] += bf16_bits_to_f32(w[q] & 0xffffu);
+                            v[2 * q + 1] += bf16_bits_to_f32(w[q] >> 16);
+                        }
+                    }
+                    u32x4_t ov;
+                    ov.x = pack_bf16x2(v[0], v[1]); ov.y = pack_bf16x2(v[2], v[3]);
+                    ov.z = pack_bf16x2(v[4], v[5]); ov.w = pack_bf16x2(v[6], v[7]);
+                    const int ob = (ok && yoff[ni] >= 0) ? (int)((yoff[ni] + cf) * 2) : -1;
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob, 0, 0);
+                    if (a.up2) {                            // the other three pixels of the 2x2 patch (row pitch 2*Wo pixels)
+                        __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_a : -1, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_b : -1, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_b + up_a : -1, 0, 0);
+                    }
+                });
+            });
+            return;
+        }
     }
 
     // ---- transposed path ---------------------------------------------------------------------------

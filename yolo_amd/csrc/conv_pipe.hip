@@ -92,8 +92,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // they are interleaved between the MFMAs, and the second half of the waves (which shares SIMDs with
 // the first half) issues them at shifted positions, so a wave stuck in a DMA issue is covered by its
 // SIMD partner's MFMAs.
+// Second launch bound = waves per SIMD the register allocation must leave room for.  The 4-wave blocks are meant to be
+// co-resident (two per CU; four for the 32-accumulator tiles): without the bound the allocator sees a 512-register budget and the
+// in-register epilogue's accumulator copies cost the second block (the 192 x 128 tile: 236 -> 308 registers, measured in the
+// metadata).  The 128 x 128 wave tile (W1) is built for one wave per SIMD.
+template <int NW, int MI, int NI, int STATS> struct PipeMinWaves {       // (STATS 2, the data-gradient sums: ~100 more live values, unbounded as before)
+    static constexpr int value = (NW != 4 || STATS == 2) ? 1 : (MI == 4 ? 1 : (MI * NI * 16 <= 32 ? 4 : 2));
+};
 template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1, int RD = 0, int KC = 1, int LEAN = 0, int STATS = 0>
-__global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvArgs a) {
+__global__ __launch_bounds__(WAVES_P* WAVES_C * 64, (PipeMinWaves<WAVES_P * WAVES_C, MI, NI, STATS>::value)) void conv_pipe_kernel(ConvArgs a) {
     constexpr int PT = 1;
     constexpr int NW = WAVES_P * WAVES_C;
     constexpr int NT = NW * 64;
