@@ -165,42 +165,27 @@ def cpu_baseline(size, seconds=6.0, batch=8):
                        % (size[0], size[1], batch, best[2], best[3], json.dumps(tried), ncpu))
 
 
-def pmc_traffic(kernel, B, size):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/*_pmc_traffic.json,
-    made by tools/pmc_traffic.py in separate --pmc passes: FETCH_SIZE doubled per the gfx950 note of
-    MI355X_MICROARCH.md, + WRITE_SIZE), or None when no profile of this kernel / workload is committed."""
+def pmc_traffic(kernel, B, size, plan_md5, launches_per_step):
+    """HBM bytes per launch of `kernel` from a committed rocprofv3 PMC summary (profiles/*_pmc_traffic.json, made by
+    tools/pmc_traffic.py from separate --pmc passes: FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, + WRITE_SIZE)
+    -- but only from a summary of the SAME launch plan: same workload, same plan_md5 (md5 over the [(op, kernel)] launch list)
+    and the same number of launches of this kernel per step.  A kernel NAME alone does not identify the layers it ran (round 4:
+    the tuner gave the name 7 layers on one box and 14 on another).  -> (bytes, file, note)"""
     import glob
+    seen = []
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')), reverse=True):
         with open(path) as f:
             prof = json.load(f)
         if prof.get('workload') != [B, size[0], size[1]]:
             continue
         ent = prof.get('kernels', {}).get(kernel)
-        if ent:
-            return int(ent['hbm_bytes_per_launch']), os.path.relpath(path, ROOT), None
-    # no committed PMC pass holds this instantiation (the tuner picked another dominant kernel on this box): say so and
-    # name the nearest profiled instantiation of the same kernel template instead of a bare null
-    import re
-    args = lambda n: [a.strip() for a in re.sub(r'^[^<]*<|>\(.*$', '', n).split(',')]
-    fam = kernel.split('<')[0]
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')), reverse=True):
-        with open(path) as f:
-            prof = json.load(f)
-        if prof.get('workload') != [B, size[0], size[1]]:
-            continue
-        for name, ent in prof.get('kernels', {}).items():
-            if name.split('<')[0] != fam or '<' not in name:
-                continue
-            same = sum(1 for a, b in zip(args(name), args(kernel)) if a == b)
-            if best is None or same > best[0]:
-                best = (same, name, int(ent['hbm_bytes_per_launch']), os.path.relpath(path, ROOT))
-        if best:
-            break
-    note = 'no committed PMC pass of this workload holds the dominant kernel of this run'
-    if best:
-        note += '; nearest profiled instantiation: %s = %d bytes per launch (%s)' % (best[1], best[2], best[3])
-    return None, None, note
+        rel = os.path.relpath(path, ROOT)
+        if prof.get('plan_md5') == plan_md5 and ent and ent.get('launches_per_step') == launches_per_step:
+            return int(ent['hbm_bytes_per_launch']), rel, None
+        seen.append('%s (plan %s%s)' % (rel, prof.get('plan_md5'), '' if not ent else ', %s launches of this kernel per step'
+                                        % ent.get('launches_per_step')))
+    return None, None, ('no committed PMC pass describes this launch plan (plan_md5 %s, %d launches of the dominant kernel per step); '
+                        'passes of this workload on file: %s' % (plan_md5, launches_per_step, '; '.join(seen[:3]) or 'none'))
 
 
 def synthetic_labels(batch, seed, num_class=24):
@@ -231,6 +216,8 @@ def train_pass(args, spec, size, B, rank, world, dev, dist, steps, warmup, prehe
     net = CarNet(spec, dtype=args.dtype, device=dev, tune='measure', tune_cache=args.tune_cache,
                  fuse_stem=not args.no_fuse_stem).initialize(seed=1234)
     tr = Trainer(net, size)
+    if getattr(args, 'plan_state', None) is not None:
+        tr.load_tuning_state(args.plan_state)
     gen = torch.Generator(device='cpu').manual_seed(100 + rank)
     x = torch.rand((B, 3) + size, generator=gen).to(dev)
     lab = torch.from_numpy(synthetic_labels(B, 3 + rank)).to(dev)
@@ -334,10 +321,22 @@ def train_pass(args, spec, size, B, rank, world, dev, dist, steps, warmup, prehe
         'exchange': exch,
     }
     res.update(tinfo)
+    res['plan'] = plan_report(args, tr.tuning_state())
     if dist is not None:
         res['per_rank_ms_per_step'] = [round(t_ / steps * 1e3, 4) for t_ in per_rank]
         res['tuning_identical_across_ranks'] = bool(tuning_same)
     return res
+
+
+def plan_report(args, state):
+    """What pinned the kernels of a pass: the plan file (and how many shapes it did not hold and were measured live), or the
+    plan this box measured for itself (--tune measure)."""
+    from yolo_amd import plans
+    info = dict(getattr(args, 'plan_info', None) or {'file': None, 'mode': 'measure'})
+    base = getattr(args, 'plan_state', None)
+    info['measured_live'] = plans.new_keys(state, base) if base is not None else sum(len(state.get(s_, {})) for s_ in plans.SECTIONS)
+    info['md5_in_force'] = plans.md5(state)
+    return info
 
 
 def bench_train(args, spec, size, B, rank, world, dev, dist):
@@ -464,6 +463,13 @@ def main():
     ap.add_argument('--no-fuse-tail', action='store_true', help='never fuse a 1x1 convolution into the 3x3 in front of it (A/B)')
     ap.add_argument('--no-side-stream', action='store_true', help='run the head tip/output convolutions on the main stream (A/B)')
     ap.add_argument('--tune-cache', default=None, help='JSON file remembering the measured per-layer kernel choices')
+    ap.add_argument('--plan', default=None,
+                    help='committed launch plan (yolo_amd/plans.py; default profiles/plan.json): the kernel variant of every layer shape, so '
+                         'that this line, the rocprofv3 kernel trace and the PMC passes under profiles/ describe the same launches')
+    ap.add_argument('--tune', default='plan', choices=['plan', 'measure'],
+                    help="'plan' (default): launch the committed plan's kernels; a shape it does not hold is measured live and counted in "
+                         "plan.measured_live.  'measure': ignore the plan, time every variant on this box (prints the plan it arrives at "
+                         "as plan.md5; tools/make_plan.py writes one)")
     ap.add_argument('--post', default='top1', choices=['top1', 'nms', 'none'],
                     help="post-processing inside the timed step: 'top1' = the reference's predict (decode + per-image arg-max + D2H of"
                          " the rows); 'nms' = decode + per-class greedy NMS (BASELINE configs[4]); 'none' = the network forward alone")
@@ -526,14 +532,22 @@ def main():
     from yolo_amd.spec import darknet53_spec
     from yolo_amd import parallel
 
+    from yolo_amd import plans
     spec = darknet53_spec()
     size = (args.size, args.size)
     B = args.batch or (64 if args.mode == 'train' else 32)
+    plan_path = args.plan or plans.DEFAULT
+    args.plan_state, args.plan_info = None, {'file': None, 'mode': args.tune}
+    if args.tune == 'plan' and os.path.exists(plan_path):
+        args.plan_state, meta = plans.load(plan_path)
+        args.plan_info.update(file=os.path.relpath(plan_path, ROOT), md5=meta.get('md5'), commit=meta.get('commit'))
     if args.mode == 'train':
         return bench_train(args, spec, size, B, rank, world, dev, dist)
     net = CarNet(spec, dtype=args.dtype, device=dev, tune='measure', tune_cache=args.tune_cache,
                  fuse_stem=not args.no_fuse_stem, side_stream=not args.no_side_stream, fuse_concat=not args.no_fuse_concat,
                  fuse_res=not args.no_fuse_res, fuse_tail=not args.no_fuse_tail).initialize(seed=1234)
+    if args.plan_state is not None:
+        net.load_tuning_state(args.plan_state)
     net.prepare()
     det = Detector(spec, size, net.graph.steps(), device=dev)
     gen = torch.Generator(device='cpu').manual_seed(100 + rank)
@@ -571,14 +585,17 @@ def main():
     # --warmup 0: one untimed step still runs first (as the training pass does): the first forward of a shape builds its launch
     # plan and MEASURES the kernel variants -- set-up, not a step; reported as `setup_steps`
     setup_steps = 1 if args.warmup == 0 else 0
-    el, per_rank = over_ranks(timed_pass(net, det, x, args.post, args.steps, args.warmup + setup_steps, fence)[0])
+    # `value` times the reference's LITERAL predict (car/YOLO.py:568-597): the rows are copied to the host by a blocking copy in
+    # every step, as rounds 1-3 measured it; the pipelined copy (pinned buffers, two deep) is `value_async_predict`
+    post_main = 'top1_blocking' if args.post == 'top1' else args.post
+    el, per_rank = over_ranks(timed_pass(net, det, x, post_main, args.steps, args.warmup + setup_steps, fence)[0])
     ms_per_step = el / args.steps * 1e3
     value = world * B * args.steps / el
     # the same K-step pass four more times: `value` stays the first pass (what the driver's clock brackets), the median of
     # the five tells a 1-3 % change from run-to-run noise
-    reps = [value] + [world * B * args.steps / over_ranks(timed_pass(net, det, x, args.post, args.steps, 0, fence)[0])[0]
+    reps = [value] + [world * B * args.steps / over_ranks(timed_pass(net, det, x, post_main, args.steps, 0, fence)[0])[0]
                       for _ in range(0 if args.no_repeats else 4)]
-    post_name = {'nms': 'per-class NMS', 'top1': 'top-1 + D2H of the rows', 'none': 'nothing (forward alone)'}[args.post]
+    post_name = {'nms': 'per-class NMS', 'top1': 'top-1 + blocking D2H of the rows', 'none': 'nothing (forward alone)'}[args.post]
 
     out = {
         'metric': 'images/sec at %dx%d bs=%d per GPU (Darknet-53 spec + 3-scale YOLO head forward, anchor '
@@ -596,18 +613,21 @@ def main():
     out['value_median'] = round(float(np.median(reps)), 2)
     out['value_repeats'] = [round(v, 1) for v in reps]
     if args.post == 'top1' and not args.no_repeats:
-        # the same pass with the reference's literal predict(): a blocking .cpu() of the rows in every step
-        elb = over_ranks(timed_pass(net, det, x, 'top1_blocking', args.steps, 0, fence)[0])[0]
-        out['value_blocking_predict'] = round(world * B * args.steps / elb, 2)
+        # the same pass with the rows copied asynchronously into pinned memory, two buffers deep (Detector.predict_async): the
+        # copy of step i overlaps the launches of step i + 1 -- a host-side gain, not kernel work, hence not `value`
+        ela = over_ranks(timed_pass(net, det, x, 'top1', args.steps, 0, fence)[0])[0]
+        out['value_async_predict'] = round(world * B * args.steps / ela, 2)
+    # md5 over [(op, kernel instantiation)] of the launch plan that ran: what a kernel trace / PMC pass must carry to describe THIS run
+    out['plan_md5'] = plan_md5
     if dist is not None:
         # stragglers and rank-dependent plans, visible the day a node exists: every rank's own time for the K steps and
         # whether all ranks launch the same kernel instantiations (rank 0 measured, the others adopted its choices)
         out['per_rank_ms_per_step'] = [round(t / args.steps * 1e3, 4) for t in per_rank]
         out['rank_ms_per_step_min_max'] = [round(min(per_rank) / args.steps * 1e3, 4), round(max(per_rank) / args.steps * 1e3, 4)]
         out['plans_identical_across_ranks'] = bool(plans_same)
-        out['plan_md5'] = plan_md5
     if shared:
         out['shared_gpu_test'] = 'TEST ONLY: %d ranks share %d GPU(s) over gloo -- not an N-GPU measurement' % (world, torch.cuda.device_count())
+    out['plan'] = plan_report(args, net.tuning_state())
     out['net_tflops'] = round(net.graph.flops(*size) * value / 1e12 / world, 1)          # per GPU
     out['net_frac'] = round(out['net_tflops'] / MFMA_PEAK_TFLOPS[args.dtype], 4)           # whole pass vs the dense MFMA peak
     out['net_frac_median'] = round(net.graph.flops(*size) * out['value_median'] / 1e12 / world / MFMA_PEAK_TFLOPS[args.dtype], 4)
@@ -633,11 +653,16 @@ def main():
         tsec, nl, fl = agg[dom]
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         ach = fl / tsec / 1e12
-        traffic, traffic_src, traffic_note = pmc_traffic(dom, B, size)
+        traffic, traffic_src, traffic_note = pmc_traffic(dom, B, size, plan_md5, nl // args.steps)
+        nbytes = net.plan_bytes(B, *size)
+        alg_bytes = sum(nbytes.get(n, 0) for n, (k, f) in info.items() if k == dom) // max(nl // args.steps, 1)
         out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s',
                            'frac': round(ach / peak, 4), 'traffic': traffic,
-                           # (a committed rocprofv3 --pmc pass of this workload, not a counter read of this run)
-                           'traffic_source': traffic_src, 'kernel': dom,
+                           # (a committed rocprofv3 --pmc pass of THIS launch plan, not a counter read of this run)
+                           'traffic_source': traffic_src,
+                           # input + output (+ residual) + weights once, mean over this kernel's launches: what `traffic` would be
+                           # with no re-fetch
+                           'algorithmic_bytes': int(alg_bytes), 'kernel': dom,
                            'launches_per_step': nl // args.steps,
                            'avg_launch_us': round(tsec / nl * 1e6, 2),
                            'flops_per_launch': fl // nl}
@@ -724,14 +749,26 @@ def main():
                 kt, wt, heat = max(args.steps, int(0.4 * args.sustain_steps)), max(args.warmup, 20), 2.0
             else:
                 kt, wt, heat = max(args.steps // 2, 5), 2, 0.0
-            t = train_pass(args, spec, size, 64, rank, world, dev, dist, kt, wt, preheat_s=heat,
+            # N = 1: BASELINE configs[2], 64 images on the GPU.  N > 1: configs[3] = the SAME training loop at GLOBAL batch 256
+            # sharded over the ranks (car/YOLO.py:372-396, yolo_gluon.py:100-124: 8 x 32) -- 256 // N images per GPU, strong
+            # scaling of that job; the 64-per-GPU pass (weak scaling of configs[2]) is the extra key `train_416_bs64_weak`.
+            Bt = 64 if world == 1 else max(256 // world, 1)
+            keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'preheat_s', 'sustained_s', 'ms_per_step', 'net_tflops',
+                    'net_frac', 'final_losses', 'exchange', 'sclk_mhz', 'power_w', 'telemetry_samples', 'telemetry_source',
+                    'per_rank_ms_per_step', 'tuning_identical_across_ranks', 'plan')
+            t = train_pass(args, spec, size, Bt, rank, world, dev, dist, kt, wt, preheat_s=heat,
                            telemetry=Telemetry(local) if (rank == 0 and sustain) else None)
-            out['train_416_bs64'] = {k: t[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'preheat_s', 'sustained_s',
-                                                       'ms_per_step', 'net_tflops', 'net_frac', 'final_losses', 'exchange', 'sclk_mhz',
-                                                       'power_w', 'telemetry_samples', 'telemetry_source', 'per_rank_ms_per_step',
-                                                       'tuning_identical_across_ranks') if k in t}
+            out['train_416_bs64'] = {k: t[k] for k in keep if k in t}
             out['train_416_bs64']['workload'] = t['config']['workload']
             out['train_416_bs64']['global_batch'] = t['config']['global_batch']
+            out['train_416_bs64']['batch_per_gpu'] = Bt
+            if world > 1 and Bt != 64:
+                torch.cuda.empty_cache()
+                t = train_pass(args, spec, size, 64, rank, world, dev, dist, max(kt // 2, 5), wt, preheat_s=0.0)
+                out['train_416_bs64_weak'] = {k: t[k] for k in keep if k in t}
+                out['train_416_bs64_weak']['workload'] = t['config']['workload'] + ' (64 per GPU: weak scaling of configs[2])'
+                out['train_416_bs64_weak']['global_batch'] = t['config']['global_batch']
+                out['train_416_bs64_weak']['batch_per_gpu'] = 64
         except Exception as e:                                   # (a rank-local failure: the other ranks meet the watchdog)
             msg = '%s: %s' % (type(e).__name__, e)
             out['train_416_bs64'] = {'error': msg, 'n_gpus': world}

@@ -1,42 +1,43 @@
 #!/bin/bash
 # Regenerates the measurement artefacts behind profiles/ on a GPU box (run through gpurun from the repo root):
-#   bash tools/refresh_profiles.sh <tag>      -> gpurun_out/<tag>_*  (copy the ones to keep into profiles/)
-# 1. un-profiled bench lines (608 bs64, 608 bs64 + NMS, training bs64; the 416 bs32 headline line after step 3)
-# 2. rocprofv3 --kernel-trace --stats of the headline bench with the kernel choices pinned by a tune cache
-# 3. two PMC passes (FETCH_SIZE / WRITE_SIZE, one counter per pass) summarised by tools/pmc_traffic.py
-# 4. rocprofv3 kernel stats of the training step
+#   bash tools/refresh_profiles.sh <tag> <prefix>     -> gpurun_out/<prefix>_*   (gpurun merges gpurun_out/ back; then: cp gpurun_out/<prefix>_* profiles/)
+# EVERY command launches the COMMITTED plan (profiles/plan.json, bench.py --tune plan = the default): the bench lines, the
+# rocprofv3 kernel traces and the PMC passes describe the same launches (plan_md5 is carried into the PMC summaries and checked
+# by bench.py before it quotes roofline.traffic).  Per workload W in {416 bs 32 (headline), 608 bs 64 (north star)}:
+#   kernel trace + stats -> <prefix>[_608]_kernel_stats.csv      two PMC passes (FETCH_SIZE | WRITE_SIZE) -> _pmc_traffic.json
+#   one PMC pass (MFMA busy, GUI active, wave cycles)            -> _pmc_mfma.json          bench line last (traffic filled in)
+# then the training step: bench line + kernel stats.
 set -u
-TAG=${1:-r02}
-PT=${2:-r02}            # prefix of the copies under profiles/
+TAG=${1:-r05}
+PT=${2:-r05}
 OUT=gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-TC=$OUT/${TAG}_tune_416.json
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --tune-cache $TC > $OUT/${TAG}_bench_first.json 2> $OUT/${TAG}_bench.err     # (measures the kernel choices; the headline line is printed at the end)
-python bench.py --steps 10 --warmup 3 --size 608 --batch 64 --no-cpu-baseline --tune-cache $OUT/${TAG}_tune_608.json > $OUT/${TAG}_bench_608.json 2>> $OUT/${TAG}_bench.err
-python bench.py --steps 10 --warmup 3 --size 608 --batch 64 --post nms --no-cpu-baseline --no-roofline --tune-cache $OUT/${TAG}_tune_608.json > $OUT/${TAG}_bench_608_nms.json 2>> $OUT/${TAG}_bench.err
-python bench.py --mode train --steps 10 --warmup 2 --tune-cache $OUT/${TAG}_tune_train.json > $OUT/${TAG}_train_bench.json 2>> $OUT/${TAG}_bench.err
-# profiled passes (kernel choices come from the caches written above: no autotune launches in the trace)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o p -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-northstar --no-train-key --no-f32-key --no-repeats --tune-cache $TC > $OUT/${TAG}_bench_profiled.json 2>> $OUT/${TAG}_bench.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_f -o p -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-northstar --no-train-key --no-f32-key --no-repeats --tune-cache $TC > /dev/null 2>> $OUT/${TAG}_bench.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_w -o p -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-northstar --no-train-key --no-f32-key --no-repeats --tune-cache $TC > /dev/null 2>> $OUT/${TAG}_bench.err
-python tools/pmc_traffic.py $OUT/${TAG}_pmc_f $OUT/${TAG}_pmc_w 32 416 $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_summary.txt 2>&1
-# the headline line last, so that its roofline.traffic comes from THIS box's PMC passes (bench.py reads profiles/*_pmc_traffic.json)
-cp $OUT/${TAG}_pmc_traffic.json profiles/${PT}_pmc_traffic.json
-python bench.py --steps 20 --warmup 5 --tune-cache $TC > $OUT/${TAG}_bench.json 2>> $OUT/${TAG}_bench.err
-# the same two passes for the 608x608 bs 64 shape, then its bench line again with roofline.traffic filled in
-T6=$OUT/${TAG}_tune_608.json
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc6_f -o p -- python bench.py --steps 3 --warmup 2 --size 608 --batch 64 --no-cpu-baseline --no-roofline --no-northstar --no-train-key --no-f32-key --no-repeats --tune-cache $T6 > /dev/null 2>> $OUT/${TAG}_bench.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc6_w -o p -- python bench.py --steps 3 --warmup 2 --size 608 --batch 64 --no-cpu-baseline --no-roofline --no-northstar --no-train-key --no-f32-key --no-repeats --tune-cache $T6 > /dev/null 2>> $OUT/${TAG}_bench.err
-python tools/pmc_traffic.py $OUT/${TAG}_pmc6_f $OUT/${TAG}_pmc6_w 64 608 $OUT/${TAG}_608_pmc_traffic.json >> $OUT/${TAG}_pmc_summary.txt 2>&1
-cp $OUT/${TAG}_608_pmc_traffic.json profiles/${PT}_608_pmc_traffic.json
-python bench.py --steps 10 --warmup 3 --size 608 --batch 64 --no-cpu-baseline --tune-cache $T6 > $OUT/${TAG}_bench_608.json 2>> $OUT/${TAG}_bench.err
-rm -rf $OUT/${TAG}_pmc6_f $OUT/${TAG}_pmc6_w
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_m -o p -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-northstar --no-train-key --no-f32-key --no-repeats --tune-cache $TC > /dev/null 2>> $OUT/${TAG}_bench.err
-python tools/pmc_mfma.py $OUT/${TAG}_pmc_m $OUT/${TAG}_pmc_mfma.json >> $OUT/${TAG}_pmc_summary.txt 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_train -o p -- python bench.py --mode train --steps 10 --warmup 2 --tune-cache $OUT/${TAG}_tune_train.json > $OUT/${TAG}_train_bench_profiled.json 2>> $OUT/${TAG}_bench.err
-cp $OUT/${TAG}_prof/p_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv 2>/dev/null
-cp $OUT/${TAG}_prof_train/p_kernel_stats.csv $OUT/${TAG}_train_kernel_stats.csv 2>/dev/null
-rm -rf $OUT/${TAG}_prof $OUT/${TAG}_prof_train $OUT/${TAG}_pmc_f $OUT/${TAG}_pmc_w $OUT/${TAG}_pmc_m
-ls -la $OUT | grep ${TAG}_
-tail -c 600 $OUT/${TAG}_bench.json
+ERR=$OUT/${TAG}_bench.err
+LEAN="--no-cpu-baseline --no-northstar --no-train-key --no-f32-key --no-repeats"
+md5_of() { python -c "import sys,json; print(json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])['plan_md5'])" $1; }
+for W in 416 608; do
+  if [ $W = 416 ]; then SH=""; SUF=""; B=32; else SH="--size 608 --batch 64"; SUF="_608"; B=64; fi
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof$SUF -o p -- python bench.py --steps 50 --warmup 5 $SH $LEAN > $OUT/${TAG}_bench${SUF}_profiled.json 2>> $ERR
+  cp $OUT/${TAG}_prof$SUF/p_kernel_stats.csv $OUT/${PT}${SUF}_kernel_stats.csv 2>/dev/null
+  MD5=$(md5_of $OUT/${TAG}_bench${SUF}_profiled.json)
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_f -o p -- python bench.py --steps 5 --warmup 2 $SH $LEAN --no-roofline > /dev/null 2>> $ERR
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_w -o p -- python bench.py --steps 5 --warmup 2 $SH $LEAN --no-roofline > /dev/null 2>> $ERR
+  python tools/pmc_traffic.py $OUT/${TAG}_pmc_f $OUT/${TAG}_pmc_w $B $W $OUT/${PT}${SUF}_pmc_traffic.json $MD5 7 >> $OUT/${TAG}_pmc_summary.txt 2>&1
+  cp $OUT/${PT}${SUF}_pmc_traffic.json profiles/${PT}${SUF}_pmc_traffic.json      # (bench.py reads profiles/*_pmc_traffic.json: the lines below quote THIS box's passes)
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_m -o p -- python bench.py --steps 5 --warmup 2 $SH $LEAN --no-roofline > /dev/null 2>> $ERR
+  python tools/pmc_mfma.py $OUT/${TAG}_pmc_m $OUT/${PT}${SUF}_pmc_mfma.json >> $OUT/${TAG}_pmc_summary.txt 2>&1
+  rm -rf $OUT/${TAG}_prof$SUF $OUT/${TAG}_pmc_f $OUT/${TAG}_pmc_w $OUT/${TAG}_pmc_m
+done
+cp $OUT/${TAG}_pmc_summary.txt $OUT/${PT}_pmc_summary.txt
+cp $OUT/${TAG}_bench_profiled.json $OUT/${PT}_bench_profiled.json
+# bench lines (un-profiled): 608 bs 64 alone and with NMS, the training step, then the full headline line (the driver's command)
+python bench.py --steps 10 --warmup 3 --size 608 --batch 64 --no-cpu-baseline > $OUT/${PT}_bench_608.json 2>> $ERR
+python bench.py --steps 10 --warmup 3 --size 608 --batch 64 --post nms --no-cpu-baseline --no-roofline > $OUT/${PT}_bench_608_nms.json 2>> $ERR
+python bench.py --mode train --steps 20 --warmup 3 > $OUT/${PT}_train_bench.json 2>> $ERR
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_train -o p -- python bench.py --mode train --steps 10 --warmup 2 > $OUT/${PT}_train_bench_profiled.json 2>> $ERR
+cp $OUT/${TAG}_prof_train/p_kernel_stats.csv $OUT/${PT}_train_kernel_stats.csv 2>/dev/null
+rm -rf $OUT/${TAG}_prof_train
+python bench.py --steps 20 --warmup 5 > $OUT/${PT}_bench.json 2>> $ERR
+ls -la $OUT | grep ${PT}_
+tail -c 1500 $OUT/${PT}_bench.json

@@ -33,8 +33,9 @@ struct ConvArgs {
     int halo_strict;        // conv_pipe.hip launch_pipe: leave one slot of the staged halo unused (the 2x2-window 4-wave tile)
     int tile_px;            // conv_igemm.hip: strip pixels a tile covers (= its 128 unless the shape needs row-limited tiles); 0 elsewhere
     int nchunks, tiles_c;
-    int buf32;              // conv_epilogue.h: != 0 (2: + the in-register transpose of the bf16 epilogue) = y, the residual (and stats_y, tail_y) extents fit 31-bit byte offsets: the epilogue's
+    int buf32;              // conv_epilogue.h: 1 = y, the residual (and stats_y, tail_y) extents fit 31-bit byte offsets: the epilogue's
                             // loads / stores are unconditional buffer accesses (out-of-range offset = no access)
+    int lab;                // lab build only (YOLO_EPI_AB): epilogue ablation bits -- 1 drop the stores, 2 drop the residual loads, 4 skip the epilogue
     int vblocks;            // conv_pipe.hip: number of (pixel tile, cout tile) units = the grid size unless the blocks are persistent
     int out_f32;
     int x_ps;       // elements between input pixels (>= Cin: x may be a channel slice of a wider NHWC buffer)

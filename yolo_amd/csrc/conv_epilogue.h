@@ -13,14 +13,6 @@
 #pragma once
 #include "conv_args.h"
 #include <type_traits>
-#include <utility>
-
-// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<N - 1>) -- the body's indices are constants whatever the
-// unroller's size limits say (an accumulator array indexed by a loop variable the unroller gave up on goes to scratch)
-template <typename F, int... I>
-__device__ __forceinline__ void yolo_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, typename F>
-__device__ __forceinline__ void yolo_static_for(F&& f) { yolo_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // bytes of LDS scratch one wave needs (max over MI in {1,2}): 32 rows x (64*4+16) + 2 x 32 x 8 (output offsets) + 2 x 32 x 8
 // (residual offsets, when the residual's strides differ from the output's)
@@ -47,6 +39,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
     constexpr int RPP = 64 / LPR;               // rows per pass
     constexpr int NPASS = 32 / RPP;
     static_assert(32 * RS + 4 * 32 * 8 <= YOLO_EPI_WAVE_BYTES_MI(MI), "scratch size");
+#ifdef YOLO_LAB
+    if (a.lab & 4) return;
+#endif
     const int l31 = lane & 31, h = lane >> 5;
     const float slope = a.slope;
     // scale == bias == nullptr: identity epilogue (the training step's raw convolutions and data gradients: BN and the
@@ -136,105 +131,6 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
         return;
     }
 
-    // ---- (round 5) bf16, no statistics: the transpose stays in REGISTERS ------------------------------------------------
-    // A lane holds couts 8g + 4h + (0..3) of its pixel for g = 0..3: the half-waves share every 8-cout run.  One
-    // v_permlane32_swap per fp32 register of a group pair (2j, 2j+1) hands the upper half's part of group 2j to the lower
-    // lane and the lower half's part of group 2j+1 to the upper lane; afterwards lane (l31, h) owns the 8 consecutive couts
-    // 16j + 8h .. + 7 of pixel l31 = 16 contiguous output bytes, exactly what the LDS transpose below produced, without the
-    // scratch round trip (8 ds_write_b128 + 8 ds_read_b128 + the offset table per 32-pixel slab and its latency chain: the
-    // phase stamps had this epilogue at 2-2.5x its issue bound, NOTES 0).  The arithmetic per value and its order are those
-    // of the transposed path (fp32 scale / bias -> LeakyReLU -> + residual -> one rounding): bit-identical outputs.  The
-    // lane keeps its own pixel, so the output offsets need no table.  Groups (mi, j) are walked outermost: scale / bias of
-    // the lane's 8 couts are loaded once per group, the residual pieces of group k + 1 are in flight under group k.
-    // (MI = 4, the one-wave-per-SIMD 128 x 128 wave tile with all 512 registers in use: this form compiled to 10 KB of scratch per
-    //  lane whatever the schedule -- it keeps the LDS transpose)
-    if constexpr (ES == 2 && STATS == 0 && MI <= 2) {
-        if (a.buf32 == 2) {
-            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-            const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, 0x7fffffff, 0x00020000);
-            const bool has_res = a.res != nullptr;
-            const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(has_res ? a.res : a.y), 0, 0x7fffffff, 0x00020000);
-            const bool res_sep = has_res && roff != nullptr && (a.r_ps != a.y_ps || a.r_bs != a.y_bs);
-            const int up_a = (int)(a.y_ps * 2), up_b = (int)(2LL * a.Wo * a.y_ps * 2);
-            constexpr int NG = MI * 2;                                  // groups of 16 couts (8 per half-wave)
-            auto group_cofs = [&](int gi, bool& ok) __attribute__((always_inline)) -> long long {
-                const int co = co_w + gi * 16 + 8 * h;
-                ok = co < a.Cout;
-                if (a.d2s) {
-                    const int C4 = a.Cout >> 2, ph = co / C4;
-                    return (long long)((ph >> 1) * 2 * a.Wo + (ph & 1)) * C4 + (co - ph * C4);
-                }
-                return co;
-            };
-            u32x4_t rb[2][NI];
-            f32x4 sb[2][4];                                             // scale (2 x 4) and bias (2 x 4) of the lane's 8 couts
-            // the loads of group gi: its scale / bias first, then its residual pieces -- issued one group ahead, so a group waits
-            // for nothing that was requested after its own operands
-            auto prefetch_g = [&](auto gi_c) __attribute__((always_inline)) {
-                constexpr int gi = decltype(gi_c)::value;
-                bool ok;
-                const long long cf = group_cofs(gi, ok);
-                const int co = co_w + gi * 16 + 8 * h;
-                if (!ident) {
-                    sb[gi & 1][0] = *(const f32x4*)(a.scale + co); sb[gi & 1][1] = *(const f32x4*)(a.scale + co + 4);     // (arrays are padded to the cout tile)
-                    sb[gi & 1][2] = *(const f32x4*)(a.bias + co); sb[gi & 1][3] = *(const f32x4*)(a.bias + co + 4);
-                }
-                if (has_res) {
-                    yolo_static_for<NI>([&](auto ni_c) __attribute__((always_inline)) {
-                        constexpr int ni = decltype(ni_c)::value;
-                        const long long r_ = res_sep ? roff[ni] : yoff[ni];
-                        rb[gi & 1][ni] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (ok && yoff[ni] >= 0) ? (int)((r_ + cf) * 2) : -1, 0, 0);
-                    });
-                }
-            };
-            prefetch_g(std::integral_constant<int, 0>{});
-            yolo_static_for<NG>([&](auto gi_c) __attribute__((always_inline)) {
-                constexpr int gi = decltype(gi_c)::value;
-                constexpr int mi = gi >> 1, j = gi & 1;
-                if constexpr (gi + 1 < NG) prefetch_g(std::integral_constant<int, gi + 1>{});
-                bool ok;
-                const long long cf = group_cofs(gi, ok);
-                const f32x4 s0 = sb[gi & 1][0], s1 = sb[gi & 1][1], b0 = sb[gi & 1][2], b1 = sb[gi & 1][3];
-                yolo_static_for<NI>([&](auto ni_c) __attribute__((always_inline)) {
-                    constexpr int ni = decltype(ni_c)::value;
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mi][ni][8 * j + e]),
-                                                                        __float_as_uint(acc[mi][ni][8 * j + 4 + e]), false, false);
-                        v[e] = __uint_as_float(r[0]); v[4 + e] = __uint_as_float(r[1]);
-                    }
-                    if (!ident) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float t0 = v[e] * s0[e] + b0[e], t1 = v[4 + e] * s1[e] + b1[e];
-                            v[e] = leaky(t0, slope); v[4 + e] = leaky(t1, slope);
-                        }
-                    }
-                    if (has_res) {
-                        const uint32_t w[4] = {rb[gi & 1][ni].x, rb[gi & 1][ni].y, rb[gi & 1][ni].z, rb[gi & 1][ni].w};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            v[2 * q] += bf16_bits_to_f32(w[q] & 0xffffu);
-                            v[2 * q + 1] += bf16_bits_to_f32(w[q] >> 16);
-                        }
-                    }
-                    u32x4_t ov;
-                    ov.x = pack_bf16x2(v[0], v[1]); ov.y = pack_bf16x2(v[2], v[3]);
-                    ov.z = pack_bf16x2(v[4], v[5]); ov.w = pack_bf16x2(v[6], v[7]);
-                    const int ob = (ok && yoff[ni] >= 0) ? (int)((yoff[ni] + cf) * 2) : -1;
-                    __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob, 0, 0);
-                    if (a.up2) {                            // the other three pixels of the 2x2 patch (row pitch 2*Wo pixels)
-                        __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_a : -1, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_b : -1, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_b + up_a : -1, 0, 0);
-                    }
-                });
-            });
-            return;
-        }
-    }
-
     // ---- transposed path ---------------------------------------------------------------------------
     const int col = lane % LPR;
     const int row0 = lane / LPR;
@@ -290,102 +186,143 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
         const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)(STATS == 2 ? a.s_y : a.y), 0, 0x7fffffff, 0x00020000);
         int yb[2][NPASS];                       // byte offset of the lane's 16-byte piece in y (-1: none)
         u32x4_t rb[2][NPASS], sb[2][NPASS];
-        auto prefetch_b = [&](int ni) {
-            if (h == 0) ytab[(ni & 1) * 32 + l31] = yoff[ni];
-            if (res_sep && h == 1) rtab[(ni & 1) * 32 + l31] = roff[ni];
-            wave_lds_fence();
-#pragma unroll
-            for (int k = 0; k < NPASS; ++k) {
-                const long long y_ = ytab[(ni & 1) * 32 + row0 + k * RPP];
-                const bool ok = co_ok && y_ >= 0;
-                yb[ni & 1][k] = ok ? (int)((y_ + cofs) * ES) : -1;
-                if (has_res) {
-                    const long long r_ = res_sep ? rtab[(ni & 1) * 32 + row0 + k * RPP] : y_;
-                    rb[ni & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, ok ? (int)((r_ + cofs) * ES) : -1, 0, 0);
+        const int up_a = (int)(a.y_ps * ES), up_b = (int)(2LL * a.Wo * a.y_ps * ES);      // (up2: the other pixels of the 2x2 patch)
+        // (round 5) The slab loop is SOFTWARE-PIPELINED through the scratch: the transposed rows of slab ni + 1 are written and read
+        // back into a second register set BEFORE slab ni's arithmetic and stores, so a pass never waits for its own ds_read (the ISA
+        // of the previous order: ds_read -> s_waitcnt lgkmcnt -> 24-44 VALU -> store, pass after pass, each read issued only after the
+        // previous pass's store because the uniform branches on `ident` / residual / up2 cut the loop body into basic blocks the
+        // scheduler cannot move loads across).  One scratch is enough: the LDS operations of a wave execute in order, so the
+        // writes of slab ni + 1 cannot overtake the reads of slab ni issued before them.  The uniform decisions (identity epilogue,
+        // residual) are taken ONCE around the whole loop (four specialisations) instead of per pass.  PIPE needs NPASS * CPL more
+        // registers: wave tiles of up to 64 couts (the 128-cout one keeps the plain order).
+        constexpr bool PIPE = MI <= 2;
+        auto run = [&](auto ident_c, auto res_c) __attribute__((always_inline)) {
+            constexpr bool IDENT = decltype(ident_c)::value, RES = decltype(res_c)::value;
+            float tv[PIPE ? 2 : 1][NPASS][CPL];
+            auto prefetch_b = [&](int ni) __attribute__((always_inline)) {
+                if (h == 0) ytab[(ni & 1) * 32 + l31] = yoff[ni];
+                if (res_sep && h == 1) rtab[(ni & 1) * 32 + l31] = roff[ni];
+                wave_lds_fence();
+    #pragma unroll
+                for (int k = 0; k < NPASS; ++k) {
+                    const long long y_ = ytab[(ni & 1) * 32 + row0 + k * RPP];
+                    const bool ok = co_ok && y_ >= 0;
+                    yb[ni & 1][k] = ok ? (int)((y_ + cofs) * ES) : -1;
+#ifdef YOLO_LAB
+                    if (a.lab & 1) yb[ni & 1][k] = -1;
+#endif
+                    if constexpr (RES) {
+                        const long long r_ = res_sep ? rtab[(ni & 1) * 32 + row0 + k * RPP] : y_;
+#ifdef YOLO_LAB
+                        rb[ni & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (ok && !(a.lab & 2)) ? (int)((r_ + cofs) * ES) : -1, 0, 0);
+#else
+                        rb[ni & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, ok ? (int)((r_ + cofs) * ES) : -1, 0, 0);
+#endif
+                    }
+                    if constexpr (STATS == 2) sb[ni & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(srs, yb[ni & 1][k], 0, 0);
                 }
-                if constexpr (STATS == 2) sb[ni & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(srs, yb[ni & 1][k], 0, 0);
+            };
+            auto write_slab = [&](int ni) __attribute__((always_inline)) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+                        *(f32x4*)(wsm + l31 * RS + (mi * 32 + 8 * g + 4 * h) * 4) = v;
+                    }
+                wave_lds_fence();
+            };
+            auto read_slab = [&](int ni) __attribute__((always_inline)) {
+#pragma unroll
+                for (int k = 0; k < NPASS; ++k)
+#pragma unroll
+                    for (int q = 0; q < CPL / 4; ++q) {
+                        const f32x4 t4 = *(const f32x4*)(wsm + (row0 + k * RPP) * RS + (col * CPL + 4 * q) * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) tv[PIPE ? (ni & 1) : 0][k][4 * q + e] = t4[e];
+                    }
+                wave_lds_fence();
+            };
+            prefetch_b(0);
+            write_slab(0);
+            read_slab(0);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                if (ni + 1 < NI) {
+                    prefetch_b(ni + 1);
+                    if constexpr (PIPE) { write_slab(ni + 1); read_slab(ni + 1); }
+                }
+#pragma unroll
+                for (int k = 0; k < NPASS; ++k) {
+                    float v[CPL];
+#pragma unroll
+                    for (int e = 0; e < CPL; ++e) v[e] = tv[PIPE ? (ni & 1) : 0][k][e];
+                    if constexpr (!IDENT) {
+#pragma unroll
+                        for (int e = 0; e < CPL; ++e) {
+                            const float t = v[e] * sc[e] + bi[e];
+                            v[e] = leaky(t, slope);
+                        }
+                    }
+                    const int ob = yb[ni & 1][k];
+                    u32x4_t ov;
+                    if constexpr (ES == 2) {
+                        if constexpr (RES) {
+                            const uint32_t w[4] = {rb[ni & 1][k].x, rb[ni & 1][k].y, rb[ni & 1][k].z, rb[ni & 1][k].w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                v[2 * q] += bf16_bits_to_f32(w[q] & 0xffffu);
+                                v[2 * q + 1] += bf16_bits_to_f32(w[q] >> 16);
+                            }
+                        }
+                        ov.x = pack_bf16x2(v[0], v[1]); ov.y = pack_bf16x2(v[2], v[3]);
+                        ov.z = pack_bf16x2(v[4], v[5]); ov.w = pack_bf16x2(v[6], v[7]);
+                        if constexpr (STATS != 0) {
+                            const uint32_t ow[4] = {ov.x, ov.y, ov.z, ov.w};
+                            float vr[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) vr[e] = bf16_bits_to_f32((e & 1) ? (ow[e >> 1] >> 16) : (ow[e >> 1] & 0xffffu));
+                            if constexpr (STATS == 1) {
+                                // (lanes past the end of the tensor compute a copy of the tile's first pixel: masked like the store)
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    const float m = ob >= 0 ? vr[e] : 0.f;
+                                    ssum[e] += m; qsum[e] += m * m;
+                                }
+                            } else {
+                                const uint32_t yw[4] = {sb[ni & 1][k].x, sb[ni & 1][k].y, sb[ni & 1][k].z, sb[ni & 1][k].w};
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    const float yv = bf16_bits_to_f32((e & 1) ? (yw[e >> 1] >> 16) : (yw[e >> 1] & 0xffffu));
+                                    const float xh = (yv - smu[e]) * sis[e];
+                                    const float da = (ob >= 0) ? vr[e] * ((sga[e] * xh + sbe[e]) > 0.f ? 1.f : a.s_slope) : 0.f;
+                                    ssum[e] += da; qsum[e] += da * xh;
+                                }
+                            }
+                        }
+                    } else {
+                        if constexpr (RES) {
+                            v[0] += __uint_as_float(rb[ni & 1][k].x); v[1] += __uint_as_float(rb[ni & 1][k].y);
+                            v[2] += __uint_as_float(rb[ni & 1][k].z); v[3] += __uint_as_float(rb[ni & 1][k].w);
+                        }
+                        ov.x = __float_as_uint(v[0]); ov.y = __float_as_uint(v[1]); ov.z = __float_as_uint(v[2]); ov.w = __float_as_uint(v[3]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob, 0, 0);
+                    if (a.up2) {                            // the other three pixels of the 2x2 patch (row pitch 2*Wo pixels)
+                        __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_a : -1, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_b : -1, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_b + up_a : -1, 0, 0);
+                    }
+                }
+                if constexpr (!PIPE) {
+                    if (ni + 1 < NI) { write_slab(ni + 1); read_slab(ni + 1); }
+                }
             }
         };
-        const int up_a = (int)(a.y_ps * ES), up_b = (int)(2LL * a.Wo * a.y_ps * ES);      // (up2: the other pixels of the 2x2 patch)
-        prefetch_b(0);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            if (ni + 1 < NI) prefetch_b(ni + 1);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
-                    *(f32x4*)(wsm + l31 * RS + (mi * 32 + 8 * g + 4 * h) * 4) = v;
-                }
-            wave_lds_fence();
-#pragma unroll
-            for (int k = 0; k < NPASS; ++k) {
-                float v[CPL];
-#pragma unroll
-                for (int q = 0; q < CPL / 4; ++q) {
-                    const f32x4 t4 = *(const f32x4*)(wsm + (row0 + k * RPP) * RS + (col * CPL + 4 * q) * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * q + e] = t4[e];
-                }
-                if (!ident) {
-#pragma unroll
-                    for (int e = 0; e < CPL; ++e) {
-                        const float t = v[e] * sc[e] + bi[e];
-                        v[e] = leaky(t, slope);
-                    }
-                }
-                const int ob = yb[ni & 1][k];
-                u32x4_t ov;
-                if constexpr (ES == 2) {
-                    if (has_res) {
-                        const uint32_t w[4] = {rb[ni & 1][k].x, rb[ni & 1][k].y, rb[ni & 1][k].z, rb[ni & 1][k].w};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            v[2 * q] += bf16_bits_to_f32(w[q] & 0xffffu);
-                            v[2 * q + 1] += bf16_bits_to_f32(w[q] >> 16);
-                        }
-                    }
-                    ov.x = pack_bf16x2(v[0], v[1]); ov.y = pack_bf16x2(v[2], v[3]);
-                    ov.z = pack_bf16x2(v[4], v[5]); ov.w = pack_bf16x2(v[6], v[7]);
-                    if constexpr (STATS != 0) {
-                        const uint32_t ow[4] = {ov.x, ov.y, ov.z, ov.w};
-                        float vr[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) vr[e] = bf16_bits_to_f32((e & 1) ? (ow[e >> 1] >> 16) : (ow[e >> 1] & 0xffffu));
-                        if constexpr (STATS == 1) {
-                            // (lanes past the end of the tensor compute a copy of the tile's first pixel: masked like the store)
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                const float m = ob >= 0 ? vr[e] : 0.f;
-                                ssum[e] += m; qsum[e] += m * m;
-                            }
-                        } else {
-                            const uint32_t yw[4] = {sb[ni & 1][k].x, sb[ni & 1][k].y, sb[ni & 1][k].z, sb[ni & 1][k].w};
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                const float yv = bf16_bits_to_f32((e & 1) ? (yw[e >> 1] >> 16) : (yw[e >> 1] & 0xffffu));
-                                const float xh = (yv - smu[e]) * sis[e];
-                                const float da = (ob >= 0) ? vr[e] * ((sga[e] * xh + sbe[e]) > 0.f ? 1.f : a.s_slope) : 0.f;
-                                ssum[e] += da; qsum[e] += da * xh;
-                            }
-                        }
-                    }
-                } else {
-                    if (has_res) {
-                        v[0] += __uint_as_float(rb[ni & 1][k].x); v[1] += __uint_as_float(rb[ni & 1][k].y);
-                        v[2] += __uint_as_float(rb[ni & 1][k].z); v[3] += __uint_as_float(rb[ni & 1][k].w);
-                    }
-                    ov.x = __float_as_uint(v[0]); ov.y = __float_as_uint(v[1]); ov.z = __float_as_uint(v[2]); ov.w = __float_as_uint(v[3]);
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob, 0, 0);
-                if (a.up2) {                            // the other three pixels of the 2x2 patch (row pitch 2*Wo pixels)
-                    __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_a : -1, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_b : -1, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_b + up_a : -1, 0, 0);
-                }
-            }
-        }
+        typedef std::true_type Y_;
+        typedef std::false_type N_;
+        if (ident) { if (has_res) run(Y_{}, Y_{}); else run(Y_{}, N_{}); }
+        else { if (has_res) run(N_{}, Y_{}); else run(N_{}, N_{}); }
     } else {
     // The residual loads of slab ni+1 are issued BEFORE slab ni is processed (two register sets), so their latency
     // hides under the previous slab's transpose/arithmetic/stores -- the phase stamps showed one exposed memory

@@ -337,10 +337,10 @@ static int launch_dtype(ConvArgs& a, int ks, int stride, hipStream_t st, const N
     return launch_shape<T, 2, 2, 1, 2>(a, ks, stride, st, nm);                    // 128 px x  64 cout
 }
 
-// conv_epilogue.h form: 2 = unconditional buffer accesses + the in-register transpose (bf16; the default), 1 = buffer accesses + the
-// LDS transpose, 0 = the branching form (also what extents beyond 31 bits get).  Lab knobs: YOLO_NO_BUF32 -> 0, YOLO_EPI_LDS -> 1.
+// conv_epilogue.h form: 1 = unconditional buffer accesses (the default), 0 = the branching form (also what extents beyond 31 bits
+// get).  Lab knob: YOLO_NO_BUF32 -> 0.
 static int conv_buf32_form() {
-    static const int v = YOLO_LAB_SET("YOLO_NO_BUF32") ? 0 : YOLO_LAB_SET("YOLO_EPI_LDS") ? 1 : 2;
+    static const int v = YOLO_LAB_SET("YOLO_NO_BUF32") ? 0 : 1;
     return v;
 }
 
@@ -446,6 +446,7 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
         const long long tb = a.t_wp ? (long long)a.N * a.t_y_bs * (a.t_out_f32 ? 4 : es) : 0;
         a.buf32 = (yb < lim && rbytes < lim && tb < lim) ? conv_buf32_form() : 0;
     }
+    { static const int lab = (int)YOLO_LAB_ENV("YOLO_EPI_AB", 0); a.lab = lab; }
     if (a.t_wp) {
         // fused tail 1x1: pipelined 3x3 variants with 256-cout tiles only (conv_pipe.hip)
         if (!d->tail_y || (!d->tail_scale != !d->tail_bias) || d->tail_cout <= 0 || !(d->tail_slope >= 0.f && d->tail_slope <= 1.f)) return YOLO_EINVAL;
@@ -531,6 +532,7 @@ extern "C" int yolo_conv_dgrad_s2(const yolo_conv_desc* d, void* stream) {
     a.halo_strict = 0;
     a.stats = nullptr; a.stats_mode = 0;
     a.t_wp = nullptr;
+    a.lab = 0;
     a.buf32 = ((long long)a.N * a.Ho * a.Wo * d->Cout * 2 < 0x7fffffffLL) ? conv_buf32_form() : 0;      // (dx: N x 2Ho x 2Wo x Cout/4, residual = dx)
     if (d->x_pixel_stride || d->upsample2x || d->stats) return YOLO_EUNSUPPORTED;
     a.y_ps = d->Cout / 4;

@@ -93,9 +93,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // the first half) issues them at shifted positions, so a wave stuck in a DMA issue is covered by its
 // SIMD partner's MFMAs.
 // Second launch bound = waves per SIMD the register allocation must leave room for.  The 4-wave blocks are meant to be
-// co-resident (two per CU; four for the 32-accumulator tiles): without the bound the allocator sees a 512-register budget and the
-// in-register epilogue's accumulator copies cost the second block (the 192 x 128 tile: 236 -> 308 registers, measured in the
-// metadata).  The 128 x 128 wave tile (W1) is built for one wave per SIMD.
+// co-resident (two per CU; four for the 32-accumulator tiles): without the bound the allocator sees a 512-register budget and an
+// epilogue that holds more values in flight (round 5: the software-pipelined transpose) costs the second block -- the metadata
+// showed the 192 x 128 tile go from 236 to 308 registers under the first such change.  The 128 x 128 wave tile (W1) is built
+// for one wave per SIMD.
 template <int NW, int MI, int NI, int STATS> struct PipeMinWaves {       // (STATS 2, the data-gradient sums: ~100 more live values, unbounded as before)
     static constexpr int value = (NW != 4 || STATS == 2) ? 1 : (MI == 4 ? 1 : (MI * NI * 16 <= 32 ? 4 : 2));
 };

@@ -744,6 +744,33 @@ class CarNet(object):
             out.append((name, buf.value.decode(), fl))
         return out
 
+    def plan_bytes(self, B, H, W):
+        """{op name: ALGORITHMIC HBM bytes of that launch} for the conv launches of one input shape: input read once + output
+        written once (+ the residual read once) + weights once (SURVEY section 8d's per-layer roofline convention; a fused tail adds
+        its own output and weights, its input never leaves the chip) -- the figure `roofline.traffic` is compared with."""
+        self._ensure_prepared()
+        self.plan_kernels(B, H, W)
+        plan = self._plans[(B, H, W)]
+        by_name = {c.name: c for c in self.graph.convs()}
+        es = 2 if self.dtype != 'f32' else 4
+        out = {}
+        for kind, d, name in plan.ops:
+            if kind != 'conv':
+                continue
+            parts = name.split('+')
+            c = by_name[parts[0]]
+            ho, wo = c.out_hw(d.H, d.W)
+            px = d.N * ho * wo
+            nb = d.N * d.H * d.W * d.Cin * es + d.Cout * d.Cin * c.k * c.k * es
+            nb += px * d.Cout * (4 if d.out_f32 else es) * (4 if d.upsample2x else 1)
+            if d.residual:
+                nb += px * d.Cout * es
+            for part in parts[1:]:
+                t = by_name[part]
+                nb += px * t.cout * (4 if d.tail_out_f32 else es) + t.cout * t.cin * es
+            out[name] = nb
+        return out
+
     def forward_timed(self, x, events):
         """forward() that brackets every launch with a pair of torch CUDA events (recorded on the
         stream the kernels run on).  events: list that receives (op name, start, end)."""
