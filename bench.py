@@ -38,7 +38,7 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
-MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # /opt/skills/guides/MI355X_MICROARCH.md (dense)
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}      # /opt/skills/guides/MI355X_MICROARCH.md (dense)
 
 
 class Telemetry(object):
@@ -454,7 +454,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (default 32; 64 in --mode train)')
     ap.add_argument('--size', type=int, default=416)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-fuse-stem', action='store_true', help='run the stem and the first down-sampling conv as two kernels (A/B)')

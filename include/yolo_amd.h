@@ -21,6 +21,9 @@ extern "C" {
 
 #define YOLO_F32 0
 #define YOLO_BF16 1
+#define YOLO_F16 2     /* IEEE half: the reference's own reduced precision (use_fp16 -> net.cast('float16'), car/YOLO.py:98-100; executor fp16 flag
+                          yolo_gluon.py:204-214).  Inference entry points only (pack, fold, nchw<->nhwc, conv_fwd, stem, res_block); the
+                          training entries take YOLO_F32 | YOLO_BF16 */
 
 #define YOLO_OK 0
 #define YOLO_EINVAL (-1)
@@ -79,7 +82,7 @@ typedef struct yolo_conv_desc {
     void* y;               /* (N,Ho,Wo,Cout) dtype, or float32 when out_f32                   */
     int N, H, W, Cin, Cout;
     int ksize, stride;
-    int dtype;             /* YOLO_F32 | YOLO_BF16: activations and weights                   */
+    int dtype;             /* YOLO_F32 | YOLO_BF16 | YOLO_F16: activations and weights        */
     int out_f32;           /* 1: y is float32 (head logits)                                   */
     float slope;           /* LeakyReLU negative slope in [0, 1]; 1.0f = linear               */
     long long y_batch_stride; /* elements between images in y; 0 = dense Ho*Wo*Cout           */

@@ -9,6 +9,7 @@ concat([upsampled, route], dim=1) (car/utils.py:92-93); YOLOOutput (basic_yolo.p
 
 forward_torch   : torch CPU fp32 (F.conv2d / batch_norm / leaky_relu)
 forward_numpy64 : numpy fp64, convolution written as explicit tap loops + einsum
+forward_torch_f16sim  : the same with IEEE half (the reference's use_fp16)
 forward_torch_bf16sim : fp32 math with operands rounded to bf16 at the points where the
                   HIP bf16 path rounds (weights; every conv input) -- the "rounding-aware"
                   oracle for the bf16 MFMA path (SURVEY.md section 7 hard parts).
@@ -28,8 +29,11 @@ def _t(P, name):
     return v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))
 
 
+_SIM_DT = [torch.bfloat16]          # the 2-byte type the rounding simulation rounds to (forward_torch_f16sim swaps it)
+
+
 def _bf16_round(x):
-    return x.to(torch.bfloat16).to(torch.float32)
+    return x.to(_SIM_DT[0]).to(torch.float32)
 
 
 def _conv_bn_act_torch(P, c, x, training=False, bn_stats=None, sim_bf16=False, round_out=True):
@@ -122,6 +126,17 @@ def forward_torch(g, P, x, training=False, bn_stats=None, sim_bf16=False, taps=N
 
 def forward_torch_bf16sim(g, P, x):
     return forward_torch(g, P, x, sim_bf16=True)
+
+
+def forward_torch_f16sim(g, P, x):
+    """The same rounding points with IEEE half: the reference's use_fp16 path (net.cast('float16'), car/YOLO.py:98-100) as the
+    HIP f16 path computes it -- fp16 weights and activations, fp32 accumulation, folded BN and LeakyReLU in fp32, one rounding
+    per stored activation."""
+    _SIM_DT[0] = torch.float16
+    try:
+        return forward_torch(g, P, x, sim_bf16=True)
+    finally:
+        _SIM_DT[0] = torch.bfloat16
 
 
 # ----------------------------------------------------------------------------- numpy fp64

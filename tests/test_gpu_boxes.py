@@ -2,7 +2,7 @@
 DECODED outputs of every arithmetic path, at the BASELINE configurations (Missing 3: only the logits' RMS was
 bounded for the reduced-precision path).  For configs[1] (D53 spec 416x416 bs 32, images 0 / 1 / 31 of the batch) and configs[4]'s
 shape (608x608, two images) the HIP net runs in dtype f32 / f16 / bf16, `Detector.decode` + `predict` turn the logits into the
-reference's rows (car/YOLO.py:552-597), and the rows are compared with the fp32 oracle's: max and RMS error of [l, t, r, b]
+reference's rows (car/YOLO.py:552-597), and the rows are compared with the fp32 oracle's: max and RMS of |a - b| / (1 + |b|) over [l, t, r, b]
 (normalised image units, as the reference emits them), of the top-1 `predict` row [score, y, x, h, w], and the fraction of images
 whose top-1 box index equals the oracle's.
 
@@ -25,8 +25,11 @@ SANITY_RMS = {'f32': 1e-4, 'f16': 2e-3, 'bf16': 2e-2}
 
 
 def _stats(rows, ref_rows, pred, ref_pred, idx, ref_idx):
-    e = (rows[..., 1:5].astype(np.float64) - ref_rows[..., 1:5])
-    ep = (pred[:, :5].astype(np.float64) - ref_pred[:, :5])
+    # error measure: |a - b| / (1 + |b|) -- absolute for boxes of image size (the reference's rows are normalised 0..1), relative
+    # for the huge ones a random-weight net also emits (exp(th) * anchor with th ~ 10: an absolute bar is meaningless there).
+    # The same measure tests/test_gpu_configs.py::test_d53_608_forward holds the fp32 path to.
+    e = (rows[..., 1:5].astype(np.float64) - ref_rows[..., 1:5]) / (1.0 + np.abs(ref_rows[..., 1:5]))
+    ep = (pred[:, :5].astype(np.float64) - ref_pred[:, :5]) / (1.0 + np.abs(ref_pred[:, :5]))
     same = idx == ref_idx
     # the top-1 row compared where both paths picked the same box (another box is another object, not a rounding error)
     eps = ep[same] if same.any() else np.zeros((1, 5))

@@ -441,7 +441,7 @@ def test_config4_608_bs64_measured_plan_replicated(cuda):
         assert e_hip < 1.5 * e_sim + 1e-3 and e_hip < 0.015, (e_hip, e_sim)
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 def test_config1_bs32_measured_plan(cuda, dtype):
     """BASELINE configs[1] as bench.py runs it: D53 spec, 416x416, bs 32, per-layer kernel variants pinned by
     measurement (tile quantisation is batch dependent: the bs-32 plan picks other variants than a B=2 plan).  Images
@@ -460,10 +460,13 @@ def test_config1_bs32_measured_plan(cuda, dtype):
         for o, r in zip(outs, ref):
             np.testing.assert_allclose(o[sel], r, rtol=0, atol=1e-3)
         return
-    sim = [s.numpy() for s in of.forward_torch_bf16sim(g, P, x[sel])]
+    # (f16 = the reference's use_fp16, car/YOLO.py:98-100: the rounding-aware oracle rounds to IEEE half; its error is ~8x smaller
+    #  than bf16's, and so are the bars)
+    sim_fn, bar, slack = (of.forward_torch_bf16sim, 0.015, 1e-3) if dtype == 'bf16' else (of.forward_torch_f16sim, 0.002, 2e-4)
+    sim = [s.numpy() for s in sim_fn(g, P, x[sel])]
     rms = lambda a: float(np.sqrt(np.mean(a * a)))
     for o, s, r in zip(outs, sim, ref):
         e_hip, e_sim = rms(o[sel] - r) / r.std(), rms(s - r) / r.std()
-        assert e_hip < 1.5 * e_sim + 1e-3 and e_hip < 0.015, (e_hip, e_sim)
+        assert e_hip < 1.5 * e_sim + slack and e_hip < bar, (e_hip, e_sim)
         for k in range(3):                                                              # every image on its own, too
-            assert rms(o[sel[k]] - r[k]) / r.std() < 0.02
+            assert rms(o[sel[k]] - r[k]) / r.std() < bar * 4 / 3

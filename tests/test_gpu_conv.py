@@ -58,6 +58,18 @@ def test_conv_bf16(lib, cuda, case):
     assert np.mean(np.abs(y - ref) > 1e-3 * (1 + np.abs(ref))) < 0.02
 
 
+@pytest.mark.parametrize('case', CASES)
+def test_conv_f16(lib, cuda, case):
+    """YOLO_F16 (the reference's use_fp16, car/YOLO.py:98-100): the same kernels on v_mfma_f32_32x32x16_f16, operands and the
+    stored activation rounded to IEEE half (v_cvt_pk_f16_f32, round-to-nearest-even) -- one half ulp of the output at most."""
+    x, w, scale, bias, r = _mk(case, 2)
+    y = run_conv(lib, cuda, x, w, scale, bias, case[6], 0.1, 'f16', residual=r)
+    ref = ref_conv(x, w, scale, bias, case[6], 0.1, residual=r, bf16='f16')
+    assert not np.isnan(y).any()
+    np.testing.assert_allclose(y, ref, rtol=2e-3, atol=2e-3)
+    assert np.mean(np.abs(y - ref) > 2e-4 * (1 + np.abs(ref))) < 0.02
+
+
 # shapes no width-dividing strip fits (prime widths on tall batches, maps one or two pixels wide): the generic kernel's ragged
 # strips / row-limited tiles (launch_cfg's fallback; these were refused with -2 until round 3 -- found by fuzzing the C ABI)
 RAGGED = [(5, 16, 25, 61, 48, 3, 1, False), (5, 512, 38, 61, 384, 3, 1, False), (5, 320, 33, 67, 256, 3, 1, True),
@@ -110,14 +122,17 @@ PIPE_ALGOS = [2, 3, 4, 5, 6, 7, 8, 11, 12, 19, 20, 21, 22, 23, 24, 25, 26, 30, 3
 
 # only the (shape, dtype, variant) pairs the library accepts (tests/util.py:eligible_pairs; the refusal rules are asserted
 # on the CPU by tests/test_host.py::test_conv_variant_eligibility_rules)
-@pytest.mark.parametrize('case,dtype,algo', eligible_pairs(PIPE_CASES, ['f32', 'bf16'], PIPE_ALGOS))
+@pytest.mark.parametrize('case,dtype,algo', eligible_pairs(PIPE_CASES, ['f32', 'bf16', 'f16'], PIPE_ALGOS))
 def test_conv_pipe(lib, cuda, case, dtype, algo):
     x, w, scale, bias, r = _mk(case, 4)
     y = run_conv(lib, cuda, x, w, scale, bias, case[6], 0.1, dtype, residual=r, algo=algo, expect_rc=0)
-    ref = ref_conv(x, w, scale, bias, case[6], 0.1, residual=r, bf16=(dtype == 'bf16'))
+    ref = ref_conv(x, w, scale, bias, case[6], 0.1, residual=r, bf16={'f32': False, 'bf16': True, 'f16': 'f16'}[dtype])
     assert not np.isnan(y).any()
     if dtype == 'f32':
         np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-4)
+    elif dtype == 'f16':
+        np.testing.assert_allclose(y, ref, rtol=2e-3, atol=2e-3)
+        assert np.mean(np.abs(y - ref) > 2e-4 * (1 + np.abs(ref))) < 0.02
     else:
         np.testing.assert_allclose(y, ref, rtol=1.6e-2, atol=2e-2)
         assert np.mean(np.abs(y - ref) > 1e-3 * (1 + np.abs(ref))) < 0.02
@@ -141,14 +156,16 @@ S2_CASES = [
 S2_ALGOS = [9, 10, 16, 17, 18]
 
 
-@pytest.mark.parametrize('case,dtype,algo', eligible_pairs(S2_CASES, ['f32', 'bf16'], S2_ALGOS))
+@pytest.mark.parametrize('case,dtype,algo', eligible_pairs(S2_CASES, ['f32', 'bf16', 'f16'], S2_ALGOS))
 def test_conv_pipe_stride2(lib, cuda, case, dtype, algo):
     x, w, scale, bias, r = _mk(case, 6)
     y = run_conv(lib, cuda, x, w, scale, bias, 2, 0.1, dtype, algo=algo, expect_rc=0)
-    ref = ref_conv(x, w, scale, bias, 2, 0.1, bf16=(dtype == 'bf16'))
+    ref = ref_conv(x, w, scale, bias, 2, 0.1, bf16={'f32': False, 'bf16': True, 'f16': 'f16'}[dtype])
     assert not np.isnan(y).any()
     if dtype == 'f32':
         np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-4)
+    elif dtype == 'f16':
+        np.testing.assert_allclose(y, ref, rtol=2e-3, atol=2e-3)
     else:
         np.testing.assert_allclose(y, ref, rtol=1.6e-2, atol=2e-2)
 
@@ -171,14 +188,15 @@ STREAM_CASES = [
 ]
 
 
-@pytest.mark.parametrize('case,dtype,algo', eligible_pairs(STREAM_CASES, ['bf16'], [13, 14]))
+@pytest.mark.parametrize('case,dtype,algo', eligible_pairs(STREAM_CASES, ['bf16', 'f16'], [13, 14]))
 def test_conv_stream(lib, cuda, case, dtype, algo):
     x, w, scale, bias, r = _mk(case, 7)
-    y = run_conv(lib, cuda, x, w, scale, bias, case[6], 0.1, 'bf16', residual=r, algo=algo, expect_rc=0)
-    ref = ref_conv(x, w, scale, bias, case[6], 0.1, residual=r, bf16=True)
+    k16 = 1.0 if dtype == 'bf16' else 0.125
+    y = run_conv(lib, cuda, x, w, scale, bias, case[6], 0.1, dtype, residual=r, algo=algo, expect_rc=0)
+    ref = ref_conv(x, w, scale, bias, case[6], 0.1, residual=r, bf16=(True if dtype == 'bf16' else 'f16'))
     assert not np.isnan(y).any()
-    np.testing.assert_allclose(y, ref, rtol=1.6e-2, atol=2e-2)
-    assert np.mean(np.abs(y - ref) > 1e-3 * (1 + np.abs(ref))) < 0.02
+    np.testing.assert_allclose(y, ref, rtol=1.6e-2 * k16, atol=2e-2 * k16)
+    assert np.mean(np.abs(y - ref) > 1e-3 * k16 * (1 + np.abs(ref))) < 0.02
 
 
 def test_conv_stream_rejects_ineligible(lib, cuda):
@@ -188,14 +206,17 @@ def test_conv_stream_rejects_ineligible(lib, cuda):
     run_conv(lib, cuda, x[:, :64], w[:, :64], scale, bias, 1, 0.1, 'f32', algo=13, expect_rc=-2)
 
 
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
 @pytest.mark.parametrize('shape', [(2, 64, 96), (1, 37, 61), (3, 8, 8), (1, 200, 250), (2, 24, 248), (1, 2, 2), (5, 33, 130)])
-def test_stem_down_fused_is_bit_identical(lib, cuda, shape):
+def test_stem_down_fused_is_bit_identical(lib, cuda, shape, dtype):
     """yolo_stem_down_fwd (stem 3->32 + first down-sampling conv 32->64 in one kernel, the 32-channel map kept in LDS)
     against the two separate kernels it replaces: same operand / accumulation order and rounding points, so the outputs
     must be bit-identical -- odd sizes, strips at the 62-pixel limit, several row slices, and against the oracle."""
     import ctypes as C
     import torch
     from yolo_amd import lib as L
+    from util import TDT, LDT
+    ldt, tdt = LDT[dtype], TDT[dtype]
     N, H, W = shape
     rng = np.random.default_rng(11)
     x = rng.random((N, 3, H, W)).astype(np.float32)
@@ -207,30 +228,31 @@ def test_stem_down_fused_is_bit_identical(lib, cuda, shape):
     dev = cuda
     xd = torch.from_numpy(x).to(dev)
     w1d, w2d = torch.from_numpy(w1).to(dev), torch.from_numpy(w2).to(dev)
-    wp2 = torch.empty(lib.yolo_packed_weight_bytes(64, 32, 3, L.BF16), dtype=torch.uint8, device=dev)
-    assert lib.yolo_pack_conv_weights(w2d.data_ptr(), wp2.data_ptr(), 64, 32, 3, L.BF16, st) == 0
+    wp2 = torch.empty(lib.yolo_packed_weight_bytes(64, 32, 3, ldt), dtype=torch.uint8, device=dev)
+    assert lib.yolo_pack_conv_weights(w2d.data_ptr(), wp2.data_ptr(), 64, 32, 3, ldt, st) == 0
     pad = lambda v: torch.cat([torch.from_numpy(v), torch.zeros(lib.yolo_padded_channels(len(v)) - len(v))]).to(dev)
     s1d, b1d, s2d, b2d = pad(s1), pad(b1), pad(s2), pad(b2)
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     # the two-kernel path
-    mid = torch.empty((N, H, W, 32), dtype=torch.bfloat16, device=dev)
+    mid = torch.empty((N, H, W, 32), dtype=tdt, device=dev)
     assert lib.yolo_stem_conv_fwd(xd.data_ptr(), w1d.data_ptr(), s1d.data_ptr(), b1d.data_ptr(), mid.data_ptr(), N, H, W, 3, 32,
-                                  L.BF16, 0.1, st) == 0
-    two = torch.full((N, Ho, Wo, 64), float('nan'), dtype=torch.bfloat16, device=dev)
+                                  ldt, 0.1, st) == 0
+    two = torch.full((N, Ho, Wo, 64), float('nan'), dtype=tdt, device=dev)
     d = L.ConvDesc()
     d.x, d.w_packed, d.scale, d.bias, d.y = mid.data_ptr(), wp2.data_ptr(), s2d.data_ptr(), b2d.data_ptr(), two.data_ptr()
-    d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.dtype, d.slope = N, H, W, 32, 64, 3, 2, L.BF16, 0.1
+    d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.dtype, d.slope = N, H, W, 32, 64, 3, 2, ldt, 0.1
     assert lib.yolo_conv_fwd(C.byref(d), st) == 0
-    one = torch.full((N, Ho, Wo, 64), float('nan'), dtype=torch.bfloat16, device=dev)
+    one = torch.full((N, Ho, Wo, 64), float('nan'), dtype=tdt, device=dev)
     assert lib.yolo_stem_down_fwd(xd.data_ptr(), w1d.data_ptr(), s1d.data_ptr(), b1d.data_ptr(), wp2.data_ptr(), s2d.data_ptr(),
-                                  b2d.data_ptr(), one.data_ptr(), N, H, W, 32, 64, L.BF16, 0.1, st) == 0
+                                  b2d.data_ptr(), one.data_ptr(), N, H, W, 32, 64, ldt, 0.1, st) == 0
     torch.cuda.synchronize()
     assert torch.equal(one.view(torch.int16), two.view(torch.int16))
     # and the oracle of the pair (rounding-aware)
-    r1 = ref_conv(x, w1, s1, b1, 1, 0.1, bf16=True)
-    r2 = ref_conv(r1, w2, s2, b2, 2, 0.1, bf16=True)
+    r1 = ref_conv(x, w1, s1, b1, 1, 0.1, bf16=(True if dtype == 'bf16' else 'f16'))
+    r2 = ref_conv(r1, w2, s2, b2, 2, 0.1, bf16=(True if dtype == 'bf16' else 'f16'))
     got = one.float().permute(0, 3, 1, 2).cpu().numpy()
-    np.testing.assert_allclose(got, r2, rtol=2e-2, atol=2e-2 * np.abs(r2).max())
+    tol = 2e-2 if dtype == 'bf16' else 3e-3
+    np.testing.assert_allclose(got, r2, rtol=tol, atol=tol * np.abs(r2).max())
 
 
 def test_stem_down_rejects(lib, cuda):
@@ -300,13 +322,17 @@ def test_conv_pipe_1x1_short_k(lib, cuda, algo, cin):
     np.testing.assert_allclose(y, ref, rtol=1.6e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
 @pytest.mark.parametrize('case', [(2, 37, 70, 64), (1, 20, 130, 128), (3, 5, 62, 64), (1, 40, 8, 128), (2, 52, 104, 128),
                                   (1, 33, 63, 64), (1, 64, 208, 64)])
-def test_res_block_fused(lib, cuda, case):
+def test_res_block_fused(lib, cuda, case, dtype):
     """yolo_res_block_fwd (one DarknetBasicBlockV3 of the first stages as one kernel) against the torch reference on the
     bf16-rounded operands with the HIP path's rounding points, and against the two separate HIP layers: several strips
     (balanced, ragged), several row slices, image edges on every side."""
     import ctypes as C
+    from util import TDT, LDT
+    ldt, tdt, sim = LDT[dtype], TDT[dtype], (True if dtype == 'bf16' else 'f16')
+    k16 = 1.0 if dtype == 'bf16' else 0.125           # (half: 3 more mantissa bits)
     N, H, W, Cc = case
     rng = np.random.default_rng(21)
     x = rng.standard_normal((N, Cc, H, W)).astype(np.float32)
@@ -314,14 +340,14 @@ def test_res_block_fused(lib, cuda, case):
     w2 = (rng.standard_normal((Cc, Cc // 2, 3, 3)) / np.sqrt(Cc // 2 * 9)).astype(np.float32)
     s1, b1 = rng.uniform(.5, 1.5, Cc // 2).astype(np.float32), (.3 * rng.standard_normal(Cc // 2)).astype(np.float32)
     s2, b2 = rng.uniform(.5, 1.5, Cc).astype(np.float32), (.3 * rng.standard_normal(Cc)).astype(np.float32)
-    mid = ref_conv(x, w1, s1, b1, 1, 0.1, bf16=True)
-    ref = ref_conv(mid, w2, s2, b2, 1, 0.1, residual=x, bf16=True)
+    mid = ref_conv(x, w1, s1, b1, 1, 0.1, bf16=sim)
+    ref = ref_conv(mid, w2, s2, b2, 1, 0.1, residual=x, bf16=sim)
     st = torch.cuda.current_stream().cuda_stream
 
     def pack(w):
         co, ci, k, _ = w.shape
-        wp = torch.empty(lib.yolo_packed_weight_bytes(co, ci, k, L.BF16), dtype=torch.uint8, device=cuda)
-        L.check(lib.yolo_pack_conv_weights(torch.from_numpy(w).to(cuda).data_ptr(), wp.data_ptr(), co, ci, k, L.BF16, st), 'pack')
+        wp = torch.empty(lib.yolo_packed_weight_bytes(co, ci, k, ldt), dtype=torch.uint8, device=cuda)
+        L.check(lib.yolo_pack_conv_weights(torch.from_numpy(w).to(cuda).data_ptr(), wp.data_ptr(), co, ci, k, ldt, st), 'pack')
         return wp
 
     def padded(v):
@@ -331,21 +357,23 @@ def test_res_block_fused(lib, cuda, case):
 
     wp1, wp2 = pack(w1), pack(w2)
     ts1, tb1, ts2, tb2 = padded(s1), padded(b1), padded(s2), padded(b2)
-    xd = to_nhwc(x, 'bf16', cuda)
-    y = torch.full((N, H, W, Cc), float('nan'), dtype=torch.bfloat16, device=cuda)
+    xd = to_nhwc(x, dtype, cuda)
+    y = torch.full((N, H, W, Cc), float('nan'), dtype=tdt, device=cuda)
     rc = lib.yolo_res_block_fwd(xd.data_ptr(), wp1.data_ptr(), ts1.data_ptr(), tb1.data_ptr(), wp2.data_ptr(), ts2.data_ptr(),
-                                tb2.data_ptr(), y.data_ptr(), N, H, W, Cc, L.BF16, 0.1, st)
+                                tb2.data_ptr(), y.data_ptr(), N, H, W, Cc, ldt, 0.1, st)
     assert rc == 0
     torch.cuda.synchronize()
     got = from_nhwc(y)
     assert np.isfinite(got).all()
     # one bf16 ulp of the output (the mid map may differ from the reference's by one rounding, too)
-    np.testing.assert_allclose(got, ref, rtol=2e-2, atol=3e-2)
-    assert np.abs(got - ref).mean() < 2e-3
+    np.testing.assert_allclose(got, ref, rtol=2e-2 * k16, atol=3e-2 * k16)
+    # (half: a finer mid map flips 8x more often against the reference's, each flip 8x smaller -- the MEAN error does not scale with
+    #  the ulp the way the maximum does)
+    assert np.abs(got - ref).mean() < (2e-3 if dtype == 'bf16' else 5e-4)
     # the two separate layers through yolo_conv_fwd: same operands and rounding points -> equal up to fp32 summation order
-    mid_h = run_conv(lib, cuda, x, w1, s1, b1, 1, 0.1, 'bf16')
-    sep = run_conv(lib, cuda, mid_h, w2, s2, b2, 1, 0.1, 'bf16', residual=x)
-    assert np.mean(got != sep) < 2e-3 and np.abs(got - sep).max() < 0.07
+    mid_h = run_conv(lib, cuda, x, w1, s1, b1, 1, 0.1, dtype)
+    sep = run_conv(lib, cuda, mid_h, w2, s2, b2, 1, 0.1, dtype, residual=x)
+    assert np.mean(got != sep) < 2e-3 and np.abs(got - sep).max() < 0.07 * k16
 
 
 def test_res_block_rejects(lib, cuda):

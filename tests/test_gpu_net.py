@@ -95,6 +95,26 @@ def test_micro_bf16(cuda):
         assert np.abs(o - r.numpy()).max() < 5e-2
 
 
+def test_micro_f16(cuda):
+    """dtype='f16' (the reference's use_fp16, car/YOLO.py:98-100; yolo_gluon.py:211-214) against the half-rounding oracle."""
+    spec, size = og.spec_micro(), (64, 96)
+    g, P, x, net, outs = _run(spec, size, 3, 'f16', 'random', cuda)
+    sim = of.forward_torch_f16sim(g, P, x)
+    ref = of.forward_torch(g, P, x)
+    for o, s, r in zip(outs, sim, ref):
+        np.testing.assert_allclose(o, s.numpy(), rtol=0, atol=3e-3)
+        assert np.abs(o - r.numpy()).max() < 8e-3
+
+
+def test_trainer_refuses_f16(cuda):
+    from yolo_amd.net import CarNet
+    from yolo_amd.train import Trainer
+    from yolo_amd import lib as L
+    net = CarNet(og.spec_micro(), dtype='f16', device=cuda).initialize(seed=0)
+    with pytest.raises(L.YoloError):
+        Trainer(net, (64, 96))
+
+
 def test_d53_416_bf16_vs_sim(cuda):
     """BASELINE config 2 geometry (Darknet-53 spec, 416x416) at B=2: bf16 path vs rounding-aware oracle."""
     spec, size = og.spec_d53(), (416, 416)
@@ -238,7 +258,8 @@ def test_rejects_sizes_the_pyramid_cannot_merge(cuda):
         net(torch.rand((1, 3, 64, 96), device=cuda).double())
 
 
-def test_fused_stem_matches_unfused(cuda):
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+def test_fused_stem_matches_unfused(cuda, dtype):
     """CarNet(fuse_stem=True) (default) runs the stem and the first down-sampling conv as one kernel on the D53 spec;
     the logits must be bit-identical to the layer-by-layer plan."""
     from yolo_amd.net import CarNet
@@ -246,10 +267,11 @@ def test_fused_stem_matches_unfused(cuda):
     x = torch.rand((2, 3, 224, 288), device=cuda)
     outs = []
     for fuse in (True, False):
-        net = CarNet(darknet53_spec(), dtype='bf16', device=cuda, fuse_stem=fuse).initialize(5)
+        net = CarNet(darknet53_spec(), dtype=dtype, device=cuda, fuse_stem=fuse).initialize(5)
         o = net(x)
         kinds = [op[0] for op in net._last_plan.ops]
         assert ('stem_down' in kinds) == fuse and ('stem' in kinds) == (not fuse)
+        assert 'res_block' in kinds                                   # (the fused residual blocks of stages 0-1 run for both 2-byte types)
         outs.append([t.clone() for t in o])
     for a, b in zip(*outs):
         assert torch.equal(a, b)

@@ -7,8 +7,8 @@ import torch.nn.functional as F
 
 from yolo_amd import lib as L
 
-TDT = {'f32': torch.float32, 'bf16': torch.bfloat16}
-LDT = {'f32': L.F32, 'bf16': L.BF16}
+TDT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}
+LDT = {'f32': L.F32, 'bf16': L.BF16, 'f16': L.F16}
 
 
 def to_nhwc(x_nchw, dtype, dev):
@@ -55,9 +55,10 @@ def run_conv(lib, dev, x, w, scale, bias, stride, slope, dtype, residual=None, o
 
 def ref_conv(x, w, scale, bias, stride, slope, residual=None, bf16=False):
     """Oracle for one fused conv: fp32 conv -> *scale+bias -> leaky -> +residual (bf16: operands and
-    result rounded to bf16 where the HIP path rounds)."""
+    result rounded to bf16 -- or, bf16='f16', to IEEE half -- where the HIP path rounds)."""
     xt, wt = torch.from_numpy(x), torch.from_numpy(w)
-    rb = lambda t: t.to(torch.bfloat16).float()
+    rdt = torch.float16 if bf16 == 'f16' else torch.bfloat16
+    rb = lambda t: t.to(rdt).float()
     if bf16:
         xt, wt = rb(xt), rb(wt)
     y = F.conv2d(xt, wt, None, stride=stride, padding=w.shape[2] // 2)

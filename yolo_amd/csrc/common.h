@@ -53,7 +53,53 @@ __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as
 // LeakyReLU for 0 <= slope <= 1 (the dispatchers reject other slopes): max(t, t*slope), two VALU ops
 __device__ __forceinline__ float leaky(float t, float slope) { return fmaxf(t, t * slope); }
 
-static inline int elem_size(int dtype) { return dtype == YOLO_BF16 ? 2 : 4; }
+// IEEE half (YOLO_F16): same storage as bf16_t, another tag.  gfx950 converts pairs with v_cvt_pk_f16_f32 (round-to-nearest-even)
+// and unpacks with v_cvt_f32_f16 (the high half through SDWA): one VALU operation each, like the bf16 forms.
+struct f16_t { uint16_t bits; };
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 yolo_f16x2;
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    const yolo_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, yolo_f16x2));
+}
+// What the kernels need to know about a 2-byte activation type: its name in kernel signatures, how two fp32 values round into a
+// packed pair and how a pair unpacks.  (bf16's forms are the expressions the kernels had inline before round 5.)
+template <typename T> struct Elem;
+template <> struct Elem<bf16_t> {
+    static constexpr const char* name = "bf16_t";
+    static constexpr int dtype = YOLO_BF16;
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+    static __device__ __forceinline__ float lo(uint32_t w) { return bf16_bits_to_f32(w & 0xffffu); }
+    static __device__ __forceinline__ float hi(uint32_t w) { return bf16_bits_to_f32(w >> 16); }
+};
+template <> struct Elem<f16_t> {
+    static constexpr const char* name = "f16_t";
+    static constexpr int dtype = YOLO_F16;
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_f16x2(lo, hi); }
+    static __device__ __forceinline__ float lo(uint32_t w) { return (float)__builtin_bit_cast(yolo_f16x2, w)[0]; }
+    static __device__ __forceinline__ float hi(uint32_t w) { return (float)__builtin_bit_cast(yolo_f16x2, w)[1]; }
+};
+template <> struct Elem<float> {
+    static constexpr const char* name = "float";
+    static constexpr int dtype = YOLO_F32;
+    // (never called: the 4-byte paths are separate branches; present so that `if constexpr (ES == 2)` bodies parse)
+    static __device__ __forceinline__ uint32_t pack2(float, float) { return 0; }
+    static __device__ __forceinline__ float lo(uint32_t) { return 0.f; }
+    static __device__ __forceinline__ float hi(uint32_t) { return 0.f; }
+};
+// one 32x32x16 MFMA step on 2-byte operands (A, B: 8 elements per lane as a uint4)
+template <typename T> __device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, const f32x16& c);
+template <> __device__ __forceinline__ f32x16 mfma16<bf16_t>(const uint4& a, const uint4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16 mfma16<f16_t>(const uint4& a, const uint4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <typename T> struct IsBf16 { static constexpr bool value = false; };
+template <> struct IsBf16<bf16_t> { static constexpr bool value = true; };
+
+static inline int elem_size(int dtype) { return dtype == YOLO_F32 ? 4 : 2; }
+static inline bool dtype_valid(int dtype) { return dtype == YOLO_F32 || dtype == YOLO_BF16 || dtype == YOLO_F16; }
 // channels held by one 64-byte K-chunk
 static inline int chunk_channels(int dtype) { return 64 / elem_size(dtype); }
 // packed weights / scale / bias are padded to a multiple of this many output channels

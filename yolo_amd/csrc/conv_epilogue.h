@@ -12,7 +12,6 @@
 // Rounding order is unchanged: fp32 (acc*scale+bias) -> LeakyReLU -> + residual (fp32) -> round.
 #pragma once
 #include "conv_args.h"
-#include <type_traits>
 
 // bytes of LDS scratch one wave needs (max over MI in {1,2}): 32 rows x (64*4+16) + 2 x 32 x 8 (output offsets) + 2 x 32 x 8
 // (residual offsets, when the residual's strides differ from the output's)
@@ -40,7 +39,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
     constexpr int NPASS = 32 / RPP;
     static_assert(32 * RS + 4 * 32 * 8 <= YOLO_EPI_WAVE_BYTES_MI(MI), "scratch size");
 #ifdef YOLO_LAB
-    if (a.lab & 4) return;
+    if (a.lab & 4) return;                      // (lab: YOLO_EPI_AB ablation bits, conv_args.h)
 #endif
     const int l31 = lane & 31, h = lane >> 5;
     const float slope = a.slope;
@@ -107,8 +106,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                         if (a.out_f32) {
                             ((float*)a.y)[o + e] = t;
                         } else if constexpr (ES == 2) {
-                            if (a.res) t += bf16_bits_to_f32(((const uint16_t*)a.res)[ro + e]);
-                            const uint16_t b16 = (uint16_t)f32_to_bf16_bits(t);
+                            if (a.res) t += Elem<T>::lo(((const uint16_t*)a.res)[ro + e]);
+                            const uint16_t b16 = (uint16_t)(Elem<T>::pack2(t, 0.f) & 0xffffu);
                             ((uint16_t*)a.y)[o + e] = b16;
                             if (a.up2) {
                                 ((uint16_t*)a.y)[o + e + a.y_ps] = b16;
@@ -162,7 +161,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
     const bool res_sep = has_res && roff != nullptr && (a.r_ps != a.y_ps || a.r_bs != a.y_bs);
     float ssum[CPL], qsum[CPL], smu[CPL], sis[CPL], sga[CPL], sbe[CPL];
     if constexpr (STATS != 0) {
-        static_assert(ES == 2, "statistics epilogue: bf16 only");
+        static_assert(IsBf16<T>::value, "statistics epilogue: bf16 only");
 #pragma unroll
         for (int e = 0; e < CPL; ++e) {
             ssum[e] = qsum[e] = 0.f;
@@ -186,143 +185,109 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
         const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)(STATS == 2 ? a.s_y : a.y), 0, 0x7fffffff, 0x00020000);
         int yb[2][NPASS];                       // byte offset of the lane's 16-byte piece in y (-1: none)
         u32x4_t rb[2][NPASS], sb[2][NPASS];
-        const int up_a = (int)(a.y_ps * ES), up_b = (int)(2LL * a.Wo * a.y_ps * ES);      // (up2: the other pixels of the 2x2 patch)
-        // (round 5) The slab loop is SOFTWARE-PIPELINED through the scratch: the transposed rows of slab ni + 1 are written and read
-        // back into a second register set BEFORE slab ni's arithmetic and stores, so a pass never waits for its own ds_read (the ISA
-        // of the previous order: ds_read -> s_waitcnt lgkmcnt -> 24-44 VALU -> store, pass after pass, each read issued only after the
-        // previous pass's store because the uniform branches on `ident` / residual / up2 cut the loop body into basic blocks the
-        // scheduler cannot move loads across).  One scratch is enough: the LDS operations of a wave execute in order, so the
-        // writes of slab ni + 1 cannot overtake the reads of slab ni issued before them.  The uniform decisions (identity epilogue,
-        // residual) are taken ONCE around the whole loop (four specialisations) instead of per pass.  PIPE needs NPASS * CPL more
-        // registers: wave tiles of up to 64 couts (the 128-cout one keeps the plain order).
-        constexpr bool PIPE = MI <= 2;
-        auto run = [&](auto ident_c, auto res_c) __attribute__((always_inline)) {
-            constexpr bool IDENT = decltype(ident_c)::value, RES = decltype(res_c)::value;
-            float tv[PIPE ? 2 : 1][NPASS][CPL];
-            auto prefetch_b = [&](int ni) __attribute__((always_inline)) {
-                if (h == 0) ytab[(ni & 1) * 32 + l31] = yoff[ni];
-                if (res_sep && h == 1) rtab[(ni & 1) * 32 + l31] = roff[ni];
-                wave_lds_fence();
-    #pragma unroll
-                for (int k = 0; k < NPASS; ++k) {
-                    const long long y_ = ytab[(ni & 1) * 32 + row0 + k * RPP];
-                    const bool ok = co_ok && y_ >= 0;
-                    yb[ni & 1][k] = ok ? (int)((y_ + cofs) * ES) : -1;
+        auto prefetch_b = [&](int ni) {
+            if (h == 0) ytab[(ni & 1) * 32 + l31] = yoff[ni];
+            if (res_sep && h == 1) rtab[(ni & 1) * 32 + l31] = roff[ni];
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k) {
+                const long long y_ = ytab[(ni & 1) * 32 + row0 + k * RPP];
+                const bool ok = co_ok && y_ >= 0;
+                yb[ni & 1][k] = ok ? (int)((y_ + cofs) * ES) : -1;
 #ifdef YOLO_LAB
-                    if (a.lab & 1) yb[ni & 1][k] = -1;
+                if (a.lab & 1) yb[ni & 1][k] = -1;
 #endif
-                    if constexpr (RES) {
-                        const long long r_ = res_sep ? rtab[(ni & 1) * 32 + row0 + k * RPP] : y_;
+                if (has_res) {
+                    const long long r_ = res_sep ? rtab[(ni & 1) * 32 + row0 + k * RPP] : y_;
 #ifdef YOLO_LAB
-                        rb[ni & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (ok && !(a.lab & 2)) ? (int)((r_ + cofs) * ES) : -1, 0, 0);
+                    rb[ni & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (ok && !(a.lab & 2)) ? (int)((r_ + cofs) * ES) : -1, 0, 0);
 #else
-                        rb[ni & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, ok ? (int)((r_ + cofs) * ES) : -1, 0, 0);
+                    rb[ni & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, ok ? (int)((r_ + cofs) * ES) : -1, 0, 0);
 #endif
-                    }
-                    if constexpr (STATS == 2) sb[ni & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(srs, yb[ni & 1][k], 0, 0);
                 }
-            };
-            auto write_slab = [&](int ni) __attribute__((always_inline)) {
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
-                        *(f32x4*)(wsm + l31 * RS + (mi * 32 + 8 * g + 4 * h) * 4) = v;
-                    }
-                wave_lds_fence();
-            };
-            auto read_slab = [&](int ni) __attribute__((always_inline)) {
-#pragma unroll
-                for (int k = 0; k < NPASS; ++k)
-#pragma unroll
-                    for (int q = 0; q < CPL / 4; ++q) {
-                        const f32x4 t4 = *(const f32x4*)(wsm + (row0 + k * RPP) * RS + (col * CPL + 4 * q) * 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) tv[PIPE ? (ni & 1) : 0][k][4 * q + e] = t4[e];
-                    }
-                wave_lds_fence();
-            };
-            prefetch_b(0);
-            write_slab(0);
-            read_slab(0);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                if (ni + 1 < NI) {
-                    prefetch_b(ni + 1);
-                    if constexpr (PIPE) { write_slab(ni + 1); read_slab(ni + 1); }
-                }
-#pragma unroll
-                for (int k = 0; k < NPASS; ++k) {
-                    float v[CPL];
-#pragma unroll
-                    for (int e = 0; e < CPL; ++e) v[e] = tv[PIPE ? (ni & 1) : 0][k][e];
-                    if constexpr (!IDENT) {
-#pragma unroll
-                        for (int e = 0; e < CPL; ++e) {
-                            const float t = v[e] * sc[e] + bi[e];
-                            v[e] = leaky(t, slope);
-                        }
-                    }
-                    const int ob = yb[ni & 1][k];
-                    u32x4_t ov;
-                    if constexpr (ES == 2) {
-                        if constexpr (RES) {
-                            const uint32_t w[4] = {rb[ni & 1][k].x, rb[ni & 1][k].y, rb[ni & 1][k].z, rb[ni & 1][k].w};
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                v[2 * q] += bf16_bits_to_f32(w[q] & 0xffffu);
-                                v[2 * q + 1] += bf16_bits_to_f32(w[q] >> 16);
-                            }
-                        }
-                        ov.x = pack_bf16x2(v[0], v[1]); ov.y = pack_bf16x2(v[2], v[3]);
-                        ov.z = pack_bf16x2(v[4], v[5]); ov.w = pack_bf16x2(v[6], v[7]);
-                        if constexpr (STATS != 0) {
-                            const uint32_t ow[4] = {ov.x, ov.y, ov.z, ov.w};
-                            float vr[8];
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) vr[e] = bf16_bits_to_f32((e & 1) ? (ow[e >> 1] >> 16) : (ow[e >> 1] & 0xffffu));
-                            if constexpr (STATS == 1) {
-                                // (lanes past the end of the tensor compute a copy of the tile's first pixel: masked like the store)
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) {
-                                    const float m = ob >= 0 ? vr[e] : 0.f;
-                                    ssum[e] += m; qsum[e] += m * m;
-                                }
-                            } else {
-                                const uint32_t yw[4] = {sb[ni & 1][k].x, sb[ni & 1][k].y, sb[ni & 1][k].z, sb[ni & 1][k].w};
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) {
-                                    const float yv = bf16_bits_to_f32((e & 1) ? (yw[e >> 1] >> 16) : (yw[e >> 1] & 0xffffu));
-                                    const float xh = (yv - smu[e]) * sis[e];
-                                    const float da = (ob >= 0) ? vr[e] * ((sga[e] * xh + sbe[e]) > 0.f ? 1.f : a.s_slope) : 0.f;
-                                    ssum[e] += da; qsum[e] += da * xh;
-                                }
-                            }
-                        }
-                    } else {
-                        if constexpr (RES) {
-                            v[0] += __uint_as_float(rb[ni & 1][k].x); v[1] += __uint_as_float(rb[ni & 1][k].y);
-                            v[2] += __uint_as_float(rb[ni & 1][k].z); v[3] += __uint_as_float(rb[ni & 1][k].w);
-                        }
-                        ov.x = __float_as_uint(v[0]); ov.y = __float_as_uint(v[1]); ov.z = __float_as_uint(v[2]); ov.w = __float_as_uint(v[3]);
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob, 0, 0);
-                    if (a.up2) {                            // the other three pixels of the 2x2 patch (row pitch 2*Wo pixels)
-                        __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_a : -1, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_b : -1, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_b + up_a : -1, 0, 0);
-                    }
-                }
-                if constexpr (!PIPE) {
-                    if (ni + 1 < NI) { write_slab(ni + 1); read_slab(ni + 1); }
-                }
+                if constexpr (STATS == 2) sb[ni & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(srs, yb[ni & 1][k], 0, 0);
             }
         };
-        typedef std::true_type Y_;
-        typedef std::false_type N_;
-        if (ident) { if (has_res) run(Y_{}, Y_{}); else run(Y_{}, N_{}); }
-        else { if (has_res) run(N_{}, Y_{}); else run(N_{}, N_{}); }
+        const int up_a = (int)(a.y_ps * ES), up_b = (int)(2LL * a.Wo * a.y_ps * ES);      // (up2: the other pixels of the 2x2 patch)
+        prefetch_b(0);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            if (ni + 1 < NI) prefetch_b(ni + 1);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+                    *(f32x4*)(wsm + l31 * RS + (mi * 32 + 8 * g + 4 * h) * 4) = v;
+                }
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k) {
+                float v[CPL];
+#pragma unroll
+                for (int q = 0; q < CPL / 4; ++q) {
+                    const f32x4 t4 = *(const f32x4*)(wsm + (row0 + k * RPP) * RS + (col * CPL + 4 * q) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * q + e] = t4[e];
+                }
+                if (!ident) {
+#pragma unroll
+                    for (int e = 0; e < CPL; ++e) {
+                        const float t = v[e] * sc[e] + bi[e];
+                        v[e] = leaky(t, slope);
+                    }
+                }
+                const int ob = yb[ni & 1][k];
+                u32x4_t ov;
+                if constexpr (ES == 2) {
+                    if (has_res) {
+                        const uint32_t w[4] = {rb[ni & 1][k].x, rb[ni & 1][k].y, rb[ni & 1][k].z, rb[ni & 1][k].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[2 * q] += Elem<T>::lo(w[q]);
+                            v[2 * q + 1] += Elem<T>::hi(w[q]);
+                        }
+                    }
+                    ov.x = Elem<T>::pack2(v[0], v[1]); ov.y = Elem<T>::pack2(v[2], v[3]);
+                    ov.z = Elem<T>::pack2(v[4], v[5]); ov.w = Elem<T>::pack2(v[6], v[7]);
+                    if constexpr (STATS != 0) {
+                        const uint32_t ow[4] = {ov.x, ov.y, ov.z, ov.w};
+                        float vr[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) vr[e] = ((e & 1) ? Elem<T>::hi(ow[e >> 1]) : Elem<T>::lo(ow[e >> 1]));
+                        if constexpr (STATS == 1) {
+                            // (lanes past the end of the tensor compute a copy of the tile's first pixel: masked like the store)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float m = ob >= 0 ? vr[e] : 0.f;
+                                ssum[e] += m; qsum[e] += m * m;
+                            }
+                        } else {
+                            const uint32_t yw[4] = {sb[ni & 1][k].x, sb[ni & 1][k].y, sb[ni & 1][k].z, sb[ni & 1][k].w};
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float yv = ((e & 1) ? Elem<T>::hi(yw[e >> 1]) : Elem<T>::lo(yw[e >> 1]));
+                                const float xh = (yv - smu[e]) * sis[e];
+                                const float da = (ob >= 0) ? vr[e] * ((sga[e] * xh + sbe[e]) > 0.f ? 1.f : a.s_slope) : 0.f;
+                                ssum[e] += da; qsum[e] += da * xh;
+                            }
+                        }
+                    }
+                } else {
+                    if (has_res) {
+                        v[0] += __uint_as_float(rb[ni & 1][k].x); v[1] += __uint_as_float(rb[ni & 1][k].y);
+                        v[2] += __uint_as_float(rb[ni & 1][k].z); v[3] += __uint_as_float(rb[ni & 1][k].w);
+                    }
+                    ov.x = __float_as_uint(v[0]); ov.y = __float_as_uint(v[1]); ov.z = __float_as_uint(v[2]); ov.w = __float_as_uint(v[3]);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob, 0, 0);
+                if (a.up2) {                            // the other three pixels of the 2x2 patch (row pitch 2*Wo pixels)
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_a : -1, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_b : -1, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_b + up_a : -1, 0, 0);
+                }
+            }
+        }
     } else {
     // The residual loads of slab ni+1 are issued BEFORE slab ni is processed (two register sets), so their latency
     // hides under the previous slab's transpose/arithmetic/stores -- the phase stamps showed one exposed memory
@@ -387,18 +352,18 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                     const uint32_t w[4] = {rv[ni & 1][k].x, rv[ni & 1][k].y, rv[ni & 1][k].z, rv[ni & 1][k].w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        v[2 * q] += bf16_bits_to_f32(w[q] & 0xffffu);
-                        v[2 * q + 1] += bf16_bits_to_f32(w[q] >> 16);
+                        v[2 * q] += Elem<T>::lo(w[q]);
+                        v[2 * q + 1] += Elem<T>::hi(w[q]);
                     }
                 }
-                ov = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                                pack_bf16x2(v[6], v[7]));
+                ov = make_uint4(Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2], v[3]), Elem<T>::pack2(v[4], v[5]),
+                                Elem<T>::pack2(v[6], v[7]));
                 if constexpr (STATS != 0) {
                     // the statistics of the STORED (bf16-rounded) values: what the separate reduction pass would read
                     const uint32_t ow[4] = {ov.x, ov.y, ov.z, ov.w};
                     float vr[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) vr[e] = bf16_bits_to_f32((e & 1) ? (ow[e >> 1] >> 16) : (ow[e >> 1] & 0xffffu));
+                    for (int e = 0; e < 8; ++e) vr[e] = ((e & 1) ? Elem<T>::hi(ow[e >> 1]) : Elem<T>::lo(ow[e >> 1]));
                     if constexpr (STATS == 1) {
                         // (lanes past the end of the tensor compute a copy of the tile's first pixel: masked like the store)
                         if (yo[ni & 1][k] >= 0) {
@@ -409,7 +374,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                         const uint32_t yw[4] = {sv[ni & 1][k].x, sv[ni & 1][k].y, sv[ni & 1][k].z, sv[ni & 1][k].w};
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            const float yv = bf16_bits_to_f32((e & 1) ? (yw[e >> 1] >> 16) : (yw[e >> 1] & 0xffffu));
+                            const float yv = ((e & 1) ? Elem<T>::hi(yw[e >> 1]) : Elem<T>::lo(yw[e >> 1]));
                             const float xh = (yv - smu[e]) * sis[e];
                             const float da = (yo[ni & 1][k] >= 0) ? vr[e] * ((sga[e] * xh + sbe[e]) > 0.f ? 1.f : a.s_slope) : 0.f;
                             ssum[e] += da; qsum[e] += da * xh;

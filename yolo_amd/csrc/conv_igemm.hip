@@ -28,6 +28,11 @@ template <> struct Frag<bf16_t> {
                                                     __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
 };
+template <> struct Frag<f16_t> {
+    static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
 template <> struct Frag<float> {
     // 16 bytes = 4 f32 per lane half -> four 32x32x2 steps; step s contracts k = {s, 4+s} of
     // the 8 channels in this 32-byte sub-chunk (same mapping on A and B, so any order is exact).
@@ -291,17 +296,17 @@ static int launch_cfg(ConvArgs& a, hipStream_t st, const NameOut* name) {
     const long long grid = (long long)a.nstrips * a.tiles_per_strip * a.tiles_c;
     if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
     // BatchNorm forward sums in the epilogue (stats_mode 1 only here; conv_epilogue.h)
-    constexpr bool kStats = sizeof(T) == 2;
+    constexpr bool kStats = IsBf16<T>::value;
     const bool stats_ok = kStats && a.stats_mode == 1 && !a.out_f32 && !a.d2s && !a.up2 && (a.Cout % 8) == 0 && (a.y_ps % 8) == 0 &&
                           (a.y_bs % 8) == 0;
     if (a.stats && !stats_ok) return YOLO_EUNSUPPORTED;
     if (name) {
         if (a.stats)
             snprintf(name->buf, name->len, "void conv_igemm_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, 1>(ConvArgs)",
-                     sizeof(T) == 2 ? "bf16_t" : "float", KS, S, WAVES_P, WAVES_C, MI, NI, XSLOTS, TS);
+                     Elem<T>::name, KS, S, WAVES_P, WAVES_C, MI, NI, XSLOTS, TS);
         else
             snprintf(name->buf, name->len, "void conv_igemm_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d>(ConvArgs)",
-                     sizeof(T) == 2 ? "bf16_t" : "float", KS, S, WAVES_P, WAVES_C, MI, NI, XSLOTS, TS);
+                     Elem<T>::name, KS, S, WAVES_P, WAVES_C, MI, NI, XSLOTS, TS);
         if (name->stats_rows) *name->stats_rows = a.stats ? a.nstrips * a.tiles_per_strip * WAVES_P : -1;
         return YOLO_OK;
     }
@@ -398,7 +403,7 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     if (d->ksize != 1 && d->ksize != 3) return YOLO_EUNSUPPORTED;
     if (d->stride != 1 && d->stride != 2) return YOLO_EUNSUPPORTED;
     if (d->ksize == 1 && d->stride != 1) return YOLO_EUNSUPPORTED;
-    if (d->dtype != YOLO_F32 && d->dtype != YOLO_BF16) return YOLO_EINVAL;
+    if (!dtype_valid(d->dtype)) return YOLO_EINVAL;
     if (!(d->slope >= 0.f && d->slope <= 1.f)) return YOLO_EINVAL;       // LeakyReLU is computed as max(t, t*slope)
     const int es = elem_size(d->dtype);
     if ((d->Cin * es) % 16) return YOLO_EUNSUPPORTED;                 // 16-byte K units
@@ -450,7 +455,7 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     if (a.t_wp) {
         // fused tail 1x1: pipelined 3x3 variants with 256-cout tiles only (conv_pipe.hip)
         if (!d->tail_y || (!d->tail_scale != !d->tail_bias) || d->tail_cout <= 0 || !(d->tail_slope >= 0.f && d->tail_slope <= 1.f)) return YOLO_EINVAL;
-        if (a.stats || d->dtype != YOLO_BF16 || d->ksize != 3) return YOLO_EUNSUPPORTED;
+        if (a.stats || elem_size(d->dtype) != 2 || d->ksize != 3) return YOLO_EUNSUPPORTED;
         if (!d->tail_out_f32 && (d->tail_cout % 4)) return YOLO_EUNSUPPORTED;
         if (d->algo) return conv_pipe_dispatch(a, d->ksize, d->stride, d->dtype, d->algo, st, nm);
         // (tiles that hold every channel of a pixel: 128-cout tiles first when Cout <= 128, else the 256-cout ones)
@@ -508,6 +513,7 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
         }
     }
     if (d->dtype == YOLO_BF16) return launch_dtype<bf16_t>(a, d->ksize, d->stride, st, nm);
+    if (d->dtype == YOLO_F16) return launch_dtype<f16_t>(a, d->ksize, d->stride, st, nm);
     return launch_dtype<float>(a, d->ksize, d->stride, st, nm);
 }
 
@@ -603,7 +609,7 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ w, T* __restr
         }
     }
     if constexpr (sizeof(T) == 2)
-        ((uint16_t*)out)[idx] = (uint16_t)f32_to_bf16_bits(v);
+        ((uint16_t*)out)[idx] = (uint16_t)(Elem<T>::pack2(v, 0.f) & 0xffffu);
     else
         out[idx] = v;
 }
@@ -658,6 +664,9 @@ extern "C" int yolo_pack_conv_weights_batch(const void* items_device, const long
         return YOLO_EINVAL;
     if (dtype == YOLO_BF16)
         YOLO_LAUNCH(pack_weights_batch_kernel<bf16_t>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                    (const PackItem*)items_device, first_block_device, n_items);
+    else if (dtype == YOLO_F16)
+        YOLO_LAUNCH(pack_weights_batch_kernel<f16_t>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
                     (const PackItem*)items_device, first_block_device, n_items);
     else if (dtype == YOLO_F32)
         YOLO_LAUNCH(pack_weights_batch_kernel<float>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
@@ -740,7 +749,7 @@ extern "C" int yolo_pack_conv_weights_pairs(const void* items_device, const long
 
 extern "C" long long yolo_packed_weight_bytes(int Cout, int Cin, int ksize, int dtype) {
     if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 2 && ksize != 3)) return YOLO_EINVAL;
-    if (dtype != YOLO_BF16 && dtype != YOLO_F32) return YOLO_EINVAL;
+    if (!dtype_valid(dtype)) return YOLO_EINVAL;
     const int nchunks = (Cin * elem_size(dtype) + 63) / 64;
     return (long long)nchunks * ksize * ksize * round_up(Cout, YOLO_COUT_PAD) * 64;
 }
@@ -783,6 +792,9 @@ static int pack_impl(const float* w_oihw, void* packed, int Cout, int Cin, int k
     if (dtype == YOLO_BF16)
         YOLO_LAUNCH(pack_weights_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
                            (bf16_t*)packed, Cout, Cin, ksize, Cout_pad, nchunks, dgrad);
+    else if (dtype == YOLO_F16)
+        YOLO_LAUNCH(pack_weights_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                           (f16_t*)packed, Cout, Cin, ksize, Cout_pad, nchunks, dgrad);
     else
         YOLO_LAUNCH(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
                            (float*)packed, Cout, Cin, ksize, Cout_pad, nchunks, dgrad);

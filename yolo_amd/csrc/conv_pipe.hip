@@ -69,6 +69,11 @@ template <> struct FragP<bf16_t> {
                                                     0, 0);
     }
 };
+template <> struct FragP<f16_t> {
+    static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
 template <> struct FragP<float> {
     static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16& c) {
         c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
@@ -92,16 +97,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // they are interleaved between the MFMAs, and the second half of the waves (which shares SIMDs with
 // the first half) issues them at shifted positions, so a wave stuck in a DMA issue is covered by its
 // SIMD partner's MFMAs.
-// Second launch bound = waves per SIMD the register allocation must leave room for.  The 4-wave blocks are meant to be
-// co-resident (two per CU; four for the 32-accumulator tiles): without the bound the allocator sees a 512-register budget and an
-// epilogue that holds more values in flight (round 5: the software-pipelined transpose) costs the second block -- the metadata
-// showed the 192 x 128 tile go from 236 to 308 registers under the first such change.  The 128 x 128 wave tile (W1) is built
-// for one wave per SIMD.
-template <int NW, int MI, int NI, int STATS> struct PipeMinWaves {       // (STATS 2, the data-gradient sums: ~100 more live values, unbounded as before)
-    static constexpr int value = (NW != 4 || STATS == 2) ? 1 : (MI == 4 ? 1 : (MI * NI * 16 <= 32 ? 4 : 2));
-};
 template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1, int RD = 0, int KC = 1, int LEAN = 0, int STATS = 0>
-__global__ __launch_bounds__(WAVES_P* WAVES_C * 64, (PipeMinWaves<WAVES_P * WAVES_C, MI, NI, STATS>::value)) void conv_pipe_kernel(ConvArgs a) {
+__global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvArgs a) {
     constexpr int PT = 1;
     constexpr int NW = WAVES_P * WAVES_C;
     constexpr int NT = NW * 64;
@@ -734,7 +731,7 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     conv_args_fastdiv(a);
     // BatchNorm statistics in the epilogue: bf16, the transposed store path (conv_epilogue.h), no sub-pixel / up-sampled
     // stores; the data-gradient sums (mode 2) only on stride-1 kernels
-    constexpr bool kStats = sizeof(T) == 2 && KS != 2;
+    constexpr bool kStats = IsBf16<T>::value && KS != 2;
     const bool stats_ok = kStats && !a.out_f32 && !a.d2s && !a.up2 && (a.Cout % 8) == 0 && (a.y_ps % 8) == 0 && (a.y_bs % 8) == 0 &&
                           (a.stats_mode == 1 || (a.stats_mode == 2 && S == 1 && a.y_ps == a.Cout));
     if (a.stats && !stats_ok) return YOLO_EUNSUPPORTED;
@@ -748,7 +745,7 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     }
     if (name) {
         snprintf(name->buf, name->len, "void conv_pipe_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d>(ConvArgs)",
-                 sizeof(T) == 2 ? "bf16_t" : "float", KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC, LEAN,
+                 Elem<T>::name, KS, WAVES_P, WAVES_C, MI, NI, XSLOTS, S, RD, KC, LEAN,
                  a.t_wp ? 3 : (a.stats && stats_ok) ? a.stats_mode : 0);
         if (name->stats_rows) *name->stats_rows = (a.stats && stats_ok) ? a.nstrips * a.tiles_per_strip * WAVES_P : -1;
         return YOLO_OK;
@@ -824,11 +821,11 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
         }
         return YOLO_EUNSUPPORTED;
     }
-    return conv_pipe_dispatch_b(a, ks, sizeof(T) == 2 ? YOLO_BF16 : YOLO_F32, algo, st, nm);
+    return conv_pipe_dispatch_b(a, ks, Elem<T>::dtype, algo, st, nm);
 #else
     if (ks == 2) {
         // 2x2 window (yolo_conv_dgrad_s2, bf16 only): four phases per K chunk
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (IsBf16<T>::value) {
             switch (algo) {
                 case 2: return launch_pipe<T, 2, 2, 4, 2, 4, 512>(a, st, nm);    // 256 px x 256 cout
                 case 6: return launch_pipe<T, 2, 2, 4, 2, 3, 384>(a, st, nm);    // 192 px x 256 cout
@@ -881,6 +878,7 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
 #if YOLO_PIPE_PART == 1
 int conv_pipe_dispatch_b(ConvArgs& a, int ks, int dtype, int algo, hipStream_t st, const NameOut* nm) {
     if (dtype == YOLO_BF16) return pipe_dispatch_t<bf16_t>(a, ks, 1, algo, st, nm);
+    if (dtype == YOLO_F16) return pipe_dispatch_t<f16_t>(a, ks, 1, algo, st, nm);
     return pipe_dispatch_t<float>(a, ks, 1, algo, st, nm);
 }
 #else
@@ -891,6 +889,7 @@ int conv_pipe_dispatch(ConvArgs& a, int ks, int stride, int dtype, int algo, hip
     if (ks == 1 && a.nchunks < 2) return YOLO_EUNSUPPORTED;     // a 1x1 needs >= 2 phases; a 3x3 has 9 per chunk
     if ((long long)a.N * a.H * a.W * a.x_ps * elem_size(dtype) >= 0xffffff00LL) return YOLO_EUNSUPPORTED;
     if (dtype == YOLO_BF16) return pipe_dispatch_t<bf16_t>(a, ks, stride, algo, st, nm);
+    if (dtype == YOLO_F16) return pipe_dispatch_t<f16_t>(a, ks, stride, algo, st, nm);
     return pipe_dispatch_t<float>(a, ks, stride, algo, st, nm);
 }
 #endif

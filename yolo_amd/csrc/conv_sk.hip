@@ -30,6 +30,11 @@ template <> struct FragS<bf16_t> {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
 };
+template <> struct FragS<f16_t> {
+    static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
 template <> struct FragS<float> {
     static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16& c) {
         c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
@@ -217,7 +222,7 @@ static int launch_sk(ConvArgs& a, hipStream_t st, const NameOut* nm) {
     if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
     conv_args_fastdiv(a);
     if (nm) {
-        snprintf(nm->buf, nm->len, "void conv_sk_kernel<%s, %d, %d, %d, %d, %d, %d>(ConvArgs)", sizeof(T) == 2 ? "bf16_t" : "float", KG,
+        snprintf(nm->buf, nm->len, "void conv_sk_kernel<%s, %d, %d, %d, %d, %d, %d>(ConvArgs)", Elem<T>::name, KG,
                  WAVES_P, WAVES_C, MI, NI, R);
         if (nm->stats_rows) *nm->stats_rows = -1;
         return YOLO_OK;
@@ -248,5 +253,6 @@ int conv_sk_dispatch(ConvArgs& a, int ks, int stride, int dtype, int algo, hipSt
     if ((a.Cin * elem_size(dtype)) % 64) return YOLO_EUNSUPPORTED;
     if ((long long)a.N * a.H * a.W * a.x_ps * elem_size(dtype) >= 0xffffff00LL) return YOLO_EUNSUPPORTED;
     if (dtype == YOLO_BF16) return sk_dispatch_t<bf16_t>(a, algo, st, nm);
+    if (dtype == YOLO_F16) return sk_dispatch_t<f16_t>(a, algo, st, nm);
     return sk_dispatch_t<float>(a, algo, st, nm);
 }

@@ -31,7 +31,7 @@ struct StreamArgs {
                             // (slice * blocks_x + block_x) * WAVES_P + pixel wave
 };
 
-template <int KS, int S, int CIN, int COUT, int NI, int STATS = 0>
+template <int KS, int S, int CIN, int COUT, int NI, int STATS = 0, typename T = bf16_t>
 __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
     constexpr int WAVES_C = COUT / 32, WAVES_P = 4 / WAVES_C;
     constexpr int TW = WAVES_P * NI * 32;               // output pixels per step (strip width capacity)
@@ -189,8 +189,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
                         const uint4 bf = *(const uint4*)(rowp + (ni * 32 * S + kw) * PITCH + kc * 32);
-                        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[(kh * KS + kw) * KC + kc]),
-                                                                          __builtin_bit_cast(bf16x8, bf), acc[ni], 0, 0, 0);
+                        acc[ni] = mfma16<T>(A[(kh * KS + kw) * KC + kc], bf, acc[ni]);
                     }
                 }
         }
@@ -224,19 +223,19 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
                     const uint32_t w[4] = {rv[ni][k].x, rv[ni][k].y, rv[ni][k].z, rv[ni][k].w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        v[2 * q] += bf16_bits_to_f32(w[q] & 0xffffu);
-                        v[2 * q + 1] += bf16_bits_to_f32(w[q] >> 16);
+                        v[2 * q] += Elem<T>::lo(w[q]);
+                        v[2 * q + 1] += Elem<T>::hi(w[q]);
                     }
                 }
                 if (yo[ni][k] >= 0) {
-                    const uint4 o = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                                               pack_bf16x2(v[6], v[7]));
+                    const uint4 o = make_uint4(Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2], v[3]), Elem<T>::pack2(v[4], v[5]),
+                                               Elem<T>::pack2(v[6], v[7]));
                     *(uint4*)(a.y + yo[ni][k]) = o;
                     if constexpr (STATS) {
                         const uint32_t ow[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            const float t = bf16_bits_to_f32((e & 1) ? (ow[e >> 1] >> 16) : (ow[e >> 1] & 0xffffu));
+                            const float t = ((e & 1) ? Elem<T>::hi(ow[e >> 1]) : Elem<T>::lo(ow[e >> 1]));
                             ssum[e] += t; qsum[e] += t * t;
                         }
                     }
@@ -273,7 +272,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
     }
 }
 
-template <int KS, int S, int CIN, int COUT, int NI>
+template <int KS, int S, int CIN, int COUT, int NI, typename T = bf16_t>
 static int launch_stream(const ConvArgs& c, hipStream_t st, const NameOut* nm) {
     constexpr int TW = (4 / (COUT / 32)) * NI * 32;
     if (c.stats && (c.stats_mode != 1 || c.res)) return YOLO_EUNSUPPORTED;      // forward sums only
@@ -292,32 +291,38 @@ static int launch_stream(const ConvArgs& c, hipStream_t st, const NameOut* nm) {
     slices = (c.Ho + a.rows_per_slice - 1) / a.rows_per_slice;
     a.stats = c.stats;
     if (nm) {
-        snprintf(nm->buf, nm->len, c.stats ? "void conv_stream_kernel<%d, %d, %d, %d, %d, 1>(StreamArgs)"
-                                           : "void conv_stream_kernel<%d, %d, %d, %d, %d>(StreamArgs)", KS, S, CIN, COUT, NI);
+        snprintf(nm->buf, nm->len, c.stats ? "void conv_stream_kernel<%d, %d, %d, %d, %d, 1, %s>(StreamArgs)"
+                                           : "void conv_stream_kernel<%d, %d, %d, %d, %d, 0, %s>(StreamArgs)", KS, S, CIN, COUT, NI, Elem<T>::name);
         if (nm->stats_rows) *nm->stats_rows = c.stats ? (int)(bx * slices * (4 / (COUT / 32))) : -1;
         return YOLO_OK;
     }
-    if (c.stats) {
-        YOLO_LAUNCH((conv_stream_kernel<KS, S, CIN, COUT, NI, 1>), dim3((unsigned)bx, (unsigned)slices), dim3(256), 0, st, a);
-        YOLO_LAUNCH_CHECK();
-        return YOLO_OK;
+    if constexpr (IsBf16<T>::value) {
+        if (c.stats) {
+            YOLO_LAUNCH((conv_stream_kernel<KS, S, CIN, COUT, NI, 1, T>), dim3((unsigned)bx, (unsigned)slices), dim3(256), 0, st, a);
+            YOLO_LAUNCH_CHECK();
+            return YOLO_OK;
+        }
+    } else if (c.stats) {
+        return YOLO_EUNSUPPORTED;                                   // (the statistics epilogue belongs to the bf16 training step)
     }
-    YOLO_LAUNCH((conv_stream_kernel<KS, S, CIN, COUT, NI>), dim3((unsigned)bx, (unsigned)slices), dim3(256), 0, st, a);
+    YOLO_LAUNCH((conv_stream_kernel<KS, S, CIN, COUT, NI, 0, T>), dim3((unsigned)bx, (unsigned)slices), dim3(256), 0, st, a);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
 
 // algo 13 (NI = 1) / 14 (NI = 2: twice the strip width per step)
 int conv_stream_dispatch(const ConvArgs& c, int ks, int stride, int dtype, int algo, hipStream_t st, const NameOut* nm) {
-    if (dtype != YOLO_BF16 || c.out_f32 || c.up2 || c.x_ps != c.Cin) return YOLO_EUNSUPPORTED;
+    if ((dtype != YOLO_BF16 && dtype != YOLO_F16) || c.out_f32 || c.up2 || c.x_ps != c.Cin) return YOLO_EUNSUPPORTED;
+    const bool half = dtype == YOLO_F16;
     if (c.y_ps != c.Cout || c.y_bs != (long long)c.Ho * c.Wo * c.Cout) return YOLO_EUNSUPPORTED;
     const int ni = algo == 14 ? 2 : 1;
 #define STREAM_CASE(KS_, S_, CIN_, COUT_)                                                        \
     if (ks == KS_ && stride == S_ && c.Cin == CIN_ && c.Cout == COUT_)                           \
-        return ni == 2 ? launch_stream<KS_, S_, CIN_, COUT_, 2>(c, st, nm) : launch_stream<KS_, S_, CIN_, COUT_, 1>(c, st, nm);
+        return half ? (ni == 2 ? launch_stream<KS_, S_, CIN_, COUT_, 2, f16_t>(c, st, nm) : launch_stream<KS_, S_, CIN_, COUT_, 1, f16_t>(c, st, nm)) \
+                    : (ni == 2 ? launch_stream<KS_, S_, CIN_, COUT_, 2>(c, st, nm) : launch_stream<KS_, S_, CIN_, COUT_, 1>(c, st, nm));
 #define STREAM_CASE1(KS_, S_, CIN_, COUT_)                                                       \
     if (ks == KS_ && stride == S_ && c.Cin == CIN_ && c.Cout == COUT_ && ni == 1)                \
-        return launch_stream<KS_, S_, CIN_, COUT_, 1>(c, st, nm);
+        return half ? launch_stream<KS_, S_, CIN_, COUT_, 1, f16_t>(c, st, nm) : launch_stream<KS_, S_, CIN_, COUT_, 1>(c, st, nm);
     STREAM_CASE(3, 1, 32, 64)
     STREAM_CASE(3, 1, 64, 128)
     STREAM_CASE1(3, 1, 64, 32)

@@ -50,7 +50,7 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__
     if constexpr (sizeof(T) == 2) {
         uint32_t w[CPAD / 2];
 #pragma unroll
-        for (int c = 0; c < CPAD / 2; ++c) w[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
+        for (int c = 0; c < CPAD / 2; ++c) w[c] = Elem<T>::pack2(v[2 * c], v[2 * c + 1]);
         uint4* dst = (uint4*)((uint16_t*)y + p * CPAD);
 #pragma unroll
         for (int q = 0; q < CPAD / 8; ++q) dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
@@ -73,6 +73,9 @@ extern "C" int yolo_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, i
     if (dtype == YOLO_BF16)
         YOLO_LAUNCH((nchw_to_nhwc_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
                            (bf16_t*)y, C, HW, total);
+    else if (dtype == YOLO_F16)
+        YOLO_LAUNCH((nchw_to_nhwc_kernel<f16_t, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
+                           (f16_t*)y, C, HW, total);
     else if (dtype == YOLO_F32)
         YOLO_LAUNCH((nchw_to_nhwc_kernel<float, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
                            (float*)y, C, HW, total);
@@ -112,7 +115,7 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__
     const long long n = nc / C, c = nc - n * C;
     const long long src = (n * HW + hw) * C + c;
     if constexpr (sizeof(T) == 2)
-        y[idx] = bf16_bits_to_f32(((const uint16_t*)x)[src]);
+        y[idx] = Elem<T>::lo(((const uint16_t*)x)[src]);
     else
         y[idx] = x[src];
 }
@@ -124,6 +127,9 @@ extern "C" int yolo_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, i
     if (dtype == YOLO_BF16)
         YOLO_LAUNCH(nhwc_to_nchw_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)x, y, C, HW, total);
+    else if (dtype == YOLO_F16)
+        YOLO_LAUNCH(nhwc_to_nchw_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const f16_t*)x, y, C, HW, total);
     else if (dtype == YOLO_F32)
         YOLO_LAUNCH(nhwc_to_nchw_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const float*)x, y, C, HW, total);

@@ -48,7 +48,7 @@ struct ResArgs {
 };
 }  // namespace
 
-template <int C, int D>
+template <int C, int D, typename T = bf16_t>
 __global__ __launch_bounds__(256) void res_block_kernel(ResArgs a) {
     constexpr int CM = C / 2;
     constexpr int WAVES_C = C / 32, WAVES_P = 4 / WAVES_C, NI = 2 / WAVES_P;   // 3x3: wave = (cout slice, pixel group)
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void res_block_kernel(ResArgs a) {
 #pragma unroll
         for (int kc = 0; kc < K1; ++kc) {
             const uint4 bf = *(const uint4*)(xp + kc * 32);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A1[kc]), __builtin_bit_cast(bf16x8, bf), acc, 0, 0, 0);
+            acc = mfma16<T>(A1[kc], bf, acc);
         }
         const int px = p1 * 32 + l31;
         const int mx = mx0 + px;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void res_block_kernel(ResArgs a) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = leaky(acc[4 * g + e] * sc1[4 * g + e] + bi1[4 * g + e], slope);
-            *(uint2*)(dst + (8 * g + 4 * h) * 2) = inside ? make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])) : make_uint2(0u, 0u);
+            *(uint2*)(dst + (8 * g + 4 * h) * 2) = inside ? make_uint2(Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2], v[3])) : make_uint2(0u, 0u);
         }
     };
 
@@ -228,8 +228,7 @@ __global__ __launch_bounds__(256) void res_block_kernel(ResArgs a) {
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
                         const uint4 bf = *(const uint4*)(rowp + (ni * 32 + kw) * PM + kc * 32);
-                        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A2[(kh * 3 + kw) * K2 + kc]),
-                                                                          __builtin_bit_cast(bf16x8, bf), acc[ni], 0, 0, 0);
+                        acc[ni] = mfma16<T>(A2[(kh * 3 + kw) * K2 + kc], bf, acc[ni]);
                     }
         }
         // ---- epilogue: folded BN, LeakyReLU, + x (from the input ring, fp32), one rounding, 16-byte row stores ---------
@@ -258,13 +257,13 @@ __global__ __launch_bounds__(256) void res_block_kernel(ResArgs a) {
                 for (int e = 0; e < 8; ++e) v[e] = leaky(v[e] * sc2[e] + bi2[e], slope);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    v[2 * q] += bf16_bits_to_f32(w[q] & 0xffffu);
-                    v[2 * q + 1] += bf16_bits_to_f32(w[q] >> 16);
+                    v[2 * q] += Elem<T>::lo(w[q]);
+                    v[2 * q + 1] += Elem<T>::hi(w[q]);
                 }
                 const int ox = ox0 + px;
                 if (ox < ox_end)
                     *(uint4*)(a.y + ((((long long)n * H + oy) * W + ox) * C + eco) * 2) =
-                        make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+                        make_uint4(Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2], v[3]), Elem<T>::pack2(v[4], v[5]), Elem<T>::pack2(v[6], v[7]));
             }
         }
         if (more) store_x(xr[u], slot3(oy + 2));
@@ -281,7 +280,7 @@ __global__ __launch_bounds__(256) void res_block_kernel(ResArgs a) {
 // of a step occupy all four waves at C = 64, and the barriers, ring bookkeeping and loop overhead are paid once per two
 // rows.  Input ring: 5 rows (oy, oy+1: residuals; oy+1, oy+2: operands of the step's mid rows; oy+3, oy+4: arriving); mid ring:
 // 4 rows (oy-1 .. oy+2).  Same operands, accumulation order (kernel row, kernel column, channel) and rounding points.
-template <int C, int D>
+template <int C, int D, typename T = bf16_t>
 __global__ __launch_bounds__(256) void res_block2_kernel(ResArgs a) {
     constexpr int CM = C / 2;
     constexpr int WAVES_C = C / 32, WAVES_P = 4 / WAVES_C, NI = 2 / WAVES_P;
@@ -396,7 +395,7 @@ __global__ __launch_bounds__(256) void res_block2_kernel(ResArgs a) {
 #pragma unroll
         for (int kc = 0; kc < K1; ++kc) {
             const uint4 bf = *(const uint4*)(xp + kc * 32);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A1[kc]), __builtin_bit_cast(bf16x8, bf), acc, 0, 0, 0);
+            acc = mfma16<T>(A1[kc], bf, acc);
         }
         const int px = p1 * 32 + l31;
         const int mx = mx0 + px;
@@ -407,7 +406,7 @@ __global__ __launch_bounds__(256) void res_block2_kernel(ResArgs a) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = leaky(acc[4 * g + e] * sc1[4 * g + e] + bi1[4 * g + e], slope);
-            *(uint2*)(dst + (8 * g + 4 * h) * 2) = inside ? make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])) : make_uint2(0u, 0u);
+            *(uint2*)(dst + (8 * g + 4 * h) * 2) = inside ? make_uint2(Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2], v[3])) : make_uint2(0u, 0u);
         }
     };
     // the two mid rows my0, my0 + 1 of a step
@@ -463,11 +462,9 @@ __global__ __launch_bounds__(256) void res_block2_kernel(ResArgs a) {
                     for (int ni = 0; ni < NI; ++ni) {
                         const uint4 bf = *(const uint4*)(rowp + (ni * 32 + kw) * PM + kc * 32);
                         if (m <= 2)
-                            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A2[(m * 3 + kw) * K2 + kc]),
-                                                                                 __builtin_bit_cast(bf16x8, bf), acc[0][ni], 0, 0, 0);
+                            acc[0][ni] = mfma16<T>(A2[(m * 3 + kw) * K2 + kc], bf, acc[0][ni]);
                         if (m >= 1)
-                            acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A2[((m - 1) * 3 + kw) * K2 + kc]),
-                                                                                 __builtin_bit_cast(bf16x8, bf), acc[1][ni], 0, 0, 0);
+                            acc[1][ni] = mfma16<T>(A2[((m - 1) * 3 + kw) * K2 + kc], bf, acc[1][ni]);
                     }
         }
         // ---- epilogue of both rows: folded BN, LeakyReLU, + x (input ring, fp32), one rounding, 16-byte row stores ----------
@@ -499,13 +496,13 @@ __global__ __launch_bounds__(256) void res_block2_kernel(ResArgs a) {
                     for (int e = 0; e < 8; ++e) v[e] = leaky(v[e] * sc2[e] + bi2[e], slope);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        v[2 * q] += bf16_bits_to_f32(w[q] & 0xffffu);
-                        v[2 * q + 1] += bf16_bits_to_f32(w[q] >> 16);
+                        v[2 * q] += Elem<T>::lo(w[q]);
+                        v[2 * q + 1] += Elem<T>::hi(w[q]);
                     }
                     const int ox = ox0 + px;
                     if (ox < ox_end)
                         *(uint4*)(a.y + ((((long long)n * H + oy + r) * W + ox) * C + eco) * 2) =
-                            make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+                            make_uint4(Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2], v[3]), Elem<T>::pack2(v[4], v[5]), Elem<T>::pack2(v[6], v[7]));
                 }
             }
         }
@@ -515,7 +512,7 @@ __global__ __launch_bounds__(256) void res_block2_kernel(ResArgs a) {
     }
 }
 
-template <int C, int D>
+template <int C, int D, typename T = bf16_t>
 static int launch_res_block2(ResArgs& a, hipStream_t st) {
     a.nstrips = (a.W + SW_MAX - 1) / SW_MAX;
     a.strip_w = (a.W + a.nstrips - 1) / a.nstrips;
@@ -533,12 +530,12 @@ static int launch_res_block2(ResArgs& a, hipStream_t st) {
     rows += rows & 1;                                            // even slices: no half-used step in the middle of the image
     a.rows_per_slice = (int)rows;
     const long long slices = (a.H + a.rows_per_slice - 1) / a.rows_per_slice;
-    YOLO_LAUNCH((res_block2_kernel<C, D>), dim3((unsigned)bx, (unsigned)slices), dim3(256), 0, st, a);
+    YOLO_LAUNCH((res_block2_kernel<C, D, T>), dim3((unsigned)bx, (unsigned)slices), dim3(256), 0, st, a);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
 
-template <int C, int D>
+template <int C, int D, typename T = bf16_t>
 static int launch_res_block(ResArgs& a, hipStream_t st) {
     a.nstrips = (a.W + SW_MAX - 1) / SW_MAX;
     a.strip_w = (a.W + a.nstrips - 1) / a.nstrips;               // balanced strips (<= 62)
@@ -557,7 +554,7 @@ static int launch_res_block(ResArgs& a, hipStream_t st) {
     }
     a.rows_per_slice = (int)((a.H + best_s - 1) / best_s);
     const long long slices = (a.H + a.rows_per_slice - 1) / a.rows_per_slice;
-    YOLO_LAUNCH((res_block_kernel<C, D>), dim3((unsigned)bx, (unsigned)slices), dim3(256), 0, st, a);
+    YOLO_LAUNCH((res_block_kernel<C, D, T>), dim3((unsigned)bx, (unsigned)slices), dim3(256), 0, st, a);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }
@@ -571,7 +568,7 @@ extern "C" int yolo_res_block_fwd(const void* x, const void* w1_packed, const fl
     if (!x || !w1_packed || !scale1 || !bias1 || !w2_packed || !scale2 || !bias2 || !y || N <= 0 || H <= 0 || W <= 0)
         return YOLO_EINVAL;
     if (!(slope >= 0.f && slope <= 1.f)) return YOLO_EINVAL;
-    if (dtype != YOLO_BF16 || (C != 64 && C != 128)) return YOLO_EUNSUPPORTED;
+    if ((dtype != YOLO_BF16 && dtype != YOLO_F16) || (C != 64 && C != 128)) return YOLO_EUNSUPPORTED;
     ResArgs a;
     a.x = (const char*)x; a.wp1 = (const char*)w1_packed; a.scale1 = scale1; a.bias1 = bias1;
     a.wp2 = (const char*)w2_packed; a.scale2 = scale2; a.bias2 = bias2; a.y = (char*)y;
@@ -583,6 +580,8 @@ extern "C" int yolo_res_block_fwd(const void* x, const void* w1_packed, const fl
     // widths with that many register sets)
     static const int r2knob = (int)YOLO_LAB_ENV("YOLO_RB_R2", -1);
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == YOLO_F16)                                               // (the defaults; the knobs below are bf16 ablations)
+        return C == 128 ? launch_res_block2<128, 2, f16_t>(a, st) : launch_res_block<64, 3, f16_t>(a, st);
     if (r2knob == 2) return C == 64 ? launch_res_block2<64, 2>(a, st) : launch_res_block2<128, 2>(a, st);
     if (r2knob == 3) return C == 64 ? launch_res_block2<64, 3>(a, st) : launch_res_block2<128, 3>(a, st);
     if (r2knob < 0 && C == 128 && !dknob) return launch_res_block2<128, 2>(a, st);

@@ -17,7 +17,7 @@ constexpr int STEM_PW = STEM_TW + 4;   // LDS row pitch in pixels (halo + over-r
 // STATS (training): per-channel sum / sum of squares of the STORED bf16 outputs, one partial row [2][Cout] per wave
 // (row = block * 4 + wave), for yolo_bn_train_fwd_partials -- BatchNorm's batch statistics without a pass over the
 // 416 x 416 x 32 map (the largest reduction of the step).  Needs the 16-byte store path (Cout % 8 == 0, 64 % (Cout / 8) == 0).
-template <int MI, int STATS = 0>
+template <int MI, int STATS = 0, typename T = bf16_t>
 __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ bias, uint16_t* __restrict__ y,
@@ -65,15 +65,15 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
                     const int kw = 2 * h + q;          // h=0: kw 0,1 ; h=1: kw 2,(3 = padding)
                     v[q][ci] = (co < Cout && kw < 3) ? w[((co * 3 + ci) * 3 + kh) * 3 + min(kw, 2)] : 0.f;
                 }
-            wf[kh][mi] = make_uint4(pack_bf16x2(v[0][0], v[0][1]), pack_bf16x2(v[0][2], 0.f),
-                                    pack_bf16x2(v[1][0], v[1][1]), pack_bf16x2(v[1][2], 0.f));
+            wf[kh][mi] = make_uint4(Elem<T>::pack2(v[0][0], v[0][1]), Elem<T>::pack2(v[0][2], 0.f),
+                                    Elem<T>::pack2(v[1][0], v[1][1]), Elem<T>::pack2(v[1][2], 0.f));
         }
     }
 #pragma unroll
     for (int j = 0; j < NPASS; ++j) {
         const int sl = tid + j * 256;
         if (sl < NSLOT)
-            tile[sl] = okp[j] ? make_uint2(pack_bf16x2(c0[j], c1[j]), pack_bf16x2(c2[j], 0.f)) : make_uint2(0u, 0u);
+            tile[sl] = okp[j] ? make_uint2(Elem<T>::pack2(c0[j], c1[j]), Elem<T>::pack2(c2[j], 0.f)) : make_uint2(0u, 0u);
     }
     __syncthreads();
 
@@ -105,9 +105,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
                 const uint4 bf = make_uint4(lo.x, lo.y, hi.x, hi.y);
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[kh][mi]),
-                                                                          __builtin_bit_cast(bf16x8, bf), acc[mi][ni],
-                                                                          0, 0, 0);
+                    acc[mi][ni] = mfma16<T>(wf[kh][mi], bf, acc[mi][ni]);
             }
         }
         // BN + LeakyReLU, then transpose through this wave's LDS scratch so each lane stores 8 contiguous
@@ -128,7 +126,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
                         v[e] = leaky(t, slope);
                     }
                     *(uint2*)(ot + (ni * 32 + l31) * OP + co * 2) =
-                        make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                        make_uint2(Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2], v[3]));
                 }
             }
         }
@@ -146,7 +144,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
                     const uint32_t ow[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float t = bf16_bits_to_f32((e & 1) ? (ow[e >> 1] >> 16) : (ow[e >> 1] & 0xffffu));
+                        const float t = ((e & 1) ? Elem<T>::hi(ow[e >> 1]) : Elem<T>::lo(ow[e >> 1]));
                         ssum[e] += t; qsum[e] += t * t;
                     }
                 }
@@ -206,11 +204,18 @@ extern "C" int yolo_stem_conv_fwd(const float* x_nchw, const float* w_oihw, cons
     if (!x_nchw || !w_oihw || !scale || !bias || !y || N <= 0 || H <= 0 || W <= 0) return YOLO_EINVAL;
     if (!(slope >= 0.f && slope <= 1.f)) return YOLO_EINVAL;
     if (Cin != 3 || Cout <= 0 || (Cout % 4) || Cout > 64) return YOLO_EUNSUPPORTED;
-    if (dtype != YOLO_BF16) return YOLO_EUNSUPPORTED;      // the fp32 path goes through the generic kernel
+    if (dtype != YOLO_BF16 && dtype != YOLO_F16) return YOLO_EUNSUPPORTED;      // the fp32 path goes through the generic kernel
     const int tiles_x = (W + STEM_TW - 1) / STEM_TW, tiles_y = (H + STEM_TH - 1) / STEM_TH;
     const long long grid = (long long)N * tiles_x * tiles_y;
     if (grid > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
-    if (Cout <= 32)
+    if (dtype == YOLO_F16) {
+        if (Cout <= 32)
+            YOLO_LAUNCH((stem_mfma_kernel<1, 0, f16_t>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x_nchw, w_oihw, scale,
+                        bias, (uint16_t*)y, N, H, W, Cout, slope, tiles_x, tiles_y);
+        else
+            YOLO_LAUNCH((stem_mfma_kernel<2, 0, f16_t>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x_nchw, w_oihw, scale,
+                        bias, (uint16_t*)y, N, H, W, Cout, slope, tiles_x, tiles_y);
+    } else if (Cout <= 32)
         YOLO_LAUNCH((stem_mfma_kernel<1, 0>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x_nchw, w_oihw, scale,
                     bias, (uint16_t*)y, N, H, W, Cout, slope, tiles_x, tiles_y);
     else

@@ -45,6 +45,7 @@ struct Args {
 };
 }  // namespace
 
+template <typename T>
 __global__ __launch_bounds__(256) void stem_down_kernel(Args a) {
     __shared__ __attribute__((aligned(16))) char smem[RING * XROW + IROWS * IPW * 8 + 4 * SCR];
     char* xl = smem;
@@ -96,8 +97,8 @@ __global__ __launch_bounds__(256) void stem_down_kernel(Args a) {
                 const int kw = 2 * h + q;          // h=0: kw 0,1 ; h=1: kw 2,(3 = padding)
                 v[q][ci] = kw < 3 ? a.w1[((l31 * 3 + ci) * 3 + kh) * 3 + min(kw, 2)] : 0.f;
             }
-        wf[kh] = make_uint4(pack_bf16x2(v[0][0], v[0][1]), pack_bf16x2(v[0][2], 0.f), pack_bf16x2(v[1][0], v[1][1]),
-                            pack_bf16x2(v[1][2], 0.f));
+        wf[kh] = make_uint4(Elem<T>::pack2(v[0][0], v[0][1]), Elem<T>::pack2(v[0][2], 0.f), Elem<T>::pack2(v[1][0], v[1][1]),
+                            Elem<T>::pack2(v[1][2], 0.f));
     }
     // ---- epilogue constants of the down conv (after the transpose a lane owns 8 couts of a pixel row) -------------
     const int ecol = lane & 3, erow0 = lane >> 2;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void stem_down_kernel(Args a) {
         const int q = tid & 127;
         const int iy = iy_first + r * 2 + (tid >> 7);
         img[((iy - iyb) & (IROWS - 1)) * IPW + q] =
-            ok ? make_uint2(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], 0.f)) : make_uint2(0u, 0u);
+            ok ? make_uint2(Elem<T>::pack2(c[0], c[1]), Elem<T>::pack2(c[2], 0.f)) : make_uint2(0u, 0u);
     };
     // ---- one group of 32 stem pixels of stem row sy: 3 MFMAs, BN + LeakyReLU, one rounding, into ring slot `slot` --
     auto stem_group = [&](int sy, int slot, int pxg) {
@@ -143,9 +144,7 @@ __global__ __launch_bounds__(256) void stem_down_kernel(Args a) {
         for (int kh = 0; kh < 3; ++kh) {
             const int s = ((sy - 1 + kh - iyb) & (IROWS - 1)) * IPW + pxg * 32 + l31 + 2 * h;
             const uint2 lo = img[s], hi = img[s + 1];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[kh]),
-                                                          __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y)),
-                                                          acc, 0, 0, 0);
+            acc = mfma16<T>(wf[kh], make_uint4(lo.x, lo.y, hi.x, hi.y), acc);
         }
         const int px = pxg * 32 + l31;
         const int sx = sx0 + px;
@@ -157,7 +156,7 @@ __global__ __launch_bounds__(256) void stem_down_kernel(Args a) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = leaky(acc[4 * g + e] * sc1[4 * g + e] + bi1[4 * g + e], slope);
-            *(uint2*)(dst + co * 2) = inside ? make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])) : make_uint2(0u, 0u);
+            *(uint2*)(dst + co * 2) = inside ? make_uint2(Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2], v[3])) : make_uint2(0u, 0u);
         }
     };
 
@@ -211,8 +210,7 @@ __global__ __launch_bounds__(256) void stem_down_kernel(Args a) {
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc) {
                     const uint4 bf = *(const uint4*)(rowp + kw * PITCH + kc * 32);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[(kh * 3 + kw) * 2 + kc]),
-                                                                  __builtin_bit_cast(bf16x8, bf), acc, 0, 0, 0);
+                    acc = mfma16<T>(A[(kh * 3 + kw) * 2 + kc], bf, acc);
                 }
         }
         // ---- the two stem rows the next output row adds (2oy+2, 2oy+3): this wave's pixel group of each ----------
@@ -243,8 +241,8 @@ __global__ __launch_bounds__(256) void stem_down_kernel(Args a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = leaky(v[e] * sc2[e] + bi2[e], slope);
             if (yo[k] >= 0)
-                *(uint4*)(a.y + yo[k]) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
-                                                    pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+                *(uint4*)(a.y + yo[k]) = make_uint4(Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2], v[3]),
+                                                    Elem<T>::pack2(v[4], v[5]), Elem<T>::pack2(v[6], v[7]));
         }
         if (more) store_img(2 * oy + 5, 0, c, ok);
         slot0 += 2;
@@ -265,7 +263,7 @@ extern "C" int yolo_stem_down_fwd(const float* x_nchw, const float* w1_oihw, con
     if (!x_nchw || !w1_oihw || !scale1 || !bias1 || !w2_packed || !scale2 || !bias2 || !y || N <= 0 || H <= 0 || W <= 0)
         return YOLO_EINVAL;
     if (!(slope >= 0.f && slope <= 1.f)) return YOLO_EINVAL;
-    if (C1_ != C1 || C2_ != C2 || dtype != YOLO_BF16) return YOLO_EUNSUPPORTED;
+    if (C1_ != C1 || C2_ != C2 || (dtype != YOLO_BF16 && dtype != YOLO_F16)) return YOLO_EUNSUPPORTED;
     Args a;
     a.x = x_nchw; a.w1 = w1_oihw; a.scale1 = scale1; a.bias1 = bias1;
     a.wp2 = (const char*)w2_packed; a.scale2 = scale2; a.bias2 = bias2; a.y = (char*)y;
@@ -281,7 +279,10 @@ extern "C" int yolo_stem_down_fwd(const float* x_nchw, const float* w1_oihw, con
     if (slices < 1) slices = 1;
     a.rows_per_slice = (int)((a.Ho + slices - 1) / slices);
     slices = (a.Ho + a.rows_per_slice - 1) / a.rows_per_slice;
-    YOLO_LAUNCH(stem_down_kernel, dim3((unsigned)bx, (unsigned)slices), dim3(256), 0, (hipStream_t)stream, a);
+    if (dtype == YOLO_F16)
+        YOLO_LAUNCH(stem_down_kernel<f16_t>, dim3((unsigned)bx, (unsigned)slices), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        YOLO_LAUNCH(stem_down_kernel<bf16_t>, dim3((unsigned)bx, (unsigned)slices), dim3(256), 0, (hipStream_t)stream, a);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
 }

@@ -15,8 +15,8 @@ import torch
 from . import lib as L
 from .spec import NetGraph, BN_EPS, LEAKY_SLOPE, xavier_bound
 
-_TORCH_DT = {'bf16': torch.bfloat16, 'f32': torch.float32}
-_LIB_DT = {'bf16': L.BF16, 'f32': L.F32}
+_TORCH_DT = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}
+_LIB_DT = {'bf16': L.BF16, 'f16': L.F16, 'f32': L.F32}
 
 
 class _Plan(object):
@@ -40,8 +40,11 @@ class CarNet(object):
         # num_sync_bn_devices is accepted for signature parity; the reference always passes -1
         # (no SyncBN, car/YOLO.py:94-96).
         if dtype not in _TORCH_DT:
-            raise ValueError('dtype must be bf16 or f32')
+            raise ValueError('dtype must be bf16, f16 or f32')
         self.graph = NetGraph(spec)
+        # 'f16' = the reference's own reduced precision (use_fp16 -> net.cast('float16'), car/YOLO.py:98-100; the executor's fp16
+        # flag, yolo_gluon.py:204-214): fp16 activations and weights on v_mfma_f32_32x32x16_f16 -- the bf16 MFMA rate with three more
+        # mantissa bits.  Inference only (Trainer refuses it).
         self.dtype = dtype
         self.device = L.resolve_device(device)
         # tune: 'auto' = the library's heuristic picks the conv tile variant; 'measure' = time every
@@ -225,7 +228,7 @@ class CarNet(object):
     TAIL_ALGOS = {1: (7, 6, 2), 2: (17, 9, 18, 16, 10)}      # 8-wave 3x3 variants whose tile can hold a pixel's every channel, by stride
 
     def _tail_eligible(self, c3, c1):
-        return (self.fuse_tail and self.dtype == 'bf16' and c3.k == 3 and c3.bn and c3.cout <= 256 and c3.cout % 32 == 0
+        return (self.fuse_tail and self.dtype in ('bf16', 'f16') and c3.k == 3 and c3.bn and c3.cout <= 256 and c3.cout % 32 == 0
                 and c1.k == 1 and c1.stride == 1 and c1.cin == c3.cout and c1.cout <= 128 and (c1.bn or c1.cout % 2 == 0))
 
     def _set_tail(self, d, c1, out1, out1_f32=False, t_bs=0, t_ps=0):
@@ -299,7 +302,7 @@ class CarNet(object):
 
     def _res_block_eligible(self, c1, c2):
         C_ = c1.cin
-        return (self.fuse_res and self.dtype == 'bf16' and C_ in (64, 128) and c1.bn and c2.bn
+        return (self.fuse_res and self.dtype in ('bf16', 'f16') and C_ in (64, 128) and c1.bn and c2.bn
                 and (c1.k, c1.stride, c1.cin, c1.cout) == (1, 1, C_, C_ // 2) and (c2.k, c2.stride, c2.cin, c2.cout) == (3, 1, C_ // 2, C_))
 
     def _use_res_block(self, c1, c2, x, shp):
@@ -486,7 +489,7 @@ class CarNet(object):
         tdt = _TORCH_DT[self.dtype]
         fused_down = None
         d0 = g.stages[0][0] if g.stages else None
-        if (self.fuse_stem and self.dtype == 'bf16' and d0 is not None and g.stem.cin == 3 and g.stem.k == 3
+        if (self.fuse_stem and self.dtype in ('bf16', 'f16') and d0 is not None and g.stem.cin == 3 and g.stem.k == 3
                 and g.stem.stride == 1 and g.stem.bn and (g.stem.cout, d0.cin, d0.cout, d0.k, d0.stride, d0.bn) == (32, 32, 64, 3, 2, True)):
             # stem + first down-sampling conv in one kernel (yolo_stem_down_fwd): the 32-channel full-resolution map
             # between them never reaches HBM
@@ -500,7 +503,7 @@ class CarNet(object):
                                            L.ptr(s2), L.ptr(b2), L.ptr(x), B, H, W, g.stem.cout, d0.cout), d0.name))
             plan.act[d0.name] = (x, shp)
             fused_down = d0
-        elif g.stem.cin == 3 and g.stem.cout % 4 == 0 and g.stem.cout <= 64 and self.dtype == 'bf16':
+        elif g.stem.cin == 3 and g.stem.cout % 4 == 0 and g.stem.cout <= 64 and self.dtype in ('bf16', 'f16'):
             # fused image-layout change + first conv (yolo_stem_conv_fwd): reads the NCHW image directly
             _, sscale, sbias = self._prepared[g.stem.name]
             x = torch.empty((B, H, W, g.stem.cout), dtype=tdt, device=self.device)

@@ -38,6 +38,8 @@ class Trainer(object):
         # transposing-read weight gradient); master weights, weight gradients, BN statistics and Adam are fp32.
         self.net, self.size = net, (int(size[0]), int(size[1]))
         self.tdt = torch.float32 if net.dtype == 'f32' else torch.bfloat16
+        if net.dtype not in ('f32', 'bf16'):
+            raise L.YoloError("Trainer: dtype %r is inference only (the training kernels take 'f32' | 'bf16')" % (net.dtype,))
         self.ldt = L.F32 if net.dtype == 'f32' else L.BF16
         self.lib, self.dev = net._lib, net.device
         self.scale = dict(DEFAULT_SCALE if scale is None else scale)
