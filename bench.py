@@ -215,7 +215,7 @@ def train_pass(args, spec, size, B, rank, world, dev, dist, steps, warmup, prehe
     from yolo_amd import parallel
     net = CarNet(spec, dtype=args.dtype, device=dev, tune='measure', tune_cache=args.tune_cache,
                  fuse_stem=not args.no_fuse_stem).initialize(seed=1234)
-    tr = Trainer(net, size)
+    tr = Trainer(net, size, grad_exchange=args.grad_exchange, grad_buckets=args.grad_buckets)
     if getattr(args, 'plan_state', None) is not None:
         tr.load_tuning_state(args.plan_state)
     gen = torch.Generator(device='cpu').manual_seed(100 + rank)
@@ -278,8 +278,10 @@ def train_pass(args, spec, size, B, rank, world, dev, dist, steps, warmup, prehe
         for i in range(reps + 1):
             if i == 1:
                 e0.record()
-            for a, b in tr.buckets.ranges:
-                dist.all_reduce(tr.gflat[a:b], op=dist.ReduceOp.SUM)
+            tr.buckets.reset()
+            for k in range(len(tr.buckets.ranges)):             # (the buckets' own launch path: fp32 slices or bf16 staging)
+                tr.buckets._launch(k)
+            tr.buckets.wait()
         e1.record(); e1.synchronize()
         ar_ms = e0.elapsed_time(e1) / reps
         # ... and what it costs inside the step: the same K steps with the exchange switched off (local gradients only).
@@ -297,8 +299,9 @@ def train_pass(args, spec, size, B, rank, world, dev, dist, steps, warmup, prehe
         t = torch.tensor([el_off], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el_off = float(t.item())
-        nbytes = tr.gflat.numel() * 4
+        nbytes = tr.gflat.numel() * (4 if args.grad_exchange == 'f32' else 2)
         exch = {'rccl_world': dist.get_world_size(), 'backend': dist.get_backend(), 'buckets': len(tr.buckets.ranges), 'bytes': nbytes,
+                'dtype': args.grad_exchange,
                 'allreduce_ms_per_step_standalone': round(ar_ms, 3),
                 'allreduce_busbw_GBps': round(2.0 * (world - 1) / max(world, 1) * nbytes / (ar_ms * 1e-3) / 1e9, 1),
                 'ms_per_step_without_exchange': round(el_off / k_off * 1e3, 4),
@@ -487,6 +490,10 @@ def main():
                          'pre-heat of the same pass and >= 20 warm-up steps.  0 = short legacy passes of --steps / 2 (tests)')
     ap.add_argument('--train-timeout', type=float, default=600.0,
                     help='watchdog (s) around the training pass under N > 1: when it fires the line is printed without the pass')
+    ap.add_argument('--grad-exchange', default='f32', choices=['f32', 'bf16'],
+                    help="N > 1 training: the dtype the gradient buckets travel in ('f32' = the reference's KVStore sum; 'bf16' = half the "
+                         "bytes per xGMI link, yolo_amd/parallel.py:GradBuckets)")
+    ap.add_argument('--grad-buckets', type=int, default=4, help='N > 1 training: number of buckets the 492 MB gradient buffer is cut into')
     ap.add_argument('--launch-check', action='store_true',
                     help='start the N ranks, rendezvous, barrier, MAX-reduce, print the world that ran, and exit (no benchmark)')
     args = ap.parse_args()

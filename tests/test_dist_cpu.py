@@ -114,6 +114,51 @@ def test_bucketed_gradient_allreduce_two_ranks():
     assert out[0][2] == out[1][2] == expect + [7.0, 0.0, 0.0, 0.0]
 
 
+def _bf16_bucket_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sizes = [1000, 4096, 37, 2500]
+    names = ['p%d' % i for i in range(len(sizes))]
+    offs, o = [], 0
+    for s in sizes:
+        offs.append(o); o += (s + 3) // 4 * 4
+    g = torch.Generator().manual_seed(17 + rank)
+    grad = torch.zeros(o + 4)
+    grad[:o] = torch.randn(o, generator=g) * torch.logspace(-6, 2, o)        # gradients over eight decades
+    grad[o] = 33.0 + 200 * rank                                               # shard sizes 33 + 233 = 266: not a bf16 number
+    out = {}
+    for dt in ('f32', 'bf16'):
+        flat = grad.clone()
+        b = P.GradBuckets(flat, names, offs, sizes, nbuckets=3, dtype=dt, exact_tail=4)
+        b.reset()
+        for group in (['p3'], ['p1', 'p2'], ['p0']):
+            b.done(group)
+        b.wait()
+        out[dt] = flat
+    q.put((rank, grad.tolist(), out['f32'].tolist(), out['bf16'].tolist()))
+    dist.destroy_process_group()
+
+
+def test_bf16_gradient_buckets_bounded_against_the_fp32_exchange():
+    """GradBuckets(dtype='bf16'): cast -> SUM all-reduce in bf16 -> back into the fp32 gradients.  Every element within
+    2^-8 * sum_r |g_r| (+ one rounding of the sum) of the fp32 exchange, identical on both ranks, and the shard-size slot exact."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_bf16_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(timeout=60) for p in ps]
+    g0, g1 = np.array(out[0][1]), np.array(out[1][1])
+    f32, b16 = np.array(out[0][2]), np.array(out[0][3])
+    assert out[0][3] == out[1][3] and out[0][2] == out[1][2]                     # both ranks hold the same sums
+    np.testing.assert_allclose(f32, (g0 + g1).astype(np.float32), rtol=1e-6)
+    bound = 2.0 ** -8 * (np.abs(g0) + np.abs(g1)) + 2.0 ** -8 * np.abs(f32) + 1e-30
+    assert (np.abs(b16 - f32) <= bound).all(), float((np.abs(b16 - f32) / bound).max())
+    assert np.abs(b16[:-4] - f32[:-4]).max() > 0                                 # (it did travel in bf16)
+    assert b16[-4] == f32[-4] == 266.0                                           # the exact tail: fp32
+
+
 def test_bucket_ranges_cover_the_buffer():
     offs, sizes = [0, 8, 24, 28, 100], [6, 16, 3, 70, 9]
     for nb in (1, 2, 3, 10):

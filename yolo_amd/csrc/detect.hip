@@ -266,7 +266,7 @@ constexpr int kDecBoxes = 128;
 
 // HIST (round 4, yolo_decode_nms): the first radix histogram of the NMS selection (nms_hist_kernel pass 0: valid scores by their
 // top 11 bits, per image) is taken HERE, from the scores the block holds in LDS, instead of in a pass of its own over the
-// score array.  A thread counts runs of equal bins over its box's scores, adds them to a 1024-bin block histogram (2 KiB: one
+// score array.  A thread counts runs of equal bins over its box's scores, adds them to a kDecHistBins-bin (512) block histogram (2 KiB: one
 // more KiB and a CU holds four of these blocks instead of five) and the block flushes the non-empty bins -- two or three -- to the
 // image's global histogram once per tile; a tile that straddles two images is flushed once per image.  512 bins: the scores
 // made here are sigmoid x softmax <= 1.0 = bin 508 (a larger value -- impossible -- would go straight to the global histogram).

@@ -77,6 +77,10 @@ class CarNet(object):
         #  tuner can check it, i.e. with tune='measure')
         self._force_tail = fuse_tail == 'force'
         self.fuse_tail = bool(fuse_tail) and (tune == 'measure' or fuse_tail == 'force')      # ('force': tests -- every eligible pair)
+        if fuse_tail is True and tune != 'measure' and fuse_tail != 'force':
+            self.fuse_tail_note = "fuse_tail=True has no effect under tune='auto' (pairs are only fused where the tuner measured a gain)"
+        else:
+            self.fuse_tail_note = None
         self._algo_cache = {}
         # optional JSON file remembering measured choices (so a profiled run launches only the chosen kernels)
         self._tune_cache = tune_cache
@@ -240,7 +244,10 @@ class CarNet(object):
         d.tail_y_batch_stride, d.tail_y_pixel_stride = t_bs, t_ps
 
     def _tail_key(self, d):
-        return ('tail', d.N, d.H, d.W, d.Cin, d.Cout, d.stride, bool(d.residual), d.tail_cout, d.tail_out_f32, int(d.y_pixel_stride))
+        # (everything the fused-or-not decision was measured under: the element type, the input view and both outputs' strides --
+        #  a decision taken for one layout must not be reused for another through the tune cache / share_tuning)
+        return ('tail', d.N, d.H, d.W, d.Cin, d.Cout, d.stride, bool(d.residual), d.tail_cout, d.tail_out_f32, int(d.y_pixel_stride),
+                int(d.dtype), int(d.x_pixel_stride), int(d.tail_y_pixel_stride), int(d.tail_y_batch_stride))
 
     def _tail_algo(self, d):
         """The 256-cout tile variant of a fused launch: the first the library takes, or (tune='measure') the fastest."""
@@ -250,8 +257,9 @@ class CarNet(object):
         return self._measure_algo(d, algos=cands, key_extra=('tail', d.tail_cout, d.tail_out_f32))
 
     def _use_tail(self, c3, c1, x, xshape, residual, out, out1, out1_f32=False, t_bs=0, t_ps=0, y_bs=0, y_ps=0):
-        """Whether (3x3 c3, then 1x1 c1 on its output) runs as ONE fused launch.  tune='auto': whenever the library takes it;
-        tune='measure': when the fused launch is faster than the two separate ones with their own best variants."""
+        """Whether (3x3 c3, then 1x1 c1 on its output) runs as ONE fused launch.  fuse_tail='force' (tests): whenever the library
+        takes the pair.  fuse_tail=True acts only under tune='measure' -- the pair is fused when the fused launch is faster than the
+        two separate ones with their own best variants (the constructor switches it off under tune='auto' and says so)."""
         if not self._tail_eligible(c3, c1):
             return False
         lib, st = self._lib, L.stream_ptr()

@@ -125,9 +125,20 @@ class GradBuckets(object):
     boundaries; `done(names)` is called as the backward finishes parameters and launches the asynchronous SUM
     all-reduce of every bucket whose parameters are all final, on the process group's own stream, while the
     remaining backward kernels keep running; `wait()` joins them before the optimiser.  xGMI is point-to-point,
-    so a few large buckets (default 4 over 492 MB) keep every ring step bandwidth-bound."""
+    so a few large buckets (default 4 over 492 MB) keep every ring step bandwidth-bound.
 
-    def __init__(self, flat, names, offsets, sizes, nbuckets=4):
+    dtype='bf16' (last row): a bucket is cast to bf16 into a staging buffer, the staging buffer is
+    SUM-reduced, and the sum is cast back into the fp32 gradients when the exchange is joined -- half the bytes per xGMI
+    link (246 MB instead of 492), at the price of one bf16 rounding per rank's contribution and one per partial sum inside
+    the collective: |error| <= ~2^-8 * sum_r |g_r| per element (bounded by tests/test_dist_cpu.py against the fp32
+    exchange).  `exact_tail` elements at the end of the flat buffer (the shard-size slot of yolo_amd/train.py: an integer
+    that trainer.step divides by) always travel in fp32.  The reference's KVStore reduce is fp32 (car/YOLO.py:160,396):
+    'f32' stays the default."""
+
+    def __init__(self, flat, names, offsets, sizes, nbuckets=4, dtype='f32', exact_tail=0):
+        if dtype not in ('f32', 'bf16'):
+            raise ValueError("GradBuckets dtype must be 'f32' or 'bf16'")
+        self.dtype, self.exact_tail = dtype, int(exact_tail)
         self.flat = flat
         self.ranges = bucket_ranges(offsets, sizes, nbuckets, flat.numel())
         self.owner = {}
@@ -136,7 +147,24 @@ class GradBuckets(object):
         self.count0 = [0] * len(self.ranges)
         for n in names:
             self.count0[self.owner[n]] += 1
+        # bf16 exchange: what bucket k sends -- [a, b) minus the exact tail -- and its staging buffer (allocated on first use)
+        self.stage = [None] * len(self.ranges)
         self.reset()
+
+    def _launch(self, k):
+        a, b = self.ranges[k]
+        self.launched[k] = True
+        if self.dtype == 'f32':
+            self.works.append((dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True), None))
+            return
+        cut = min(b, self.flat.numel() - self.exact_tail)
+        if cut > a:
+            if self.stage[k] is None:
+                self.stage[k] = torch.empty(cut - a, dtype=torch.bfloat16, device=self.flat.device)
+            self.stage[k].copy_(self.flat[a:cut])               # (fp32 -> bf16, round-to-nearest-even, on the current stream)
+            self.works.append((dist.all_reduce(self.stage[k], op=dist.ReduceOp.SUM, async_op=True), (k, a, cut)))
+        if cut < b:
+            self.works.append((dist.all_reduce(self.flat[max(cut, a):b], op=dist.ReduceOp.SUM, async_op=True), None))
 
     def active(self):
         # (YOLO_BENCH_FORCE_DIST exercises the exchange on a single rank)
@@ -161,17 +189,17 @@ class GradBuckets(object):
                 if before_launch is not None:
                     before_launch()
                     before_launch = None
-                a, b = self.ranges[k]
-                self.launched[k] = True
-                self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
+                self._launch(k)
 
     def wait(self):
         if not self.active():
             return
         for k, (a, b) in enumerate(self.ranges):          # anything the backward never reported (defensive)
             if not self.launched[k]:
-                self.launched[k] = True
-                self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
-        for w in self.works:
+                self._launch(k)
+        for w, back in self.works:
             w.wait()
+            if back is not None:                                # the bf16 sum back into the fp32 gradients
+                k, a, cut = back
+                self.flat[a:cut].copy_(self.stage[k])
         self.works = []

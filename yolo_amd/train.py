@@ -33,7 +33,9 @@ class _T(object):
 class Trainer(object):
     def __init__(self, net, size, scale=None, learning_rate=1e-3, positive_weight=1.0, negative_weight=0.1,
                  car_rotate=False, beta1=0.9, beta2=0.999, eps=1e-8, lp_scale=None, lp_r_max=(45, 60, 45),
-                 lp_positive_weight=1.0, lp_negative_weight=0.1):
+                 lp_positive_weight=1.0, lp_negative_weight=0.1, grad_exchange='f32', grad_buckets=4):
+        # grad_exchange / grad_buckets (N > 1): the dtype the gradient buckets travel in ('f32' = the reference's KVStore sum;
+        # 'bf16' halves the bytes per xGMI link, parallel.GradBuckets) and how many buckets the 492 MB buffer is cut into
         # dtype of activations and activation gradients: 'f32' (parity path) or 'bf16' (MFMA bf16 convolutions,
         # transposing-read weight gradient); master weights, weight gradients, BN statistics and Adam are fp32.
         self.net, self.size = net, (int(size[0]), int(size[1]))
@@ -79,7 +81,7 @@ class Trainer(object):
             self.pview[n] = net.params[n]
             self.gview[n] = self.gflat[of:of + s].view(shp)
         self._gb_slot = self.gflat[o:o + 1]
-        self.buckets = parallel.GradBuckets(self.gflat, names, offs, sizes, nbuckets=4)
+        self.buckets = parallel.GradBuckets(self.gflat, names, offs, sizes, nbuckets=grad_buckets, dtype=grad_exchange, exact_tail=4)
         net._trainer = self                     # CarNet.forward(x, training=True) / CarNet.backward(grads) run through it
         # the parameters moved into the flat buffer: the net's launch plans hold pointers to the old tensors (stem
         # weights), and its folded / packed images are re-made on the next inference forward (net._version)
