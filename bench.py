@@ -338,7 +338,7 @@ def plan_report(args, state):
     info = dict(getattr(args, 'plan_info', None) or {'file': None, 'mode': 'measure'})
     base = getattr(args, 'plan_state', None)
     info['measured_live'] = plans.new_keys(state, base) if base is not None else sum(len(state.get(s_, {})) for s_ in plans.SECTIONS)
-    info['md5_in_force'] = plans.md5(state)
+    info['state_md5'] = plans.md5(state)          # (of the sections this pass uses: an inference pass holds no dgrad / wgrad choices)
     return info
 
 
