@@ -147,7 +147,11 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
 #pragma unroll
     for (int q = 0; q < CPL / 4; ++q) {
         f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+#ifdef YOLO_LAB
+        if (!ident && !(a.lab & 8)) {
+#else
         if (!ident) {
+#endif
             s4 = *(const f32x4*)(a.scale + co + 4 * q);     // arrays are padded to the cout tile
             b4 = *(const f32x4*)(a.bias + co + 4 * q);
         }
@@ -213,6 +217,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             if (ni + 1 < NI) prefetch_b(ni + 1);
+#ifdef YOLO_LAB
+            if (!(a.lab & 16))
+#endif
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -226,7 +233,12 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                 float v[CPL];
 #pragma unroll
                 for (int q = 0; q < CPL / 4; ++q) {
+#ifdef YOLO_LAB
+                    f32x4 t4 = {acc[0][ni][4 * q], acc[0][ni][4 * q + 1], acc[0][ni][4 * q + 2], acc[0][ni][4 * q + 3]};      // (ablation 16: no transpose, wrong values)
+                    if (!(a.lab & 16)) t4 = *(const f32x4*)(wsm + (row0 + k * RPP) * RS + (col * CPL + 4 * q) * 4);
+#else
                     const f32x4 t4 = *(const f32x4*)(wsm + (row0 + k * RPP) * RS + (col * CPL + 4 * q) * 4);
+#endif
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[4 * q + e] = t4[e];
                 }

@@ -62,6 +62,19 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// The kernel's argument block read afresh from the kernarg segment (ConvArgs is the kernel's only argument: offset 0).  The
+// optimiser cannot tell two such reads apart from two different structs, so the fields a region uses are s_load'ed where the
+// region starts instead of at the top of the kernel -- and do not stay in SGPRs across the regions that do not use them.  The
+// persistent tile loop keeps every tile-set-up scalar (seven division constants, the dimensions, the strides, six pointers)
+// live across the epilogue otherwise: the ISA of the round-4 epilogue spent 70 of its 330 vector-pipe instructions per
+// 32-pixel slab on v_readlane / v_writelane SGPR spill traffic (buffer descriptors rebuilt from spilled halves before every
+// load and store, each followed by the s_nop its hazard needs).
+__device__ __forceinline__ const ConvArgs& kargs_fresh() {
+    const __attribute__((address_space(4))) ConvArgs* p = (const __attribute__((address_space(4))) ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const ConvArgs*)p;
+}
+
 template <typename T> struct FragP;
 template <> struct FragP<bf16_t> {
     static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16& c) {
@@ -98,7 +111,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // the first half) issues them at shifted positions, so a wave stuck in a DMA issue is covered by its
 // SIMD partner's MFMAs.
 template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int S = 1, int RD = 0, int KC = 1, int LEAN = 0, int STATS = 0>
-__global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvArgs a) {
+__global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvArgs a0) {
     constexpr int PT = 1;
     constexpr int NW = WAVES_P * WAVES_C;
     constexpr int NT = NW * 64;
@@ -158,7 +171,9 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     STAMP(0); STAMP_ID();
     // a.vblocks tiles over gridDim.x blocks: a resident grid walks them (launch_pipe: one round of blocks, persistent), or one
     // block per tile when the launch has no more tiles than that
-    for (int vb = blockIdx.x; vb < a.vblocks; vb += gridDim.x) {
+    for (int vb = blockIdx.x; vb < a0.vblocks; vb += gridDim.x) {
+    const ConvArgs& a = kargs_fresh();                 // (tile set-up and K loop: their own reads of the argument block)
+    const char* const ax = a.x;                        // (read HERE: a conditional read inside the K loop is not hoisted out of it)
     // The per-thread constants are derived from a LAUNDERED thread id inside the tile loop: as loop invariants the compiler
     // hoists them -- and every address built from them -- out of the loop and keeps them in registers across the K loop
     // (+40-50 VGPRs: the 4-wave 192 x 128 tile lost its second wave per SIMD, the 8-wave 256 x 256 tile spilled: -10 % on the
@@ -221,7 +236,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     auto issue_x = [&](int j, int c, int buf) {
         const int kc = j / XL1, jj = j - kc * XL1;
         const int cc = (KS != 1) ? min(c, nchunks - 1) : min(c, nphase - 1) * KC + kc;      // (1x1: c counts phases)
-        const char* src = (xo[jj] != 0xffffffffu) ? a.x + ((size_t)xo[jj] + (size_t)cc * 64) : zero_page;
+        const char* src = (xo[jj] != 0xffffffffu) ? ax + ((size_t)xo[jj] + (size_t)cc * 64) : zero_page;
         glds16(src, wave_lds + buf * X_STAGE + kc * X_STAGE1 + jj * NT * 16);
     };
     static_assert(KS == 1 || XL <= PPC, "3x3: at most one input DMA per phase");
@@ -390,7 +405,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
             for (int j = 0; j < XL; ++j) {
                 const int kc = j / XL1, jj = j - kc * XL1;
                 const bool ok = xo[jj] != 0xffffffffu;
-                xq[j] = ok ? a.x + ((size_t)xo[jj] + (size_t)(g0 + kc) * 64) : (const char*)yolo_zero_page;
+                xq[j] = ok ? ax + ((size_t)xo[jj] + (size_t)(g0 + kc) * 64) : (const char*)yolo_zero_page;
                 if (kc == 0) xinc[jj] = ok ? 64u * KC : 0u;
             }
         }
@@ -535,6 +550,9 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
 
     // ---- epilogue (conv_epilogue.h): every wave transposes its slab through its own LDS scratch ------
     __builtin_amdgcn_s_barrier();        // all waves are done reading the pipeline's LDS
+    {
+    const ConvArgs& a = kargs_fresh();                 // (the epilogue's own reads: nothing of the set-up stays live for it)
+    const int Ho = a.Ho, Wo = a.Wo, TWt = a.TWt;
     long long yoff[NI];                  // output element offset of each lane's pixels (-1: none)
     long long roff[NI];                  // residual element offset (dense tensor; differs when y is strided)
 #pragma unroll
@@ -598,6 +616,8 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
             const long long off = ((long long)n * a.y_bs + (long long)pix * a.y_ps) * 2;
             xs2[j] = valid ? (unsigned)(off + ((part ^ ((slot >> 2) & 3)) * 16)) : 0xffffffffu;
         }
+        const char* const ay = a.y;
+        const char* const atwp = a.t_wp;
         const int nph2 = a.Cout >> 5;                                       // K chunks of 32 channels (the host checks Cout % 32 == 0)
         const long long wplane2 = (long long)round_up(a.t_cout, YOLO_COUT_PAD) * 64;
         const char* zp2 = (const char*)yolo_zero_page;
@@ -606,10 +626,10 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
             const uint32_t base = wave_lds + (c % R2) * S2;
 #pragma unroll
             for (int j = 0; j < XL2; ++j)
-                glds16(xs2[j] != 0xffffffffu ? a.y + ((size_t)xs2[j] + (size_t)cc * 64) : zp2, base + j * NT * 16);
+                glds16(xs2[j] != 0xffffffffu ? ay + ((size_t)xs2[j] + (size_t)cc * 64) : zp2, base + j * NT * 16);
 #pragma unroll
             for (int j = 0; j < WL2; ++j)
-                glds16(a.t_wp + (long long)cc * wplane2 + (long long)(tid + j * NT) * 16, base + X2_STAGE + j * NT * 16);
+                glds16(atwp + (long long)cc * wplane2 + (long long)(tid + j * NT) * 16, base + X2_STAGE + j * NT * 16);
         };
         f32x16 acc2[1][NI];
 #pragma unroll
@@ -665,7 +685,8 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(5);
 #endif
-    if (vb + (int)gridDim.x < a.vblocks) __syncthreads();     // the next tile's DMAs overwrite the epilogue's scratch
+    }
+    if (vb + (int)gridDim.x < a0.vblocks) __syncthreads();     // the next tile's DMAs overwrite the epilogue's scratch
     }
 }
 
