@@ -33,10 +33,10 @@ torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); lib.yolo_conv_fwd(C.byref(d), st); e1.record(); torch.cuda.synchronize()
 print('kernel %.1f us' % (e0.elapsed_time(e1) * 1e3))
-nb = 8192
-buf = np.zeros(nb * 8, np.int64)
-assert lib.yolo_debug_read_stamps(buf.ctypes.data, nb * 8) == 0
-s = buf.reshape(nb, 8)
+nb, NS = 8192, 16
+buf = np.zeros(nb * NS, np.int64)
+assert lib.yolo_debug_read_stamps(buf.ctypes.data, nb * NS) == 0
+s = buf.reshape(nb, NS)
 s = s[s[:, 0] != 0]
 print('blocks stamped', len(s))
 ph = np.stack([s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], s[:, 4] - s[:, 3], s[:, 5] - s[:, 4], s[:, 5] - s[:, 0]], 1)
@@ -44,12 +44,23 @@ names = ['prologue', 'K loop', 'drain+barrier', 'epilogue issue', 'store drain',
 for i, n in enumerate(names):
     v = ph[:, i]
     print('%-15s mean %8.0f  p10 %8.0f  p50 %8.0f  p90 %8.0f cycles' % (n, v.mean(), np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90)))
+# the epilogue as wave 0 walks it (slots 8-15, conv_epilogue.h): entry -> offsets + residual requests of slab 0 -> per slab:
+# transpose written to LDS | its passes (LDS reads, arithmetic, stores issued)
+if s[:, 8].any():
+    e = s[:, 8:16]
+    names2 = ['enter->prefetch0', 'slab0 LDS write', 'slab0 passes', 'slab1 prefetch+write', 'slab1 passes', 'slab2 prefetch+write', 'slab2 passes']
+    for i, n in enumerate(names2):
+        v = e[:, i + 1] - e[:, i]
+        v = v[(e[:, i + 1] != 0) & (e[:, i] != 0)]
+        if len(v):
+            print('  epi %-22s mean %7.0f  p10 %7.0f  p50 %7.0f  p90 %7.0f cycles' % (n, v.mean(), np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90)))
+    print('  epi setup (stamp 3 -> enter): mean %.0f' % (s[:, 8] - s[:, 3]).mean())
 wall = s[:, 6]
 print('wall span of block starts: %.1f us (100 MHz ticks); first-round blocks (start within 2 us of the first): %d'
       % ((wall.max() - wall.min()) / 100.0, int((wall - wall.min() < 200).sum())))
 # per-CU timelines: CU = (XCC_ID, SE_ID, SH_ID, CU_ID)
 hw = s[:, 7]
-bidx = np.nonzero(buf.reshape(nb, 8)[:, 0] != 0)[0]
+bidx = np.nonzero(buf.reshape(nb, NS)[:, 0] != 0)[0]
 key = ((hw >> 32) & 0xf) * 256 + ((hw >> 8) & 0xff)
 print('distinct CUs seen: %d' % len(set(key.tolist())))
 for k0 in sorted(set(key.tolist()))[:2]:

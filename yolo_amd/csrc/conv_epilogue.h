@@ -12,6 +12,7 @@
 // Rounding order is unchanged: fp32 (acc*scale+bias) -> LeakyReLU -> + residual (fp32) -> round.
 #pragma once
 #include "conv_args.h"
+#include "stamp.h"
 
 // bytes of LDS scratch one wave needs (max over MI in {1,2}): 32 rows x (64*4+16) + 2 x 32 x 8 (output offsets) + 2 x 32 x 8
 // (residual offsets, when the residual's strides differ from the output's)
@@ -213,7 +214,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
             }
         };
         const int up_a = (int)(a.y_ps * ES), up_b = (int)(2LL * a.Wo * a.y_ps * ES);      // (up2: the other pixels of the 2x2 patch)
+        STAMP(8);
         prefetch_b(0);
+        STAMP(9);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             if (ni + 1 < NI) prefetch_b(ni + 1);
@@ -228,6 +231,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                     *(f32x4*)(wsm + l31 * RS + (mi * 32 + 8 * g + 4 * h) * 4) = v;
                 }
             wave_lds_fence();
+            if (ni < 3) STAMP(10 + 2 * ni);
 #pragma unroll
             for (int k = 0; k < NPASS; ++k) {
                 float v[CPL];
@@ -299,6 +303,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                     __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_b + up_a : -1, 0, 0);
                 }
             }
+            if (ni < 3) STAMP(11 + 2 * ni);
         }
     } else {
     // The residual loads of slab ni+1 are issued BEFORE slab ni is processed (two register sets), so their latency

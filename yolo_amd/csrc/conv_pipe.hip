@@ -15,8 +15,12 @@
 //     the main loop.
 //   * XCD-aware block order: the blocks that share an input tile (different cout tiles) are
 //     consecutive on one XCD so its L2 serves the re-reads.
+#ifndef YOLO_PIPE_PART
+#define YOLO_PIPE_PART 0
+#endif
 #include "common.h"
 #include "conv_args.h"
+#include "stamp.h"
 #include "conv_epilogue.h"
 #include <stdio.h>
 #include <type_traits>
@@ -24,23 +28,7 @@
 
 // The file is compiled TWICE (csrc/Makefile): YOLO_PIPE_PART 0 = the 3x3 kernels and conv_pipe_dispatch, 1 = the 2x2-window
 // and 1x1 kernels behind conv_pipe_dispatch_b -- two translation units of ~65 instantiations each build in parallel.
-#ifndef YOLO_PIPE_PART
-#define YOLO_PIPE_PART 0
-#endif
 namespace { __device__ __attribute__((aligned(64))) unsigned int yolo_zero_page[16]; }
-
-#if defined(YOLO_STAMP) && YOLO_PIPE_PART == 0
-// Instrumented build only (make stamp): per-block shader-clock stamps of the phases of conv_pipe_kernel (3x3 unit).
-__device__ long long yolo_stamps[8192 * 8];
-#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) yolo_stamps[blockIdx.x * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
-#define STAMP_ID() do { if (threadIdx.x == 0 && blockIdx.x < 8192) { unsigned id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); yolo_stamps[blockIdx.x * 8 + 7] = (long long)id | ((long long)(xcc & 0xf) << 32); yolo_stamps[blockIdx.x * 8 + 6] = wall_clock64(); } } while (0)
-extern "C" int yolo_debug_read_stamps(long long* host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(yolo_stamps), sizeof(long long) * n, 0, hipMemcpyDeviceToHost);
-}
-#else
-#define STAMP(i)
-#define STAMP_ID()
-#endif
 
 typedef __attribute__((address_space(3))) char lds_char;
 
@@ -546,10 +534,10 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     }
     }
     STAMP(2);
-    wait_vmcnt<0>();     // the tail's dead DMAs must land before the block's LDS is released
-
     // ---- epilogue (conv_epilogue.h): every wave transposes its slab through its own LDS scratch ------
-    __builtin_amdgcn_s_barrier();        // all waves are done reading the pipeline's LDS
+    // (round 5) The output offsets -- a dozen divisions per lane -- and the epilogue's reads of the argument block are done
+    // BEFORE the K loop's drain: the phase stamps (tools/stamp_probe.py) showed ~1.5 k cycles of drain + barrier (the tail's dead
+    // DMAs making their round trip) followed by ~1 k cycles of this set-up, one after the other, with nothing else to issue.
     {
     const ConvArgs& a = kargs_fresh();                 // (the epilogue's own reads: nothing of the set-up stays live for it)
     const int Ho = a.Ho, Wo = a.Wo, TWt = a.TWt;
@@ -577,6 +565,8 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         yoff[ni] = (i < a.total_i) ? (long long)n * a.y_bs + (long long)pix * a.y_ps : -1;
         roff[ni] = (long long)n * a.r_bs + (long long)pix * a.r_ps;
     }
+    wait_vmcnt<0>();                     // the tail's dead DMAs must land before the block's LDS is released
+    __builtin_amdgcn_s_barrier();        // all waves are done reading the pipeline's LDS
     STAMP(3);
     // (STATS: one partial row of BatchNorm sums per (pixel tile, pixel wave))
     constexpr int ESTATS = STATS == 3 ? 0 : STATS;       // (3 = the fused tail 1x1 below, not a statistics mode)
@@ -681,7 +671,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         b.up2 = 0; b.d2s = 0; b.slope = a.t_slope; b.y_bs = a.t_y_bs; b.y_ps = a.t_y_ps; b.stats = nullptr;
         conv_epilogue<T, 1, NI, 0>(acc2, yoff2, smem + wave * YOLO_EPI_WAVE_BYTES_MI(1), b, wave_c * 32, lane, nullptr, nullptr);
     }
-#if defined(YOLO_STAMP) && YOLO_PIPE_PART == 0
+#if defined(YOLO_STAMP_ON)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(5);
 #endif
