@@ -12,6 +12,7 @@
 // Rounding order is unchanged: fp32 (acc*scale+bias) -> LeakyReLU -> + residual (fp32) -> round.
 #pragma once
 #include "conv_args.h"
+#include <type_traits>
 #include "stamp.h"
 
 // bytes of LDS scratch one wave needs (max over MI in {1,2}): 32 rows x (64*4+16) + 2 x 32 x 8 (output offsets) + 2 x 32 x 8
@@ -190,7 +191,18 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
         const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)(STATS == 2 ? a.s_y : a.y), 0, 0x7fffffff, 0x00020000);
         int yb[2][NPASS];                       // byte offset of the lane's 16-byte piece in y (-1: none)
         u32x4_t rb[2][NPASS], sb[2][NPASS];
-        auto prefetch_b = [&](int ni) {
+        // (round 5) The uniform decisions -- identity epilogue, residual, 2x2 up-sampled stores -- are taken ONCE around the slab loop:
+        // the common combinations are compiled as specialisations (the flag a compile-time constant), the rest runs the generic
+        // form with the flags read at run time (FLAG < 0).  Inside the loop the branches cut every pass into basic blocks: the
+        // results of the scale / bias block were copied into the registers the residual block expects (4 v_mov_b64 per pass), the
+        // up-sampling test cost a compare and three selects per pass, and the LDS addresses were recomputed per pass.  The
+        // epilogue is bound by the vector pipe (two waves per SIMD, ~260 VALU instructions each per 32-pixel slab: stamp_probe.py).
+        const char* const rbase = wsm + row0 * RS + col * CPL * 4;       // this lane's piece of row row0; pass k, quad q: + k * RPP * RS + q * 16
+        char* const wbase = wsm + l31 * RS + 16 * h;                       // this lane's row of the slab; (mi, g): + (mi * 32 + 8 * g) * 4
+        auto run = [&](auto id_c, auto rs_c, auto up_c) __attribute__((always_inline)) {
+        constexpr int ID_ = decltype(id_c)::value, RS_ = decltype(rs_c)::value, UP_ = decltype(up_c)::value;
+        const bool f_ident = ID_ < 0 ? ident : (bool)ID_, f_res = RS_ < 0 ? has_res : (bool)RS_, f_up2 = UP_ < 0 ? (bool)a.up2 : (bool)UP_;
+        auto prefetch_b = [&](int ni) __attribute__((always_inline)) {
             if (h == 0) ytab[(ni & 1) * 32 + l31] = yoff[ni];
             if (res_sep && h == 1) rtab[(ni & 1) * 32 + l31] = roff[ni];
             wave_lds_fence();
@@ -202,7 +214,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
 #ifdef YOLO_LAB
                 if (a.lab & 1) yb[ni & 1][k] = -1;
 #endif
-                if (has_res) {
+                if (f_res) {
                     const long long r_ = res_sep ? rtab[(ni & 1) * 32 + row0 + k * RPP] : y_;
 #ifdef YOLO_LAB
                     rb[ni & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (ok && !(a.lab & 2)) ? (int)((r_ + cofs) * ES) : -1, 0, 0);
@@ -228,7 +240,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
-                    *(f32x4*)(wsm + l31 * RS + (mi * 32 + 8 * g + 4 * h) * 4) = v;
+                    *(f32x4*)(wbase + (mi * 32 + 8 * g) * 4) = v;
                 }
             wave_lds_fence();
             if (ni < 3) STAMP(10 + 2 * ni);
@@ -239,14 +251,14 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                 for (int q = 0; q < CPL / 4; ++q) {
 #ifdef YOLO_LAB
                     f32x4 t4 = {acc[0][ni][4 * q], acc[0][ni][4 * q + 1], acc[0][ni][4 * q + 2], acc[0][ni][4 * q + 3]};      // (ablation 16: no transpose, wrong values)
-                    if (!(a.lab & 16)) t4 = *(const f32x4*)(wsm + (row0 + k * RPP) * RS + (col * CPL + 4 * q) * 4);
+                    if (!(a.lab & 16)) t4 = *(const f32x4*)(rbase + k * RPP * RS + q * 16);
 #else
-                    const f32x4 t4 = *(const f32x4*)(wsm + (row0 + k * RPP) * RS + (col * CPL + 4 * q) * 4);
+                    const f32x4 t4 = *(const f32x4*)(rbase + k * RPP * RS + q * 16);
 #endif
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[4 * q + e] = t4[e];
                 }
-                if (!ident) {
+                if (!f_ident) {
 #pragma unroll
                     for (int e = 0; e < CPL; ++e) {
                         const float t = v[e] * sc[e] + bi[e];
@@ -256,7 +268,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                 const int ob = yb[ni & 1][k];
                 u32x4_t ov;
                 if constexpr (ES == 2) {
-                    if (has_res) {
+                    if (f_res) {
                         const uint32_t w[4] = {rb[ni & 1][k].x, rb[ni & 1][k].y, rb[ni & 1][k].z, rb[ni & 1][k].w};
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
@@ -290,14 +302,14 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                         }
                     }
                 } else {
-                    if (has_res) {
+                    if (f_res) {
                         v[0] += __uint_as_float(rb[ni & 1][k].x); v[1] += __uint_as_float(rb[ni & 1][k].y);
                         v[2] += __uint_as_float(rb[ni & 1][k].z); v[3] += __uint_as_float(rb[ni & 1][k].w);
                     }
                     ov.x = __float_as_uint(v[0]); ov.y = __float_as_uint(v[1]); ov.z = __float_as_uint(v[2]); ov.w = __float_as_uint(v[3]);
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob, 0, 0);
-                if (a.up2) {                            // the other three pixels of the 2x2 patch (row pitch 2*Wo pixels)
+                if (f_up2) {                            // the other three pixels of the 2x2 patch (row pitch 2*Wo pixels)
                     __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_a : -1, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_b : -1, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(ov, yrs, ob >= 0 ? ob + up_b + up_a : -1, 0, 0);
@@ -305,6 +317,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
             }
             if (ni < 3) STAMP(11 + 2 * ni);
         }
+        };
+        typedef std::integral_constant<int, 0> F0;
+        typedef std::integral_constant<int, 1> F1;
+        typedef std::integral_constant<int, -1> FR;
+        if (a.up2) run(FR{}, FR{}, FR{});                                   // (two transition convolutions per net)
+        else if (!ident) { if (has_res) run(F0{}, F1{}, F0{}); else run(F0{}, F0{}, F0{}); }
+        else { if (has_res) run(F1{}, F1{}, F0{}); else run(F1{}, F0{}, F0{}); }
     } else {
     // The residual loads of slab ni+1 are issued BEFORE slab ni is processed (two register sets), so their latency
     // hides under the previous slab's transpose/arithmetic/stores -- the phase stamps showed one exposed memory
