@@ -770,8 +770,11 @@ def main():
             out['train_416_bs64']['global_batch'] = t['config']['global_batch']
             out['train_416_bs64']['batch_per_gpu'] = Bt
             if world > 1 and Bt != 64:
+                import gc
+                del t
+                gc.collect()                              # (net <-> trainer reference cycle: the first pass's 10-40 GB must go first)
                 torch.cuda.empty_cache()
-                t = train_pass(args, spec, size, 64, rank, world, dev, dist, max(kt // 2, 5), wt, preheat_s=0.0)
+                t = train_pass(args, spec, size, 64, rank, world, dev, dist, max(kt // 2, 3), wt, preheat_s=0.0)
                 out['train_416_bs64_weak'] = {k: t[k] for k in keep if k in t}
                 out['train_416_bs64_weak']['workload'] = t['config']['workload'] + ' (64 per GPU: weak scaling of configs[2])'
                 out['train_416_bs64_weak']['global_batch'] = t['config']['global_batch']

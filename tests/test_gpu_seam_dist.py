@@ -391,6 +391,9 @@ def test_bench_two_ranks_sharing_the_gpu(world):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     env.update(YOLO_BENCH_BACKEND='gloo', YOLO_BENCH_SHARED_GPU='1')
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()                # (the N ranks share THIS process's GPU: give back what the earlier tests cached)
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', '3', '--warmup', '1', '--no-northstar',
                         '--no-roofline', '--no-repeats', '--sustain-steps', '0', '--train-timeout', '900'], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
