@@ -186,3 +186,28 @@ def test_conv_variant_eligibility_rules():
                 assert not (ok and m == 2 and c[6] != 1), (c, a, m)
                 n_stats += ok
     assert n_stats == 246
+
+
+def test_launch_plan_round_trip_and_committed_file():
+    """yolo_amd/plans.py: tuning states survive the JSON file (nested tuple keys, bools as 0 / 1), the md5 is over the contents, and
+    the COMMITTED plan (profiles/plan.json, what bench.py launches by default) loads and holds choices for the three sections."""
+    import tempfile
+    from yolo_amd import plans
+    st = {'algo': {(32, 13, 13, 1024, 512, 1, 1, 0, False, 1): 12, ('tail', 32, 52, 52, 128, 256, 1, True, 128, 0, 0, 1, 0, 0, 0): 1,
+                   ('res', 32, 208, 208, 64): 1},
+          'dgrad': {('s2', (64, 26, 26, 512), 512, 256, True): 6, ((64, 13, 13, 1024), 1024, 512, 3, False): 2},
+          'wgrad': {(64, 13, 13, 512, 1024, 3, 1): 3}}
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'p.json')
+        plans.save(path, st, {'commit': 'x'})
+        got, meta = plans.load(path)
+        assert got == st and meta['md5'] == plans.md5(st) == plans.md5(got) and meta['commit'] == 'x'
+        # a hand-edited plan is refused
+        txt = open(path).read().replace('12', '13', 1)
+        open(path, 'w').write(txt)
+        with pytest.raises(ValueError):
+            plans.load(path)
+    assert plans.new_keys(plans.merge(st, {'algo': {(1, 2): 3}}), st) == 1 and plans.new_keys(st, st) == 0
+    state, meta = plans.load(plans.DEFAULT)
+    assert all(len(state[s]) > 20 for s in plans.SECTIONS), {s: len(state[s]) for s in plans.SECTIONS}
+    assert meta['md5'] == plans.md5(state) and meta.get('commit')

@@ -6,7 +6,7 @@ tag=${1:-r2}
 TC=gpurun_out/${tag}_tune_train.json
 python bench.py --mode train --steps 10 --warmup 2 --tune-cache $TC > gpurun_out/${tag}_train.json 2>/dev/null
 rm -rf /tmp/trprof
-YOLO_TRAIN_SERIAL_WGRAD=${SERIAL-1} rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/trprof -- python bench.py --mode train --steps 10 --warmup 2 --tune-cache $TC > gpurun_out/${tag}_train_serial.json 2>/dev/null
+YOLO_LAB=1 YOLO_TRAIN_SERIAL_WGRAD=${SERIAL-1} rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/trprof -- python bench.py --mode train --steps 10 --warmup 2 --tune-cache $TC > gpurun_out/${tag}_train_serial.json 2>/dev/null
 f=$(find /tmp/trprof -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/${tag}_train_serial_kernel_stats.csv
 f=$(find /tmp/trprof -name "*kernel_trace.csv" | head -1); python - "$f" > gpurun_out/${tag}_train_last_step.txt <<'PY'
 import csv, sys

@@ -20,6 +20,16 @@ class YoloError(RuntimeError):
     pass
 
 
+def lab_knob(name, default=None):
+    """A/B and ablation switches of tools/ (YOLO_TRAIN_*, YOLO_SIDE_FILTER, ...): read ONLY when YOLO_LAB=1 is set -- the product
+    does not change behaviour with the environment of whoever imports it (the C library's knobs are compiled out the same way:
+    csrc/common.h YOLO_LAB_ENV).  Two deliberate exceptions stay plain: YOLO_AMD_LIB (which library to load) and the test-only
+    switches of bench.py / GradBuckets.active (YOLO_BENCH_*)."""
+    if os.environ.get('YOLO_LAB') != '1':
+        return default
+    return os.environ.get(name, default)
+
+
 class ConvDesc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('w_packed', C.c_void_p), ('scale', C.c_void_p), ('bias', C.c_void_p),
                 ('residual', C.c_void_p), ('y', C.c_void_p),

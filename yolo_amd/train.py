@@ -97,21 +97,21 @@ class Trainer(object):
         # two BatchNorm workspaces used alternately (yolo_bn_train_*_pp: a call leaves its own dirty and zeroes the next one's)
         self.ws2 = [torch.zeros(2 * cmax, dtype=torch.float64, device=self.dev) for _ in range(2)]
         self._ws_i = 0
-        self._bn3 = bool(os.environ.get('YOLO_TRAIN_BN3'))      # (the knob: separate finalize launches, for A/B runs)
+        self._bn3 = bool(L.lab_knob('YOLO_TRAIN_BN3'))      # (the knob: separate finalize launches, for A/B runs)
         self.ws = torch.zeros(2 * cmax, dtype=torch.float64, device=self.dev)
         wsb = max(self.lib.yolo_conv_wgrad_workspace_bytes(max(c.cin, 8), c.cout, c.k, self.ldt) for c in g.convs())
         self.wg_ws = torch.zeros(max(wsb, 16), dtype=torch.uint8, device=self.dev)       # (kept zeroed by the library)
         # weight gradients run on a side stream: they are off the backward pass's critical path (dy -> data gradient ->
         # previous layer's BN backward) and MFMA-bound, while the BN passes they overlap are HBM-bound
         self._side = torch.cuda.Stream(device=self.dev)
-        self._overlap = not os.environ.get('YOLO_TRAIN_SERIAL_WGRAD')          # (the knob keeps the serial order for A/B runs)
+        self._overlap = not L.lab_knob('YOLO_TRAIN_SERIAL_WGRAD')          # (the knob keeps the serial order for A/B runs)
         # BatchNorm sums taken in the producing convolution's epilogue (yolo_conv_desc.stats) instead of in a reduction pass
         # of their own; (the knob: the separate passes, for A/B runs)
-        self._fuse_stats = self.ldt == L.BF16 and not os.environ.get('YOLO_TRAIN_NO_STATS_FUSION')
+        self._fuse_stats = self.ldt == L.BF16 and not L.lab_knob('YOLO_TRAIN_NO_STATS_FUSION')
         self._stats_b = None            # partial rows of the data gradients' statistics epilogues (grown on demand)
-        modes = os.environ.get('YOLO_TRAIN_STATS_MODES', '1')    # '1' forward sums, '2' backward sums, '12' both
+        modes = L.lab_knob('YOLO_TRAIN_STATS_MODES', '1')    # '1' forward sums, '2' backward sums, '12' both
         self._fuse_fwd, self._fuse_bwd = self._fuse_stats and '1' in modes, self._fuse_stats and '2' in modes
-        self._identity = not os.environ.get('YOLO_TRAIN_UNIT_EPILOGUE')        # (the knob: scale 1 / bias 0 arrays instead of the identity epilogue)
+        self._identity = not L.lab_knob('YOLO_TRAIN_UNIT_EPILOGUE')        # (the knob: scale 1 / bias 0 arrays instead of the identity epilogue)
         self._repack()
         self._packed_version = net._version
 
@@ -145,7 +145,7 @@ class Trainer(object):
                 ones = torch.zeros(cp, dtype=torch.float32, device=self.dev); ones[:max(c.cout, c.cin)] = 1.0
                 bias = torch.zeros(cp, dtype=torch.float32, device=self.dev)
                 self._prep[c.name] = (wp, wd, ones, bias, torch.zeros(cp, dtype=torch.float32, device=self.dev))
-                nb = lib.yolo_pack_pair_blocks(c.cout, c.cin, c.k) if (self.ldt == L.BF16 and not os.environ.get('YOLO_TRAIN_OLD_PACK')) else -1
+                nb = lib.yolo_pack_pair_blocks(c.cout, c.cin, c.k) if (self.ldt == L.BF16 and not L.lab_knob('YOLO_TRAIN_OLD_PACK')) else -1
                 if nb > 0:
                     # both images from one read of the weights (yolo_pack_conv_weights_pairs)
                     pairs.append((w.data_ptr(), wp.data_ptr(), wd.data_ptr(), c.cout, c.cin, c.k, 0))
@@ -157,7 +157,7 @@ class Trainer(object):
                     recs.append((w.data_ptr(), wd.data_ptr(), c.cin, c.cout, c.k, 1))
                     first.append(first[-1] + lib.yolo_pack_batch_blocks(c.cin, c.cout, c.k, self.ldt))
                 if (c.k == 3 and c.stride == 2 and self.ldt == L.BF16 and c.cin % 8 == 0 and c.cout % 32 == 0
-                        and not os.environ.get('YOLO_TRAIN_DILATED_DGRAD')):      # (the knob keeps the old form for A/B runs)
+                        and not L.lab_knob('YOLO_TRAIN_DILATED_DGRAD')):      # (the knob keeps the old form for A/B runs)
                     # sub-pixel data gradient (yolo_conv_dgrad_s2): 2x2-window image with 4 x Cin_f output channels
                     w2 = torch.empty(lib.yolo_packed_weight_bytes(4 * c.cin, c.cout, 2, self.ldt), dtype=torch.uint8, device=self.dev)
                     cp4 = lib.yolo_padded_channels(4 * c.cin)
@@ -481,7 +481,7 @@ class Trainer(object):
         """yolo_conv_wgrad_algo id for conv c: 0 (the library's choice) unless the net was built with tune='measure' -- then the
         fastest of the kernels that take the shape, timed once per layer shape on a scratch gradient (the 8-wave row walk wins
         on two D53 shapes, the 16-column walker on the 13x13 ones, ...)."""
-        if getattr(self.net, 'tune', None) != 'measure' or self.ldt != L.BF16 or os.environ.get('YOLO_TRAIN_NO_WGRAD_TUNE'):
+        if getattr(self.net, 'tune', None) != 'measure' or self.ldt != L.BF16 or L.lab_knob('YOLO_TRAIN_NO_WGRAD_TUNE'):
             return 0
         N, Hh, Ww, Cx = xin.shape
         key = (N, Hh, Ww, Cx, c.cout, c.k, c.stride)
@@ -518,7 +518,7 @@ class Trainer(object):
         side stream (all of them, in order: they share one workspace).  The gradient buckets hear about `names` one
         layer later, once the current stream has been made to wait for that layer's side-stream work."""
         main = torch.cuda.current_stream()
-        flt = os.environ.get('YOLO_SIDE_FILTER')                  # (diagnostics: exactly these classes go to the side stream)
+        flt = L.lab_knob('YOLO_SIDE_FILTER')                  # (diagnostics: exactly these classes go to the side stream)
         side = (tag in flt.split(',')) if flt is not None else True
         if not self._overlap or not side:
             if self._overlap:
