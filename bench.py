@@ -117,10 +117,14 @@ class Telemetry(object):
                 'telemetry_source': self.source}
 
 
-def cpu_baseline(size, seconds=6.0, batch=8):
+def cpu_baseline(size, seconds=6.0, batch=8, dev=None):
     """Oracle forward + numpy decode/top-1 on the host cores: images/s on a bounded sample.  oneDNN does not scale to
     every hardware thread of a big host (SMT siblings, NUMA), so the sample is run at a few thread counts (all
-    hardware threads, half, a quarter) and the BEST is reported with its count."""
+    hardware threads, half, a quarter) and the BEST is reported with its count.
+
+    dev: the oracle also CHECKS the HIP path here (it is the checker, never the thing measured): the first two images of the
+    sample through CarNet in every arithmetic path, decoded, against the oracle's rows -> `box_parity` (max / RMS of
+    |a - b| / (1 + |b|) over [l, t, r, b] of all boxes, top-1 index agreement): the `north_star` tolerance as a number in the line."""
     from oracle import graph as og, forward as of, detect as od
     spec = og.spec_d53()
     g = og.build_graph(spec)
@@ -158,7 +162,29 @@ def cpu_baseline(size, seconds=6.0, batch=8):
             best = (tried[nt], nt, n, el)
         elif tried[nt] < 0.7 * best[0]:
             break
-    return dict(value=best[0], unit='images/s', cores=best[1], kind='port',
+    parity = None
+    if dev is not None:
+        from yolo_amd.net import CarNet
+        from yolo_amd.detect import Detector
+        with torch.no_grad():
+            ref = [o.numpy() for o in of.forward_torch(g, Pt, x[:2])]
+        ref_rows = od.decode_all(ref, spec['slice_point'], size, syxhw)
+        _, ref_idx = od.predict(ref, spec['slice_point'], size, syxhw)
+        det = Detector(spec, size, steps, device=dev)
+        parity = {'sample': 'images 0-1 of the cpu_baseline sample (D53 spec, identity BN, Xavier weights seed 0), decoded rows vs the fp32 oracle',
+                  'measure': 'max / RMS of |a - b| / (1 + |b|) over [l,t,r,b] of all %d boxes' % ref_rows.shape[1]}
+        for dt in ('f32', 'f16', 'bf16'):
+            net = CarNet(spec, dtype=dt, device=dev).load_params(P)
+            outs = net(x[:2].to(dev))
+            rows = det.decode(outs).cpu().numpy()
+            _, idx = det.predict_device(outs)
+            e = (rows[..., 1:5].astype(np.float64) - ref_rows[..., 1:5]) / (1.0 + np.abs(ref_rows[..., 1:5]))
+            parity[dt] = {'box_max': float(np.abs(e).max()), 'box_rms': float(np.sqrt(np.mean(e * e))),
+                          'score_max': float(np.abs(rows[..., 0] - ref_rows[..., 0]).max()),
+                          'top1_index_agreement': float(np.mean(idx.cpu().numpy() == ref_idx))}
+            del net
+        torch.cuda.empty_cache()
+    return dict(value=best[0], unit='images/s', cores=best[1], kind='port', box_parity=parity,
                 sample='oracle.forward_torch (torch-CPU fp32 oneDNN restatement of the reference graph; MXNet cannot run '
                        'here) + numpy decode/top-1, D53 spec %dx%d, batch %d x %d iterations after 1 warm-up (%.1f s) at the '
                        'best of the thread counts tried %s on a %d-thread host'
@@ -792,7 +818,7 @@ def main():
             if dog is not None:
                 dog.cancel()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(size)
+        out['cpu_baseline'] = cpu_baseline(size, dev=dev)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

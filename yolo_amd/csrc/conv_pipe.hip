@@ -368,6 +368,11 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         } else {
             wait_vmcnt<(R1 - 2) * (WL + XL)>();
         }
+#ifdef YOLO_LAB
+        // (lab, YOLO_EPI_AB bit 32: every second barrier dropped -- WRONG results, a timing probe of what a barrier costs;
+        //  bit 64: the counted waits of those phases dropped as well)
+        if (!((a.lab & 32) && (q & 1)))
+#endif
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);      // keep the next phase's address math out of this phase (VGPR pressure)
     };
