@@ -754,7 +754,22 @@ def main():
                            'unit': 'images/s', 'steps': k32, 'ms_per_step': round(el32 / k32 * 1e3, 4),
                            'net_tflops': round(net32.graph.flops(*size) * v32 / 1e12, 1),
                            'frac_of_f32_peak': round(net32.graph.flops(*size) * v32 / 1e12 / MFMA_PEAK_TFLOPS['f32'], 4)}
-        net = net32
+        # ... and the reference's own reduced precision (use_fp16, car/YOLO.py:98-100) on the same workload: the bf16 MFMA rate minus
+        # what the power cap takes, 12x closer to the fp32 oracle on the decoded boxes (cpu_baseline.box_parity)
+        del net32
+        torch.cuda.empty_cache()
+        net16 = CarNet(spec, dtype='f16', device=dev, tune='measure').initialize(seed=1234)
+        if args.plan_state is not None:
+            net16.load_tuning_state(args.plan_state)
+        net16.prepare()
+        k16 = max(args.steps, 10)
+        el16 = timed_pass(net16, det, x32, 'top1_blocking', k16, 3, fence)[0]
+        v16 = B * k16 / el16
+        out['f16_path'] = {'workload': "the headline workload with dtype='f16' (the reference's use_fp16)", 'value': round(v16, 2), 'unit': 'images/s',
+                           'steps': k16, 'ms_per_step': round(el16 / k16 * 1e3, 4),
+                           'net_tflops': round(net16.graph.flops(*size) * v16 / 1e12, 1),
+                           'frac_of_peak': round(net16.graph.flops(*size) * v16 / 1e12 / MFMA_PEAK_TFLOPS['f16'], 4)}
+        net = net16
         del x32
     if not args.no_train_key and headline:
         # BASELINE configs[2] (training step, 416x416 bs=64 per GPU) in the same driver-run line; under N > 1 this is

@@ -43,6 +43,15 @@ if not a.no_f32:
     print(shapes[-1], '%.0f s' % (time.time() - t0), flush=True)
     del net
     torch.cuda.empty_cache()
+net = CarNet(spec, dtype='f16', device=dev, tune='measure').initialize(seed=1234)
+net.prepare()
+for B, S in ((32, 416), (64, 608)):
+    net.plan_signature(B, S, S)
+    shapes.append('infer f16 %dx%d bs %d' % (S, S, B))
+    print(shapes[-1], '%.0f s' % (time.time() - t0), flush=True)
+states.append(net.tuning_state())
+del net
+torch.cuda.empty_cache()
 for B in [int(v) for v in a.train_batches.split(',') if v]:
     net = CarNet(spec, dtype='bf16', device=dev, tune='measure').initialize(seed=1234)
     tr = Trainer(net, (416, 416))

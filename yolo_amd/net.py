@@ -320,7 +320,7 @@ class CarNet(object):
             return False
         if self.tune != 'measure':
             return True
-        key = ('res', shp[0], shp[1], shp[2], C_)
+        key = ('res', shp[0], shp[1], shp[2], C_, _LIB_DT[self.dtype])
         if key in self._algo_cache:
             return bool(self._algo_cache[key])
         lib, st, dt = self._lib, L.stream_ptr(), _LIB_DT[self.dtype]
