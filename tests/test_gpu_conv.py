@@ -117,7 +117,7 @@ PIPE_CASES = [
 ]
 
 
-PIPE_ALGOS = [2, 3, 4, 5, 6, 7, 8, 11, 12, 19, 20, 21, 22, 23, 24, 25, 26, 30, 31, 32, 33, 35, 36, 37, 38, 39]
+PIPE_ALGOS = [2, 3, 4, 5, 6, 7, 8, 11, 12, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 35, 36, 37, 38, 39]
 
 
 # only the (shape, dtype, variant) pairs the library accepts (tests/util.py:eligible_pairs; the refusal rules are asserted

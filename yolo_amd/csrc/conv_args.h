@@ -35,7 +35,7 @@ struct ConvArgs {
     int nchunks, tiles_c;
     int buf32;              // conv_epilogue.h: 1 = y, the residual (and stats_y, tail_y) extents fit 31-bit byte offsets: the epilogue's
                             // loads / stores are unconditional buffer accesses (out-of-range offset = no access)
-    int lab;                // lab build only (YOLO_EPI_AB): epilogue ablation bits -- 1 drop the stores, 2 drop the residual loads, 4 skip the epilogue, 8 no scale / bias loads, 16 no LDS transpose
+    int lab;                // lab build only (YOLO_EPI_AB): epilogue ablation bits -- 1 drop the stores, 2 drop the residual loads, 4 skip the epilogue, 8 no scale / bias loads, 16 no LDS transpose; K-loop probes (wrong results): 32 every second barrier dropped, 64 no weight DMAs, 128 no input DMAs
     int vblocks;            // conv_pipe.hip: number of (pixel tile, cout tile) units = the grid size unless the blocks are persistent
     int out_f32;
     int x_ps;       // elements between input pixels (>= Cin: x may be a channel slice of a wider NHWC buffer)

@@ -206,6 +206,9 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     // weight DMA j (of WL) of global phase gp; the tail is clamped: it re-loads the last plane into a
     // dead ring slot so every phase issues the same number of DMAs and the counted waits stay exact
     auto issue_w1 = [&](int gp, int j) {
+#ifdef YOLO_LAB
+        if ((a.lab & 64) && gp >= WR) return;           // (lab probe, WRONG results: no weight DMAs after the first ring: what the L2 -> LDS weight stream costs)
+#endif
         const int kc = j / WL1, jj = j - kc * WL1;
         const int g = min(gp, nphase - 1) * KC + kc;
         glds16(wsrc + (long long)g * wplane + (long long)jj * NT * 16,
@@ -222,6 +225,9 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     const char* zero_page = (const char*)yolo_zero_page;
     if constexpr (W1) asm volatile("" : "+s"(zero_page));
     auto issue_x = [&](int j, int c, int buf) {
+#ifdef YOLO_LAB
+        if ((a.lab & 128) && c >= 2) return;            // (lab probe, WRONG results: no input DMAs after the first two chunks)
+#endif
         const int kc = j / XL1, jj = j - kc * XL1;
         const int cc = (KS != 1) ? min(c, nchunks - 1) : min(c, nphase - 1) * KC + kc;      // (1x1: c counts phases)
         const char* src = (xo[jj] != 0xffffffffu) ? ax + ((size_t)xo[jj] + (size_t)cc * 64) : zero_page;
@@ -831,6 +837,12 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
             case 7: return launch_pipe<T, 3, 2, 4, 1, 3, 384>(a, st, nm);
             case 8: return launch_pipe<T, 3, 2, 2, 2, 3, 320>(a, st, nm);
             case 11: return launch_pipe<T, 3, 2, 2, 2, 1, 192>(a, st, nm);
+            // (round 5) pixel-heavy tiles: the same wave tiles as algo 6 / 2 (96 x 64, 128 x 64) arranged 4 x 2 instead of 2 x 4.  A 3x3
+            // re-reads its weights for every tap and its input once per K chunk, so per output the L2 -> LDS stream of a 384 x 128
+            // tile is ~40 % smaller than that of the 192 x 256 one (X 30 KB + W 9 x 8 KB against 24.5 + 9 x 16 per chunk) -- and a lab
+            // probe that drops the weight DMAs (wrong results, timing only: tools/ab_barrier.sh) runs these kernels 8-12 % faster.
+            case 27: return launch_pipe<T, 3, 4, 2, 2, 3, 768>(a, st, nm);     // 8 waves, 384 px x 128 cout (wave tile 96x64)
+            case 28: return launch_pipe<T, 3, 4, 2, 2, 4, 1024>(a, st, nm);    // 8 waves, 512 px x 128 cout (wave tile 128x64)
             case 26:                                                            // 4 waves, 256 px x 256 cout (wave tile 128x128)
                 if constexpr (sizeof(T) == 2) return launch_pipe<T, 3, 2, 2, 4, 4, 512>(a, st, nm);
                 break;
