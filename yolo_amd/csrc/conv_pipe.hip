@@ -40,9 +40,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst_unifor
                  : "v"(gsrc), "s"(lds_dst_uniform)
                  : "memory");
 }
-// The same without saving / restoring m0 (the lean loops: nothing the compiler emits for gfx950 in these kernels reads
-// m0 -- LDS instructions have not needed it since GFX9 -- and the generic form's save + restore is two of the four
-// scalar instructions of every DMA).
+// The same without saving / restoring m0 (nothing the compiler emits for gfx950 in these kernels reads m0 -- LDS instructions
+// have not needed it since GFX9 -- and the generic form's save + restore is two of the four scalar instructions of every DMA):
+// every K loop of this file since round 5 (the lean 1x1 loops since round 3); the fused tail keeps the saving form.
 __device__ __forceinline__ void glds16_m0(const void* gsrc, uint32_t lds_dst_uniform) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
 }
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
 #endif
         const int kc = j / WL1, jj = j - kc * WL1;
         const int g = min(gp, nphase - 1) * KC + kc;
-        glds16(wsrc + (long long)g * wplane + (long long)jj * NT * 16,
+        glds16_m0(wsrc + (long long)g * wplane + (long long)jj * NT * 16,
                wave_lds + W_OFF + (gp % WR) * W_STAGE + kc * W_STAGE1 + jj * NT * 16);
     };
     auto issue_w = [&](int gp) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         const int kc = j / XL1, jj = j - kc * XL1;
         const int cc = (KS != 1) ? min(c, nchunks - 1) : min(c, nphase - 1) * KC + kc;      // (1x1: c counts phases)
         const char* src = (xo[jj] != 0xffffffffu) ? ax + ((size_t)xo[jj] + (size_t)cc * 64) : zero_page;
-        glds16(src, wave_lds + buf * X_STAGE + kc * X_STAGE1 + jj * NT * 16);
+        glds16_m0(src, wave_lds + buf * X_STAGE + kc * X_STAGE1 + jj * NT * 16);
     };
     static_assert(KS == 1 || XL <= PPC, "3x3: at most one input DMA per phase");
     static_assert(BC * 4 >= NT, "one weight DMA covers rows of a single tap plane");
