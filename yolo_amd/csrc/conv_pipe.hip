@@ -26,8 +26,15 @@
 #include <type_traits>
 #include <atomic>
 
-// The file is compiled TWICE (csrc/Makefile): YOLO_PIPE_PART 0 = the 3x3 kernels and conv_pipe_dispatch, 1 = the 2x2-window
-// and 1x1 kernels behind conv_pipe_dispatch_b -- two translation units of ~65 instantiations each build in parallel.
+// The file is compiled FOUR times (csrc/Makefile), kernel kind x element type, so that the ~270 instantiations build in parallel:
+//   YOLO_PIPE_PART 0: 3x3 kernels, bf16 + conv_pipe_dispatch     1: 2x2-window and 1x1 kernels, bf16 (conv_pipe_dispatch_b)
+//                  2: 3x3 kernels, f16 and f32 (.._dispatch_c)   3: 1x1 kernels, f16 and f32 (conv_pipe_dispatch_d)
+//                  4: 3x3 stride-2 kernels, bf16 (conv_pipe_dispatch_e)
+//                  5: 3x3 stride-1 kernels, bf16, the second half of the tile variants (conv_pipe_dispatch_f)
+#define YOLO_PIPE_3X3 (YOLO_PIPE_PART == 0 || YOLO_PIPE_PART == 2 || YOLO_PIPE_PART == 4 || YOLO_PIPE_PART == 5)
+// (which stride-1 3x3 variants a unit holds: bf16 is split over units 0 and 5)
+#define YOLO_PIPE_S1A (YOLO_PIPE_PART == 0 || YOLO_PIPE_PART == 2)
+#define YOLO_PIPE_S1B (YOLO_PIPE_PART == 5 || YOLO_PIPE_PART == 2)
 namespace { __device__ __attribute__((aligned(64))) unsigned int yolo_zero_page[16]; }
 
 typedef __attribute__((address_space(3))) char lds_char;
@@ -809,11 +816,18 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
 //       and was removed: the long-K layers are not bound by LDS traffic or by the loop structure (power / clock)
 //   (also tried: algo 4 with a 2-slot weight ring = 48 KB of LDS, three blocks per CU -- 4-10 % faster than algo 4 on the short-K
 //    layers, never faster than the 192-pixel tiles there, which fit neither three blocks of LDS nor of registers; removed)
-int conv_pipe_dispatch_b(ConvArgs& a, int ks, int dtype, int algo, hipStream_t st, const NameOut* nm);     // (unit 1)
+int conv_pipe_dispatch_b(ConvArgs& a, int ks, int dtype, int algo, hipStream_t st, const NameOut* nm);                 // (unit 1)
+int conv_pipe_dispatch_c(ConvArgs& a, int ks, int stride, int dtype, int algo, hipStream_t st, const NameOut* nm);     // (unit 2)
+int conv_pipe_dispatch_d(ConvArgs& a, int ks, int dtype, int algo, hipStream_t st, const NameOut* nm);                 // (unit 3)
+int conv_pipe_dispatch_e(ConvArgs& a, int algo, hipStream_t st, const NameOut* nm);                                    // (unit 4)
+int conv_pipe_dispatch_f(ConvArgs& a, int algo, hipStream_t st, const NameOut* nm);                                    // (unit 5)
 
 template <typename T>
 static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_t st, const NameOut* nm) {
 #if YOLO_PIPE_PART == 0
+    if (ks == 3 && stride == 2) return conv_pipe_dispatch_e(a, algo, st, nm);      // (bf16: a unit of its own)
+#endif
+#if YOLO_PIPE_PART == 2 || YOLO_PIPE_PART == 4
     if (ks == 3 && stride == 2) {
         // stride 2: the input footprint is ~4x the output tile, so tiles are 128 output pixels
         switch (algo) {
@@ -827,15 +841,25 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
         }
         return YOLO_EUNSUPPORTED;
     }
+#endif
+#if YOLO_PIPE_PART == 4
+    return YOLO_EUNSUPPORTED;
+#elif YOLO_PIPE_3X3
     if (ks == 3) {
         switch (algo) {
+#if YOLO_PIPE_S1A
             case 2: return launch_pipe<T, 3, 2, 4, 2, 4, 512>(a, st, nm);
             case 3: return launch_pipe<T, 3, 4, 2, 2, 2, 512>(a, st, nm);
             case 4: return launch_pipe<T, 3, 2, 2, 2, 2, 256>(a, st, nm);
-            case 5: return launch_pipe<T, 3, 1, 8, 1, 4, 256>(a, st, nm);
             case 6: return launch_pipe<T, 3, 2, 4, 2, 3, 384>(a, st, nm);
             case 7: return launch_pipe<T, 3, 2, 4, 1, 3, 384>(a, st, nm);
             case 8: return launch_pipe<T, 3, 2, 2, 2, 3, 320>(a, st, nm);
+#endif
+#if YOLO_PIPE_PART == 0
+            default: return conv_pipe_dispatch_f(a, algo, st, nm);
+#endif
+#if YOLO_PIPE_S1B
+            case 5: return launch_pipe<T, 3, 1, 8, 1, 4, 256>(a, st, nm);
             case 11: return launch_pipe<T, 3, 2, 2, 2, 1, 192>(a, st, nm);
             // (round 5) pixel-heavy tiles: the same wave tiles as algo 6 / 2 (96 x 64, 128 x 64) arranged 4 x 2 instead of 2 x 4.  A 3x3
             // re-reads its weights for every tap and its input once per K chunk, so per output the L2 -> LDS stream of a 384 x 128
@@ -846,10 +870,17 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
             case 26:                                                            // 4 waves, 256 px x 256 cout (wave tile 128x128)
                 if constexpr (sizeof(T) == 2) return launch_pipe<T, 3, 2, 2, 4, 4, 512>(a, st, nm);
                 break;
+#endif
         }
         return YOLO_EUNSUPPORTED;
     }
+#if YOLO_PIPE_PART == 5
+    return YOLO_EUNSUPPORTED;
+#elif YOLO_PIPE_PART == 0
     return conv_pipe_dispatch_b(a, ks, Elem<T>::dtype, algo, st, nm);
+#else
+    return conv_pipe_dispatch_d(a, ks, Elem<T>::dtype, algo, st, nm);
+#endif
 #else
     if (ks == 2) {
         // 2x2 window (yolo_conv_dgrad_s2, bf16 only): four phases per K chunk
@@ -903,11 +934,23 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
 #endif
 }
 
-#if YOLO_PIPE_PART == 1
+#if YOLO_PIPE_PART == 5
+int conv_pipe_dispatch_f(ConvArgs& a, int algo, hipStream_t st, const NameOut* nm) { return pipe_dispatch_t<bf16_t>(a, 3, 1, algo, st, nm); }
+#elif YOLO_PIPE_PART == 4
+int conv_pipe_dispatch_e(ConvArgs& a, int algo, hipStream_t st, const NameOut* nm) { return pipe_dispatch_t<bf16_t>(a, 3, 2, algo, st, nm); }
+#elif YOLO_PIPE_PART == 1
 int conv_pipe_dispatch_b(ConvArgs& a, int ks, int dtype, int algo, hipStream_t st, const NameOut* nm) {
-    if (dtype == YOLO_BF16) return pipe_dispatch_t<bf16_t>(a, ks, 1, algo, st, nm);
+    return pipe_dispatch_t<bf16_t>(a, ks, 1, algo, st, nm);
+}
+#elif YOLO_PIPE_PART == 3
+int conv_pipe_dispatch_d(ConvArgs& a, int ks, int dtype, int algo, hipStream_t st, const NameOut* nm) {
     if (dtype == YOLO_F16) return pipe_dispatch_t<f16_t>(a, ks, 1, algo, st, nm);
     return pipe_dispatch_t<float>(a, ks, 1, algo, st, nm);
+}
+#elif YOLO_PIPE_PART == 2
+int conv_pipe_dispatch_c(ConvArgs& a, int ks, int stride, int dtype, int algo, hipStream_t st, const NameOut* nm) {
+    if (dtype == YOLO_F16) return pipe_dispatch_t<f16_t>(a, ks, stride, algo, st, nm);
+    return pipe_dispatch_t<float>(a, ks, stride, algo, st, nm);
 }
 #else
 int conv_pipe_dispatch(ConvArgs& a, int ks, int stride, int dtype, int algo, hipStream_t st, const NameOut* nm) {
@@ -917,7 +960,6 @@ int conv_pipe_dispatch(ConvArgs& a, int ks, int stride, int dtype, int algo, hip
     if (ks == 1 && a.nchunks < 2) return YOLO_EUNSUPPORTED;     // a 1x1 needs >= 2 phases; a 3x3 has 9 per chunk
     if ((long long)a.N * a.H * a.W * a.x_ps * elem_size(dtype) >= 0xffffff00LL) return YOLO_EUNSUPPORTED;
     if (dtype == YOLO_BF16) return pipe_dispatch_t<bf16_t>(a, ks, stride, algo, st, nm);
-    if (dtype == YOLO_F16) return pipe_dispatch_t<f16_t>(a, ks, stride, algo, st, nm);
-    return pipe_dispatch_t<float>(a, ks, stride, algo, st, nm);
+    return conv_pipe_dispatch_c(a, ks, stride, dtype, algo, st, nm);
 }
 #endif

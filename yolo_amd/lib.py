@@ -123,7 +123,7 @@ def build(force=False):
     """Compile libyolo_amd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     if force:
         subprocess.check_call(['make', '-C', CSRC, 'clean'])
-    subprocess.check_call(['make', '-C', CSRC, '-j4'])
+    subprocess.check_call(['make', '-C', CSRC, '-j%d' % max(4, min(8, os.cpu_count() or 4))])
     return LIB_PATH
 
 
