@@ -413,3 +413,24 @@ def test_bench_two_ranks_sharing_the_gpu(world):
     # variants on both ranks (tune='measure' is box- and rank-dependent when left alone), and every rank's own time is in the line
     assert d['plans_identical_across_ranks'] is True and t['tuning_identical_across_ranks'] is True
     assert len(d['per_rank_ms_per_step']) == world and len(t['per_rank_ms_per_step']) == world and 'errors' not in d
+
+
+def test_bench_line_launches_the_committed_plan_and_quotes_its_own_pmc_pass():
+    """bench.py's default command (what the driver runs) launches profiles/plan.json: no shape is measured live, and the launch
+    plan it arrives at is the one the committed PMC pass was taken with -- `roofline.traffic` is quoted (a summary of another
+    plan would be refused: the lookup is keyed by plan_md5 and launches per step).  Guards profiles/ against a plan that was
+    re-made without refreshing the passes, and the plan against kernels that were renamed without re-making it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-northstar', '--no-train-key',
+                        '--no-f32-key', '--no-cpu-baseline', '--no-repeats'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert d['plan']['mode'] == 'plan' and d['plan']['file'] == 'profiles/plan.json' and d['plan']['measured_live'] == 0, d['plan']
+    rf = d['roofline']
+    assert rf['traffic'] is not None and rf['traffic_source'].startswith('profiles/'), rf
+    assert rf['traffic'] >= 0.9 * rf['algorithmic_bytes'] and 0.2 < rf['frac'] < 1.0
+    assert d['dtype'] == 'bf16' and d['config']['global_batch'] == 32 and d['unit'] == 'images/s'
