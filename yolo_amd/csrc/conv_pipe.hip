@@ -864,7 +864,7 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
             // (round 5) pixel-heavy tiles: the same wave tiles as algo 6 / 2 (96 x 64, 128 x 64) arranged 4 x 2 instead of 2 x 4.  A 3x3
             // re-reads its weights for every tap and its input once per K chunk, so per output the L2 -> LDS stream of a 384 x 128
             // tile is ~40 % smaller than that of the 192 x 256 one (X 30 KB + W 9 x 8 KB against 24.5 + 9 x 16 per chunk) -- and a lab
-            // probe that drops the weight DMAs (wrong results, timing only: tools/ab_barrier.sh) runs these kernels 8-12 % faster.
+            // probe that drops the weight DMAs (wrong results, timing only: tools/ab_kloop.sh) runs these kernels 8-12 % faster.
             case 27: return launch_pipe<T, 3, 4, 2, 2, 3, 768>(a, st, nm);     // 8 waves, 384 px x 128 cout (wave tile 96x64)
             case 28: return launch_pipe<T, 3, 4, 2, 2, 4, 1024>(a, st, nm);    // 8 waves, 512 px x 128 cout (wave tile 128x64)
             case 26:                                                            // 4 waves, 256 px x 256 cout (wave tile 128x128)
