@@ -289,22 +289,30 @@ __global__ __launch_bounds__(256 * KH, 2 / KH) void wgrad_walk_kernel(WalkArgs a
     float* drow = a.dwt + ((long long)(co0 + wm * 32) * a.Cin + (ci0 + wn * 32)) * 9;
     const long long co_pitch = (long long)a.Cin * 9;
     const int rot = (a.dbg & 4) ? 0 : (int)((unsigned)(slice * 7 + cseg * 11) % 36u);
+    // (round 5) The walk over the scratch -- element idx = tt * 64 + lane of [8 rows][288], tt = rot, rot + 1, ... mod 36 -- carries
+    // its row / remainder / gradient offset along instead of dividing per atomic (the rotation makes tt a run-time value: the
+    // compiler spent ~14 vector instructions per atomic on idx / 288, the row's cout and a 64-bit multiply by the cout pitch; the
+    // epilogue is ~20 % of the kernel and issues nothing else).  Row r of pass p is cout 8 p + r: one pitch per carry.
+    const int idx0 = rot * 64 + lane;
+    const int row0 = idx0 / 288;
+    const int rem0 = idx0 - row0 * 288;
+    const int pitch = (int)co_pitch;                    // (elements; the host bounds Cout * Cin * 9 below 2^31)
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) scr[((j + 4 * h) * 32 + l31) * 9 + tp] = acc[tp][4 * p + j];
+        int idx = idx0, row = row0, rem = rem0;
+        int off = (8 * p + row0) * pitch + rem0;        // element offset of (cout 8 p + row, rem) from drow
 #pragma unroll
         for (int t = 0; t < 36; ++t) {
             // (the K-slices of a tile finish together: each starts its pass at another row, so that they do not queue on
             //  the same addresses of the memory-side atomic units)
-            int tt = t + rot;
-            tt = tt >= 36 ? tt - 36 : tt;
-            const int idx = tt * 64 + lane;             // [row 0..7][288]
-            const int row = idx / 288, rem = idx - row * 288;
-            const int co_l = (row & 3) + 8 * p + 4 * (row >> 2);
-            atomicAdd(drow + co_l * co_pitch + rem, scr[idx]);
+            atomicAdd(drow + off, scr[idx]);
+            idx += 64; rem += 64; off += 64;
+            if (rem >= 288) { rem -= 288; row += 1; off += pitch - 288; }
+            if (row == 8) { row = 0; idx -= 2304; off -= 8 * pitch; }
         }
     }
 }
