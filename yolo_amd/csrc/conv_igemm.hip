@@ -355,22 +355,29 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
 // rounds x tile work, where rounds = ceil(tiles / (256 CUs x resident blocks per CU)) -- at the
 // reference's batch sizes tile quantisation on the 13x13 / 26x26 maps costs more than any difference
 // between the variants' inner loops.  The per-variant factors are measured (tools/conv_bench.py).
-static int conv_auto_algo(const ConvArgs& a, int ks, int stride, int dtype) {
+static int conv_auto_algo(const ConvArgs& a, int ks, int stride, int dtype, bool px_heavy = true) {
     if ((a.Cin * elem_size(dtype)) % 64 || (ks == 1 && a.nchunks < 2)) return 1;
     if (stride == 2) return ks == 3 ? (a.Cout > 128 ? 18 : 9) : 1;      // (18 = 10 with the 4-slot weight ring)
     struct V { int algo, bp, bc, bpc; float f; bool k1; };
+    // (round 5: the pixel-heavy 3x3 tiles 27 / 28 -- ~40 % less L2 -> LDS weight stream per output, measured 0.5-3.4 % faster than
+    //  6 / 2 wherever they fill the chip, tools/ab_tiles.sh)
     static const V vs[] = {{2, 256, 256, 1, 1.00f, true}, {3, 256, 128, 1, 1.10f, true}, {4, 128, 128, 2, 1.05f, true},
-                           {6, 192, 256, 1, 1.00f, false}, {8, 192, 128, 2, 1.05f, true}};
+                           {6, 192, 256, 1, 1.00f, false}, {8, 192, 128, 2, 1.05f, true},
+                           {27, 384, 128, 1, 0.98f, false}, {28, 512, 128, 1, 0.97f, false}};
     const long long px = (long long)a.N * a.Ho * a.Wo;
     int best = 1;
     double best_cost = 1e30;
     for (const V& v : vs) {
         if (ks == 1 && !v.k1) continue;
+        if (!px_heavy && v.algo >= 27) continue;
         const long long tiles = ((px + v.bp - 1) / v.bp) * ((a.Cout + v.bc - 1) / v.bc);
         const long long slots = 256LL * v.bpc;
-        const long long rounds = (tiles + slots - 1) / slots;
-        // a partially filled last round still costs a full block time; blocks co-resident on a CU share it
-        const double cost = (double)rounds * v.bp * v.bc * v.bpc * v.f;
+        // full rounds keep every CU's bpc block slots busy (the co-resident blocks share the CU: bpc block times); the last,
+        // partial round puts ceil(rest / 256) blocks on the busiest CU -- a launch of fewer tiles than CUs runs one block per CU
+        // at full speed whatever bpc is (13^2 512 -> 1024 at batch 32: 232 tiles of the two-per-CU 192 x 128 tile beat 120 of
+        // the 384 x 128 one, 50.7 against 64.2 us)
+        const long long full = tiles / slots, rest = tiles - full * slots;
+        const double cost = (double)(full * v.bpc + (rest + 255) / 256) * v.bp * v.bc * v.f;
         if (cost < best_cost) { best_cost = cost; best = v.algo; }
     }
     return best;
@@ -485,7 +492,11 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
         }
         if (algo >= 2) {
             ConvArgs b = a;
-            const int rc = conv_pipe_dispatch(b, d->ksize, d->stride, d->dtype, algo, st, nm);
+            int rc = conv_pipe_dispatch(b, d->ksize, d->stride, d->dtype, algo, st, nm);
+            if (rc == YOLO_EUNSUPPORTED && !d->algo && algo >= 27) {       // (halo of the pixel-heavy tile does not fit: the next best)
+                b = a;
+                rc = conv_pipe_dispatch(b, d->ksize, d->stride, d->dtype, conv_auto_algo(a, d->ksize, d->stride, d->dtype, false), st, nm);
+            }
             if (rc != YOLO_EUNSUPPORTED || d->algo) return rc;
         }
         if (a.stats_mode != 1 || d->dtype != YOLO_BF16) return YOLO_EUNSUPPORTED;   // generic kernel: forward sums, bf16
@@ -508,6 +519,10 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
             if (rc == YOLO_EUNSUPPORTED && pick == 18) {
                 b = a;
                 rc = conv_pipe_dispatch(b, d->ksize, d->stride, d->dtype, 10, st, nm);
+            }
+            if (rc == YOLO_EUNSUPPORTED && pick >= 27) {       // (the halo of a 384 / 512-pixel tile does not fit every map: the next best)
+                b = a;
+                rc = conv_pipe_dispatch(b, d->ksize, d->stride, d->dtype, conv_auto_algo(a, d->ksize, d->stride, d->dtype, false), st, nm);
             }
             if (rc != YOLO_EUNSUPPORTED) return rc;
         }
