@@ -30,6 +30,7 @@ struct ConvArgs {
     char* y;
     int N, H, W, Cin, Ho, Wo, Cout, Cout_pad;
     int TWt, nstrips, tiles_per_strip, PW, total_i;
+    int row_swz, TP;            // conv_pipe 3x3 stride 1: halo pitch TWt + 4 and a row-relative unit swizzle (see launch_pipe); TP = PW - 4 * row_swz
     int halo_strict;        // conv_pipe.hip launch_pipe: leave one slot of the staged halo unused (the 2x2-window 4-wave tile)
     int tile_px;            // conv_igemm.hip: strip pixels a tile covers (= its 128 unless the shape needs row-limited tiles); 0 elsewhere
     int nchunks, tiles_c;
@@ -75,13 +76,13 @@ struct NameOut { char* buf; int len; int* stats_rows; };     // stats_rows: rece
 // Worst-case number of LDS slots of the zero-padded input halo tile for a BP-pixel output tile on
 // strips of width d (stride S; KS = 3: 3x3, pad 1; KS = 2: 2x2 window anchored at the output pixel, zero row / column
 // after the last).
-static inline int conv_halo_slots(int BP, int d, int Ho, int H, int S, long long total_rows, int KS = 3) {
+static inline int conv_halo_slots(int BP, int d, int Ho, int H, int S, long long total_rows, int KS = 3, int pitch_extra = 0) {
     long long nro = (BP - 1 + d - 1) / d + 1;
     if (nro > total_rows) nro = total_rows;
     const long long nb = (nro - 1 + Ho - 1) / Ho;
     const int extra = H + 1 - Ho * S;
     const long long NR = (long long)S * (nro - 1) + KS + nb * (extra > 0 ? extra : 0);
-    const int PW = (d - 1) * S + KS;
+    const int PW = (d - 1) * S + KS + pitch_extra;
     return (int)(NR * PW);
 }
 

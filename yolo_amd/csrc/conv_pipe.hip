@@ -255,20 +255,22 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         const int slot = (S == 2) ? ((pos & ~7) | ((pos & 3) << 1) | ((pos >> 2) & 1)) : pos;
         bool valid;
         long long off;
+        int swz = (S == 2 ? pos >> 3 : pos >> 2);
         if constexpr (KS != 1) {
             const int rr = fdiv(slot, a.d_PW), cc = slot - rr * PW;
+            if constexpr (S == 1) swz -= rr * a.row_swz;         // (row-relative swizzle: launch_pipe)
             const int Rr = Rin_lo + rr;
             const int n = fdiv(Rr, a.d_H1);
             const int yy = Rr - n * (H + 1) - PAD;
             const int xx = x0 + cc;
-            valid = slot < HS && yy >= 0 && yy < H && n < a.N && xx >= 0 && xx < W;
+            valid = slot < HS && yy >= 0 && yy < H && n < a.N && xx >= 0 && xx < W && cc < (TWt - 1) * S + KS;      // (cc beyond: pitch padding)
             off = ((long long)(n * H + yy) * W + xx) * row_bytes;
         } else {
             const int i = i0 + slot;
             valid = i < a.total_i;
             off = (long long)i * row_bytes;
         }
-        const int lp = (part ^ ((S == 2 ? pos >> 3 : pos >> 2) & 3)) * 16;
+        const int lp = (part ^ (swz & 3)) * 16;
         xo[j] = valid ? (unsigned)(off + lp) : 0xffffffffu;
     }
     if constexpr (KS != 1) {
@@ -287,7 +289,11 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         }
     }
     // ---- per-lane MFMA operand bases ------------------------------------------------------------
-    int slot00[NI];
+    // RSW (3x3 stride 1): t00 = slot00 - 4 * row_swz * (halo row) -- the index the unit swizzle is taken from; a tap moves it by
+    // dy * TP + dx where the slot moves by dy * PW + dx
+    constexpr bool RSW = KS == 3 && S == 1;
+    const int TP = a.TP;
+    int slot00[NI], t00[RSW ? NI : 1];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int i = i0 + (wave_p * NI + ni) * 32 + l31;
@@ -296,7 +302,9 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
             const int r = fdiv(ii, a.d_TWt);
             const int tx = ii - r * TWt;
             const int n = fdiv(r, a.d_Ho);
-            slot00[ni] = (n * (H + 1) + (r - n * Ho) * S - Rin_lo) * PW + tx * S;
+            const int hrow = n * (H + 1) + (r - n * Ho) * S - Rin_lo;
+            slot00[ni] = hrow * PW + tx * S;
+            if constexpr (RSW) t00[ni] = hrow * TP + tx;
         } else {
             slot00[ni] = ii - i0;
         }
@@ -337,7 +345,10 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         int bx[NI];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-            const int slot = (KS != 1) ? slot00[ni] + (q / KS) * PW + (q % KS) : slot00[ni];
+            int slot = (KS != 1) ? slot00[ni] + (q / KS) * PW + (q % KS) : slot00[ni];
+#ifdef YOLO_LAB
+            if (KS == 3 && (a.lab & 256)) slot = (wave_p * NI + ni) * 32 + l31 + q;      // (lab probe, WRONG results: consecutive slots = conflict-free fragment reads)
+#endif
             if constexpr (S == 2) {
                 // stride 2: the 32 pixels of a fragment are every other slot.  Inside each group of 8 slots the even ones
                 // sit in the first 256 bytes and the odd ones in the second, so that 16 lanes still cover four whole
@@ -345,6 +356,12 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
                 // every input fragment read, which bound these kernels); the unit swizzle follows the group index
                 const int pos = (slot & ~7) | ((slot & 1) << 2) | ((slot >> 1) & 3);
                 bx[ni] = pos * 64 + ((h ^ ((slot >> 3) & 3)) << 4);
+            } else if constexpr (RSW) {
+                int t = t00[ni] + (q / KS) * TP + (q % KS);
+#ifdef YOLO_LAB
+                if (a.lab & 256) t = slot;
+#endif
+                bx[ni] = slot * 64 + ((h ^ ((t >> 2) & 3)) << 4);
             } else {
                 bx[ni] = slot * 64 + ((h ^ ((slot >> 2) & 3)) << 4);
             }
@@ -489,7 +506,8 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const int slot = slot00[ni] + (q / KS) * PW + (q % KS);
-                const int bxn = slot * 64 + ((h ^ ((slot >> 2) & 3)) << 4);
+                const int t = t00[ni] + (q / KS) * TP + (q % KS);
+                const int bxn = slot * 64 + ((h ^ ((t >> 2) & 3)) << 4);
                 fb[B][ni] = *(const uint4*)(Xl + (bxn ^ (ks * 32)));
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -734,20 +752,33 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     constexpr int BP = WAVES_P * NI * 32, BC = WAVES_C * MI * 32;
     if (KC > 1 && (a.nchunks % KC || a.nchunks < 2 * KC)) return YOLO_EUNSUPPORTED;
     if (LEAN && a.nchunks / KC < 4) return YOLO_EUNSUPPORTED;       // the lean loop starts after a full ring of phases
+    a.row_swz = 0;
     if (KS != 1) {
+        // 3x3 stride 1: halo rows of pitch TWt + 4 instead of TWt + 2 where that fits the buffer.  A 32-pixel input fragment
+        // crosses strip rows, and ds_read_b128 is served in 16-lane groups ({0-3, 12-15, 20-27}, ...) that are conflict-free when
+        // their 16 (slot % 4, 16-byte unit) pairs differ: with pitch = TWt (mod 4) and the unit swizzle ((slot >> 2) - halo row) & 3
+        // that pair is the pixel's index in the strip (row * TWt + column) mod 16 for every tap -- 16 different values in every
+        // group.  With pitch TWt + 2 and swizzle (slot >> 2) & 3 each row crossing shifts it by 2: SQ_LDS_BANK_CONFLICT was 36 % of
+        // the LDS-active cycles of these kernels; a lab probe with conflict-free (wrong) addresses ran them 2-5 % faster
+        // (tools/ab_bank.sh).
         int best = -1, best_hs = 1 << 30;
-        for (int d = 1; d <= a.Wo; ++d) {
-            if (a.Wo % d) continue;
-            const int hs = conv_halo_slots(BP, d, a.Ho, a.H, S, (long long)a.N * a.Ho, KS);
-            if (hs <= XSLOTS - (a.halo_strict ? 1 : 0) && hs <= best_hs) { best = d; best_hs = hs; }
+        static const int rsw_off = (int)YOLO_LAB_ENV("YOLO_NO_ROW_SWZ", 0);       // (lab A/B: the round-4 layout)
+        for (int pad = (KS == 3 && S == 1 && !rsw_off) ? 2 : 0; pad >= 0 && best < 0; pad -= 2) {
+            for (int d = 1; d <= a.Wo; ++d) {
+                if (a.Wo % d) continue;
+                const int hs = conv_halo_slots(BP, d, a.Ho, a.H, S, (long long)a.N * a.Ho, KS, pad);
+                if (hs <= XSLOTS - (a.halo_strict ? 1 : 0) && hs <= best_hs) { best = d; best_hs = hs; }
+            }
+            if (best >= 0) a.row_swz = pad / 2;
         }
         if (best < 0) return YOLO_EUNSUPPORTED;
         a.TWt = best;
-        a.PW = (best - 1) * S + KS;
+        a.PW = (best - 1) * S + KS + 2 * a.row_swz;
     } else {
         a.TWt = a.Wo;
         a.PW = a.Wo;
     }
+    a.TP = a.PW - 4 * a.row_swz;
     a.nstrips = a.Wo / a.TWt;
     const long long tot = (long long)a.N * a.Ho * a.TWt;
     if (tot > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
@@ -853,7 +884,7 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
             case 4: return launch_pipe<T, 3, 2, 2, 2, 2, 256>(a, st, nm);
             case 6: return launch_pipe<T, 3, 2, 4, 2, 3, 384>(a, st, nm);
             case 7: return launch_pipe<T, 3, 2, 4, 1, 3, 384>(a, st, nm);
-            case 8: return launch_pipe<T, 3, 2, 2, 2, 3, 320>(a, st, nm);
+            case 8: return launch_pipe<T, 3, 2, 2, 2, 3, 384>(a, st, nm);      // (384 slots = 80 KB with the 4-slot ring: still two blocks per CU; room for the padded pitch on 13-wide strips)
 #endif
 #if YOLO_PIPE_PART == 0
             default: return conv_pipe_dispatch_f(a, algo, st, nm);
