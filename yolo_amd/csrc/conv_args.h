@@ -30,13 +30,13 @@ struct ConvArgs {
     char* y;
     int N, H, W, Cin, Ho, Wo, Cout, Cout_pad;
     int TWt, nstrips, tiles_per_strip, PW, total_i;
-    int row_swz, TP;            // conv_pipe 3x3 stride 1: halo pitch TWt + 4 and a row-relative unit swizzle (see launch_pipe); TP = PW - 4 * row_swz
+    int row_swz, TP;            // conv_pipe 3x3 stride 1: halo pitch TWt + 4 and a row-relative unit swizzle (see launch_pipe); TP = PW - 4 * row_swz (stride 2: (PW - TWt) / 4)
     int halo_strict;        // conv_pipe.hip launch_pipe: leave one slot of the staged halo unused (the 2x2-window 4-wave tile)
     int tile_px;            // conv_igemm.hip: strip pixels a tile covers (= its 128 unless the shape needs row-limited tiles); 0 elsewhere
     int nchunks, tiles_c;
     int buf32;              // conv_epilogue.h: 1 = y, the residual (and stats_y, tail_y) extents fit 31-bit byte offsets: the epilogue's
                             // loads / stores are unconditional buffer accesses (out-of-range offset = no access)
-    int lab;                // lab build only (YOLO_EPI_AB): epilogue ablation bits -- 1 drop the stores, 2 drop the residual loads, 4 skip the epilogue, 8 no scale / bias loads, 16 no LDS transpose; K-loop probes (wrong results): 32 every second barrier dropped, 64 no weight DMAs, 128 no input DMAs
+    int lab;                // lab build only (YOLO_EPI_AB): epilogue ablation bits -- 1 drop the stores, 2 drop the residual loads, 4 skip the epilogue, 8 no scale / bias loads, 16 no LDS transpose; K-loop probes (wrong results): 32 every second barrier dropped, 64 no weight DMAs, 128 no input DMAs, 256 3x3 input fragments from consecutive slots (no bank conflicts)
     int vblocks;            // conv_pipe.hip: number of (pixel tile, cout tile) units = the grid size unless the blocks are persistent
     int out_f32;
     int x_ps;       // elements between input pixels (>= Cin: x may be a channel slice of a wider NHWC buffer)

@@ -259,6 +259,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         if constexpr (KS != 1) {
             const int rr = fdiv(slot, a.d_PW), cc = slot - rr * PW;
             if constexpr (S == 1) swz -= rr * a.row_swz;         // (row-relative swizzle: launch_pipe)
+            else swz -= (rr >> 1) * a.TP;                        // (stride 2: TP = (PW - TWt) / 4 per OUTPUT row, or 0)
             const int Rr = Rin_lo + rr;
             const int n = fdiv(Rr, a.d_H1);
             const int yy = Rr - n * (H + 1) - PAD;
@@ -291,9 +292,11 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     // ---- per-lane MFMA operand bases ------------------------------------------------------------
     // RSW (3x3 stride 1): t00 = slot00 - 4 * row_swz * (halo row) -- the index the unit swizzle is taken from; a tap moves it by
     // dy * TP + dx where the slot moves by dy * PW + dx
-    constexpr bool RSW = KS == 3 && S == 1;
+    // RS2 (3x3 stride 2): t00 = the lane's halo row; the swizzle subtracts TP = (PW - TWt) / 4 per output row (launch_pipe)
+    constexpr bool RSW = KS != 1 && S == 1;
+    constexpr bool RS2 = KS == 3 && S == 2;
     const int TP = a.TP;
-    int slot00[NI], t00[RSW ? NI : 1];
+    int slot00[NI], t00[(RSW || RS2) ? NI : 1];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int i = i0 + (wave_p * NI + ni) * 32 + l31;
@@ -305,6 +308,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
             const int hrow = n * (H + 1) + (r - n * Ho) * S - Rin_lo;
             slot00[ni] = hrow * PW + tx * S;
             if constexpr (RSW) t00[ni] = hrow * TP + tx;
+            if constexpr (RS2) t00[ni] = hrow;
         } else {
             slot00[ni] = ii - i0;
         }
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
                 // 256-byte lines (with the slots in pixel order they would touch half the banks: two-way conflicts on
                 // every input fragment read, which bound these kernels); the unit swizzle follows the group index
                 const int pos = (slot & ~7) | ((slot & 1) << 2) | ((slot >> 1) & 3);
-                bx[ni] = pos * 64 + ((h ^ ((slot >> 3) & 3)) << 4);
+                bx[ni] = pos * 64 + ((h ^ (((slot >> 3) - ((t00[ni] + q / KS) >> 1) * TP) & 3)) << 4);
             } else if constexpr (RSW) {
                 int t = t00[ni] + (q / KS) * TP + (q % KS);
 #ifdef YOLO_LAB
@@ -763,22 +767,27 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
         // (tools/ab_bank.sh).
         int best = -1, best_hs = 1 << 30;
         static const int rsw_off = (int)YOLO_LAB_ENV("YOLO_NO_ROW_SWZ", 0);       // (lab A/B: the round-4 layout)
-        for (int pad = (KS == 3 && S == 1 && !rsw_off) ? 2 : 0; pad >= 0 && best < 0; pad -= 2) {
+        // The 2x2 window (stride-2 data gradient) likewise with TWt + 4 for TWt + 1.  Stride 2: a fragment's lanes are same-parity
+        // slots 2 apart (the 8-slot permutation keeps them on whole 256-byte lines) and an output row is 2 halo rows: pitch = TWt
+        // (mod 4) -- 0-3 slots more than 2 TWt + 1 -- and the swizzle ((slot >> 3) - (halo row >> 1) * (PW - TWt) / 4) & 3.
+        int best_pad = 0;
+        for (int pass = rsw_off ? 1 : 0; pass < 2 && best < 0; ++pass) {
             for (int d = 1; d <= a.Wo; ++d) {
                 if (a.Wo % d) continue;
+                const int pad = pass ? 0 : (S == 1 ? 4 - (KS - 1) : (4 - ((d + 1) & 3)) & 3);
                 const int hs = conv_halo_slots(BP, d, a.Ho, a.H, S, (long long)a.N * a.Ho, KS, pad);
-                if (hs <= XSLOTS - (a.halo_strict ? 1 : 0) && hs <= best_hs) { best = d; best_hs = hs; }
+                if (hs <= XSLOTS - (a.halo_strict ? 1 : 0) && hs <= best_hs) { best = d; best_hs = hs; best_pad = pad; }
             }
-            if (best >= 0) a.row_swz = pad / 2;
+            if (best >= 0) a.row_swz = pass ? 0 : 1;
         }
         if (best < 0) return YOLO_EUNSUPPORTED;
         a.TWt = best;
-        a.PW = (best - 1) * S + KS + 2 * a.row_swz;
+        a.PW = (best - 1) * S + KS + best_pad;
     } else {
         a.TWt = a.Wo;
         a.PW = a.Wo;
     }
-    a.TP = a.PW - 4 * a.row_swz;
+    a.TP = S == 1 ? a.PW - 4 * a.row_swz : (a.row_swz ? (a.PW - a.TWt) / 4 : 0);
     a.nstrips = a.Wo / a.TWt;
     const long long tot = (long long)a.N * a.Ho * a.TWt;
     if (tot > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
