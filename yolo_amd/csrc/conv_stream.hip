@@ -41,6 +41,10 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
     constexpr int XW = (TW - 1) * S + KS;
     constexpr int INUSE = KS, NEW = S, RING = INUSE + NEW;
     constexpr int XROW = XW * PITCH;
+    // stride 2: a ring row holds its even pixels first, then the odd ones -- the fragment reads (every other pixel) then have a lane
+    // stride of PITCH, an odd number of 16-byte units, instead of 2 * PITCH (two-way bank conflicts; stem_down.hip)
+    constexpr int XHALF = (XW + 1) / 2;
+    auto pxoff = [](int px) { return S == 2 ? ((px & 1) * XHALF + (px >> 1)) * PITCH : px * PITCH; };
     constexpr int XU = (NEW * XW * PARTS + 255) / 256;
     constexpr int SCR = 32 * 144;                        // per-wave epilogue scratch: 32 pixel rows x (32 f32 + pad)
     __shared__ __attribute__((aligned(16))) char smem[RING * XROW + 4 * SCR];
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
             if (r < NEW) {
                 int slot = slot_first + r;
                 if (slot >= RING) slot -= RING;
-                *(uint4*)(xl + slot * XROW + px * PITCH + part * 16) = xr[SET][j];
+                *(uint4*)(xl + slot * XROW + pxoff(px) + part * 16) = xr[SET][j];
             }
         }
     };
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
     load_x(Set1{}, oy0 * S - PAD + INUSE);              // the rows step oy0 stores at its bottom
     __syncthreads();
 
-    const int b_off = (wave_p * NI * 32 + l31) * S * PITCH + h * 16;
+    const int b_off = (wave_p * NI * 32 + l31) * PITCH + h * 16;        // (stride 2: pixel 2 j + kw = half kw & 1, index j + (kw >> 1))
     int slot0 = 0;
     // step k = output row oy; its parity names the set that is free at its top (it receives the rows of step k + 2); the
     // other set holds the rows step k stores at its bottom
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StreamArgs a) {
                 for (int kc = 0; kc < KC; ++kc) {
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
-                        const uint4 bf = *(const uint4*)(rowp + (ni * 32 * S + kw) * PITCH + kc * 32);
+                        const uint4 bf = *(const uint4*)(rowp + (S == 2 ? ni * 32 * PITCH + pxoff(kw) : (ni * 32 + kw) * PITCH) + kc * 32);
                         acc[ni] = mfma16<T>(A[(kh * KS + kw) * KC + kc], bf, acc[ni]);
                     }
                 }

@@ -24,6 +24,10 @@ constexpr int SW_MAX = 62;
 constexpr int XW = 129;                  // stem ring row capacity (pixel 128 is only read by discarded lanes)
 constexpr int PITCH = C1 * 2 + 16;       // bytes per stem pixel in the ring (+16: conflict-free 16-byte reads)
 constexpr int XROW = XW * PITCH;
+// A ring row holds its even pixels first, then the odd ones (pixel p at ((p & 1) * XHALF + (p >> 1)) * PITCH): the stride-2 down conv
+// reads every other pixel, and at a lane stride of 2 * PITCH = 160 bytes a 16-lane ds_read_b128 group covers only 8 of the 16 bank
+// quads (two-way conflicts on every fragment read: SQ_LDS_BANK_CONFLICT was 34 % of the LDS-active cycles); at PITCH it covers all 16.
+constexpr int XHALF = (XW + 1) / 2;
 constexpr int RING = 5;                  // 3 stem rows in use + 2 being produced
 constexpr int IPW = 136;                 // image window row pitch in pixels (8 B each: NHWC4 bf16)
 constexpr int IROWS = 8;                 // image window rows (4 in use + 2 arriving, power of two)
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256) void stem_down_kernel(Args a) {
         const int px = pxg * 32 + l31;
         const int sx = sx0 + px;
         const bool inside = sy >= 0 && sy < H && sx >= 0 && sx < W;
-        char* dst = xl + slot * XROW + px * PITCH;
+        char* dst = xl + slot * XROW + ((px & 1) * XHALF + (px >> 1)) * PITCH;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int co = 8 * g + 4 * h;
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256) void stem_down_kernel(Args a) {
     for (int r = 0; r < 3; ++r) stem_group(2 * oy0 - 1 + r, r, wave);
     __syncthreads();
 
-    const int b_off = (wave_p * 32 + l31) * 2 * PITCH + h * 16;
+    const int b_off = (wave_p * 32 + l31) * PITCH + h * 16;          // (pixel 2 j + kw: half kw & 1, index j + (kw >> 1))
     int slot0 = 0;
     // image rows 2oy+5, 2oy+6 are used by step oy+1's stem rows and stored at the bottom of step oy; they are requested TWO
     // steps ahead (top of step oy-1) into one of two register sets, unconditionally (clamped addresses: always readable) --
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256) void stem_down_kernel(Args a) {
             for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc) {
-                    const uint4 bf = *(const uint4*)(rowp + kw * PITCH + kc * 32);
+                    const uint4 bf = *(const uint4*)(rowp + ((kw & 1) * XHALF + (kw >> 1)) * PITCH + kc * 32);
                     acc = mfma16<T>(A[(kh * 3 + kw) * 2 + kc], bf, acc);
                 }
         }
