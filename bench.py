@@ -763,10 +763,12 @@ def main():
             net16.load_tuning_state(args.plan_state)
         net16.prepare()
         k16 = max(args.steps, 10)
-        el16 = timed_pass(net16, det, x32, 'top1_blocking', k16, 3, fence)[0]
+        # (two passes, the faster one: one refresh of round 5 saw this pass alone at 7.5 ms per step between two runs at 4.2)
+        el16s = [timed_pass(net16, det, x32, 'top1_blocking', k16, 3, fence)[0] for _ in range(2)]
+        el16 = min(el16s)
         v16 = B * k16 / el16
         out['f16_path'] = {'workload': "the headline workload with dtype='f16' (the reference's use_fp16)", 'value': round(v16, 2), 'unit': 'images/s',
-                           'steps': k16, 'ms_per_step': round(el16 / k16 * 1e3, 4),
+                           'steps': k16, 'ms_per_step': round(el16 / k16 * 1e3, 4), 'passes_ms_per_step': [round(e / k16 * 1e3, 4) for e in el16s],
                            'net_tflops': round(net16.graph.flops(*size) * v16 / 1e12, 1),
                            'frac_of_peak': round(net16.graph.flops(*size) * v16 / 1e12 / MFMA_PEAK_TFLOPS['f16'], 4)}
         net = net16
