@@ -138,6 +138,25 @@ def test_conv_pipe(lib, cuda, case, dtype, algo):
         assert np.mean(np.abs(y - ref) > 1e-3 * (1 + np.abs(ref))) < 0.02
 
 
+# prime widths (one strip as wide as the map, or refusal): the tiles whose conflict-free halo (pitch TWt + 4, conv_pipe.hip
+# launch_pipe) does not fit their buffer fall back to the plain pitch TWt + 2, others take the padded one; images of 9 / 21 rows put
+# fragments across image boundaries in both layouts
+LAYOUT_CASES = [(2, 64, 9, 31, 128, 3, 1, True), (3, 32, 21, 37, 64, 3, 1, False), (2, 64, 5, 43, 128, 3, 1, True), (1, 128, 30, 47, 64, 3, 1, False)]
+
+
+@pytest.mark.parametrize('case,dtype,algo', eligible_pairs(LAYOUT_CASES, ['f32', 'bf16'], [2, 3, 4, 5, 6, 7, 8, 11, 26, 27, 28]))
+def test_conv_pipe_halo_layouts(lib, cuda, case, dtype, algo):
+    x, w, scale, bias, r = _mk(case, 14)
+    y = run_conv(lib, cuda, x, w, scale, bias, 1, 0.1, dtype, residual=r, algo=algo, expect_rc=0)
+    ref = ref_conv(x, w, scale, bias, 1, 0.1, residual=r, bf16=dtype == 'bf16')
+    assert not np.isnan(y).any()
+    if dtype == 'f32':
+        np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-4)
+    else:
+        np.testing.assert_allclose(y, ref, rtol=1.6e-2, atol=2e-2)
+        assert np.mean(np.abs(y - ref) > 1e-3 * (1 + np.abs(ref))) < 0.02
+
+
 def test_conv_pipe_rejects_ineligible(lib, cuda):
     """A pinned pipelined algo on a shape it cannot run must fail loudly, not fall back."""
     case = (2, 16, 16, 24, 32, 3, 2, False)          # stride 2
@@ -150,6 +169,7 @@ S2_CASES = [
     (4, 128, 52, 52, 256, 3, 2, False),     # -> 26x26, tiles crossing images
     (3, 64, 38, 38, 96, 3, 2, False),       # 608 family -> 19x19, ragged Cout
     (2, 128, 16, 40, 64, 3, 2, False),
+    (2, 64, 22, 58, 128, 3, 2, False),      # -> 11x29 (a prime width: the padded pitch of the conflict-free layout or the plain one)
 ]
 
 
