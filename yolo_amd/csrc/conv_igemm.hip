@@ -102,17 +102,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     for (int j = 0; j < XP; ++j) {
         const int u = tid + j * 256;
         if constexpr (KS == 3) {
-            const int slot = u >> 2, part = u & 3;
+            // (stride 1: the conflict-free halo layout of conv_pipe.hip launch_pipe -- pitch TWt + 4, unit swizzle ((slot >> 2) - halo
+            //  row) & 3; a.row_swz == 0: the plain pitch and the slot swizzle.  Stride 2 keeps the plain layout: its instantiation sits at 256 registers, and the
+            //  address terms of conv_pipe's stride-2 layout took it to 268 = one wave per SIMD: the 64 -> 128 layer 157 us instead of 113)
+            const int pos = u >> 2, part = u & 3;
+            const int slot = pos;
             bool valid = slot < HS && u < X_UNITS;
             const int rr = slot / PW;
             const int cc = slot - rr * PW;
+            if constexpr (S == 1) valid = valid && cc < TWt + 2;          // (beyond: the pitch padding)
             const int Rr = Rin_lo + rr;
             const int n = Rr / (H + 1);
             const int yy = Rr - n * (H + 1) - 1;
             const int xx = x0 + cc;
             valid = valid && yy >= 0 && n < a.N && xx >= 0 && xx < W;
             xoff[j] = valid ? ((long long)(n * H + yy) * W + xx) * row_pitch : -1;
-            xlp[j] = (part ^ ((slot >> 2) & 3)) * 16;
+            xlp[j] = (part ^ (((pos >> 2) - (S == 1 ? rr * a.row_swz : 0)) & 3)) * 16;
         } else {
             const int plane = u / (XSLOTS * 4);
             const int rem = u - plane * (XSLOTS * 4);
@@ -139,11 +144,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             if (strip * TWt + tx >= Wo) ok = false;            // (a ragged last strip: launch_cfg's fallback for widths no strip divides)
             n = r / Ho;
             const int oy = r - n * Ho;
-            const int slot00 = (n * (H + 1) + oy * S - Rin_lo) * PW + tx * S;
+            const int hrow = n * (H + 1) + oy * S - Rin_lo;
+            const int slot00 = hrow * PW + tx * S;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int slot = slot00 + (t / 3) * PW + (t % 3);
-                addrX[ni][t] = slot * 64 + ((h ^ ((slot >> 2) & 3)) << 4);
+                if constexpr (S == 1) addrX[ni][t] = slot * 64 + ((h ^ (((slot >> 2) - (hrow + t / 3) * a.row_swz) & 3)) << 4);
+                else addrX[ni][t] = slot * 64 + ((h ^ ((slot >> 2) & 3)) << 4);
             }
             pix = oy * Wo + strip * TWt + tx;
             if (a.up2) pix = oy * 4 * Wo + 2 * (strip * TWt + tx);
@@ -259,12 +266,19 @@ constexpr int XSLOTS_S2 = 832;
 template <typename T, int KS, int S, int WAVES_P, int WAVES_C, int MI, int NI, int XSLOTS, int TS>
 static int launch_cfg(ConvArgs& a, hipStream_t st, const NameOut* name) {
     constexpr int BP = WAVES_P * NI * 32, BC = WAVES_C * MI * 32;
+    a.row_swz = 0;
+    a.TP = 0;
     if (KS == 3) {
-        int best = -1, best_hs = 1 << 30;
-        for (int d = 1; d <= a.Wo; ++d) {
-            if (a.Wo % d) continue;
-            const int hs = conv_halo_slots(BP, d, a.Ho, a.H, S, (long long)a.N * a.Ho);
-            if (hs <= XSLOTS && hs <= best_hs) { best = d; best_hs = hs; }
+        int best = -1, best_hs = 1 << 30, best_pad = 0;
+        static const int rsw_off = (int)YOLO_LAB_ENV("YOLO_NO_ROW_SWZ", 0);       // (lab A/B)
+        for (int pass = (rsw_off || S == 2) ? 1 : 0; pass < 2 && best < 0; ++pass) {        // (the padded pitch of the conflict-free layout where it fits, else the plain one)
+            for (int d = 1; d <= a.Wo; ++d) {
+                if (a.Wo % d) continue;
+                const int pad = pass ? 0 : 2;
+                const int hs = conv_halo_slots(BP, d, a.Ho, a.H, S, (long long)a.N * a.Ho, 3, pad);
+                if (hs <= XSLOTS && hs <= best_hs) { best = d; best_hs = hs; best_pad = pad; }
+            }
+            if (best >= 0) a.row_swz = pass ? 0 : 1;
         }
         a.tile_px = BP;
         if (best < 0) {
@@ -281,7 +295,7 @@ static int launch_cfg(ConvArgs& a, hipStream_t st, const NameOut* name) {
             if (best < 0) return YOLO_EUNSUPPORTED;
         }
         a.TWt = best;
-        a.PW = (best - 1) * S + 3;
+        a.PW = (best - 1) * S + 3 + (a.row_swz ? best_pad : 0);
     } else {
         a.TWt = a.Wo;
         a.PW = a.Wo;
