@@ -185,7 +185,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     const int strip = fdiv(tile_p, a.d_tps);
     const int i0 = (tile_p - strip * a.tiles_per_strip) * BP;
     const int co0 = tile_c * BC;
-    const int H = a.H, W = a.W, Ho = a.Ho, Wo = a.Wo, TWt = a.TWt, PW = a.PW;
+    const int H = a.H, W = a.W, Ho = a.Ho, TWt = a.TWt, PW = a.PW;
     const int row_bytes = a.x_ps * (int)sizeof(T);          // pitch of an input pixel
 
     int Rin_lo = 0, HS = XSLOTS, x0 = 0;
