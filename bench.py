@@ -117,7 +117,7 @@ class Telemetry(object):
                 'telemetry_source': self.source}
 
 
-def cpu_baseline(size, seconds=6.0, batch=8, dev=None):
+def cpu_baseline(size, seconds=6.0, batch=8, dev=None, plan_state=None, plan_batch=None):
     """Oracle forward + numpy decode/top-1 on the host cores: images/s on a bounded sample.  oneDNN does not scale to
     every hardware thread of a big host (SMT siblings, NUMA), so the sample is run at a few thread counts (all
     hardware threads, half, a quarter) and the BEST is reported with its count.
@@ -173,11 +173,18 @@ def cpu_baseline(size, seconds=6.0, batch=8, dev=None):
         det = Detector(spec, size, steps, device=dev)
         parity = {'sample': 'images 0-1 of the cpu_baseline sample (D53 spec, identity BN, Xavier weights seed 0), decoded rows vs the fp32 oracle',
                   'measure': 'max / RMS of |a - b| / (1 + |b|) over [l,t,r,b] of all %d boxes' % ref_rows.shape[1]}
+        # (round 6) the checked nets launch the COMMITTED PLAN's kernels -- the set the headline is made of -- at the plan's batch
+        # (the two images repeated: eval-mode images are independent); without a plan the variants are measured on this box
+        rep = max(1, (plan_batch or 2) // 2)
+        parity['kernels'] = 'committed plan, batch %d (images 0-1 repeated)' % (2 * rep) if plan_state is not None else 'measured on this box'
         for dt in ('f32', 'f16', 'bf16'):
-            net = CarNet(spec, dtype=dt, device=dev).load_params(P)
-            outs = net(x[:2].to(dev))
-            rows = det.decode(outs).cpu().numpy()
+            net = CarNet(spec, dtype=dt, device=dev, tune='measure').load_params(P)
+            if plan_state is not None:
+                net.load_tuning_state(plan_state)
+            outs = net(x[:2].to(dev).repeat(rep, 1, 1, 1))
+            rows = det.decode(outs).cpu().numpy()[:2]
             _, idx = det.predict_device(outs)
+            idx = idx[:2]
             e = (rows[..., 1:5].astype(np.float64) - ref_rows[..., 1:5]) / (1.0 + np.abs(ref_rows[..., 1:5]))
             parity[dt] = {'box_max': float(np.abs(e).max()), 'box_rms': float(np.sqrt(np.mean(e * e))),
                           'score_max': float(np.abs(rows[..., 0] - ref_rows[..., 0]).max()),
@@ -661,6 +668,7 @@ def main():
     if shared:
         out['shared_gpu_test'] = 'TEST ONLY: %d ranks share %d GPU(s) over gloo -- not an N-GPU measurement' % (world, torch.cuda.device_count())
     out['plan'] = plan_report(args, net.tuning_state())
+    out['plan']['stale'] = net.stale_choices     # (plan entries this library build refused: dropped, measured live)
     out['net_tflops'] = round(net.graph.flops(*size) * value / 1e12 / world, 1)          # per GPU
     out['net_frac'] = round(out['net_tflops'] / MFMA_PEAK_TFLOPS[args.dtype], 4)           # whole pass vs the dense MFMA peak
     out['net_frac_median'] = round(net.graph.flops(*size) * out['value_median'] / 1e12 / world / MFMA_PEAK_TFLOPS[args.dtype], 4)
@@ -835,7 +843,7 @@ def main():
             if dog is not None:
                 dog.cancel()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(size, dev=dev)
+        out['cpu_baseline'] = cpu_baseline(size, dev=dev, plan_state=args.plan_state, plan_batch=B)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

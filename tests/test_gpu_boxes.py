@@ -16,6 +16,7 @@ import pytest
 import torch
 
 from oracle import graph as og, forward as of, detect as od
+from util import KERNEL_SETS, pin_kernels, assert_plan_held
 
 pytestmark = pytest.mark.gpu
 
@@ -51,7 +52,9 @@ def _record(key, st):
     print('box error %s: %s' % (key, json.dumps(st)))
 
 
-def _run(cuda, dtype, size, B, sel, seed):
+def _run(cuda, dtype, size, B, sel, seed, kernels='measured', rep=1):
+    """rep > 1: the B images repeated rep times (a, b, a, b, ...) -- the committed plan holds the shapes of 608x608 at bs 64, the
+    oracle cannot hold 64 different images of that size; eval-mode images are independent."""
     from yolo_amd.net import CarNet
     from yolo_amd.detect import Detector
     spec = og.spec_d53()
@@ -59,7 +62,9 @@ def _run(cuda, dtype, size, B, sel, seed):
     P = og.init_params(g, seed=0, bn='random')
     x = np.random.default_rng(seed).random((B, 3) + size, dtype=np.float32)
     net = CarNet(spec, dtype=dtype, device=cuda, tune='measure').load_params(P)
-    outs = net(torch.from_numpy(x).to(cuda))
+    pinned = pin_kernels(net, kernels)
+    outs = net(torch.from_numpy(x).to(cuda).repeat(rep, 1, 1, 1))
+    assert_plan_held(net, pinned, 'boxes_%dx%d_bs%d_%s' % (size[0], size[1], B * rep, dtype))
     steps = od.init_steps(spec['layers'], spec['all_anchors'])
     syxhw = od.init_syxhw(size, steps, spec['all_anchors'])
     det = Detector(spec, size, steps, device=cuda)
@@ -72,20 +77,25 @@ def _run(cuda, dtype, size, B, sel, seed):
     return _stats(rows, ref_rows, pred, ref_pred, idx, ref_idx)
 
 
+@pytest.mark.parametrize('kernels', KERNEL_SETS)
 @pytest.mark.parametrize('dtype', ['f32', 'f16', 'bf16'])
-def test_config1_box_error_vs_fp32_oracle(cuda, dtype):
-    st = _run(cuda, dtype, (416, 416), 32, [0, 1, 31], seed=7)
-    _record('configs1_416_bs32_%s' % dtype, st)
+def test_config1_box_error_vs_fp32_oracle(cuda, dtype, kernels):
+    st = _run(cuda, dtype, (416, 416), 32, [0, 1, 31], seed=7, kernels=kernels)
+    _record('configs1_416_bs32_%s%s' % (dtype, '' if kernels == 'measured' else '_plan'), st)
     assert np.isfinite(list(v for v in st.values())).all()
     assert st['box_ltrb_rms'] < SANITY_RMS[dtype], st
     if dtype == 'f32':
         assert st['box_ltrb_max'] <= 1e-3 and st['score_max'] <= 1e-3 and st['predict_row_max'] <= 1e-3 and st['top1_index_agreement'] == 1.0, st
 
 
+@pytest.mark.parametrize('kernels', KERNEL_SETS)
 @pytest.mark.parametrize('dtype', ['f32', 'f16', 'bf16'])
-def test_config4_box_error_vs_fp32_oracle(cuda, dtype):
-    st = _run(cuda, dtype, (608, 608), 2, [0, 1], seed=5)
-    _record('configs4_608_%s' % dtype, st)
+def test_config4_box_error_vs_fp32_oracle(cuda, dtype, kernels):
+    if kernels == 'plan' and dtype == 'f32':
+        pytest.skip('the committed plan holds no fp32 shapes at 608x608 (bench.py runs f32 at 416x416 bs 32 only)')
+    # ('plan': the plan's shapes are bs 64 -- the two images 32 times over)
+    st = _run(cuda, dtype, (608, 608), 2, [0, 1], seed=5, kernels=kernels, rep=32 if kernels == 'plan' else 1)
+    _record('configs4_608_%s%s' % (dtype, '' if kernels == 'measured' else '_plan'), st)
     assert st['box_ltrb_rms'] < SANITY_RMS[dtype], st
     if dtype == 'f32':
         assert st['box_ltrb_max'] <= 1e-3 and st['score_max'] <= 1e-3 and st['predict_row_max'] <= 1e-3 and st['top1_index_agreement'] == 1.0, st

@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import graph as og, forward as of, train as ot, detect as od
+from util import KERNEL_SETS, pin_kernels, assert_plan_held
 
 pytestmark = pytest.mark.gpu
 
@@ -292,7 +293,8 @@ def _taps_wgrad(x, dy, k, stride):
     return dw
 
 
-def test_d53_train_bs64_bf16_device_one_hop(cuda):
+@pytest.mark.parametrize('kernels', KERNEL_SETS)
+def test_d53_train_bs64_bf16_device_one_hop(cuda, kernels):
     """BASELINE configs[2] at its own size and arithmetic -- bs 64, bf16, measured kernel variants, 64 DIFFERENT images, half
     of them without an object -- held one hop at a time ON THE DEVICE (the CPU oracle cannot hold 64 images): for a spread of
     layers that covers every kernel family at its full-size launch (the fused-statistics forward convolutions, the split-pixel
@@ -302,6 +304,7 @@ def test_d53_train_bs64_bf16_device_one_hop(cuda):
     one-hop test: 2.5 bf16 ulps of the largest element for stored activations, 2e-3 for fp32 weight gradients."""
     from yolo_amd.spec import LEAKY_SLOPE
     spec, g, P, _, _, net, tr = _d53(cuda, 'bf16', 2, tune='measure')
+    pinned = pin_kernels(tr, kernels)              # ('plan': profiles/plan.json's forward / data-gradient / weight-gradient choices)
     B = 64
     x = torch.rand((B, 3) + SIZE, generator=torch.Generator().manual_seed(11)).to(cuda)
     lab = torch.from_numpy(ot.synthetic_labels(B, seed=5, render_rate=0.5, num_class=24)).to(cuda)
@@ -379,6 +382,7 @@ def test_d53_train_bs64_bf16_device_one_hop(cuda):
         note('dgrad s%d k%d' % (c.stride, c.k), cons, rel(cap[prod]['dz'].float(), rb(ref)), tol)
         del ref
     print('bs-64 device one-hop worst:', worst)
+    assert_plan_held(tr, pinned, 'train_416_bs64_bf16_one_hop')
 
 
 def test_d53_608_forward(cuda):
@@ -424,7 +428,8 @@ def test_d53_608_forward(cuda):
         assert e_hip < 1.5 * e_sim + 1e-3 and e_hip < 0.015, (e_hip, e_sim)
 
 
-def test_config4_608_bs64_measured_plan_replicated(cuda):
+@pytest.mark.parametrize('kernels', KERNEL_SETS)
+def test_config4_608_bs64_measured_plan_replicated(cuda, kernels):
     """The north-star shape as bench.py runs it (BASELINE configs[4] per GPU: D53 spec, 608x608, bs 64, bf16, measured kernel
     variants).  A size-independent property at the full size: eval-mode images are independent, so a batch that repeats two
     images must return each of them bit-identically wherever it sits in the batch (pixel tiles cross image boundaries at
@@ -436,7 +441,9 @@ def test_config4_608_bs64_measured_plan_replicated(cuda):
     two = np.random.default_rng(5).random((2, 3) + size, dtype=np.float32)
     x = torch.from_numpy(two).to(cuda).repeat(32, 1, 1, 1)                 # a, b, a, b, ...
     net = CarNet(spec, dtype='bf16', device=cuda, tune='measure').load_params(P)
+    pinned = pin_kernels(net, kernels)
     outs = [o.clone() for o in net(x)]
+    assert_plan_held(net, pinned, 'configs4_608_bs64_bf16')
     assert len({op[1].algo for op in net._last_plan.ops if op[0] == 'conv'}) > 3
     for o in outs:
         assert o.shape[0] == 64 and bool(torch.isfinite(o).all())
@@ -451,8 +458,9 @@ def test_config4_608_bs64_measured_plan_replicated(cuda):
         assert e_hip < 1.5 * e_sim + 1e-3 and e_hip < 0.015, (e_hip, e_sim)
 
 
+@pytest.mark.parametrize('kernels', KERNEL_SETS)
 @pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
-def test_config1_bs32_measured_plan(cuda, dtype):
+def test_config1_bs32_measured_plan(cuda, dtype, kernels):
     """BASELINE configs[1] as bench.py runs it: D53 spec, 416x416, bs 32, per-layer kernel variants pinned by
     measurement (tile quantisation is batch dependent: the bs-32 plan picks other variants than a B=2 plan).  Images
     0, 1 and 31 of the batch against the oracle (eval-mode BN: images are independent)."""
@@ -462,7 +470,9 @@ def test_config1_bs32_measured_plan(cuda, dtype):
     P = og.init_params(g, seed=0, bn='random')
     x = np.random.default_rng(7).random((32, 3) + SIZE, dtype=np.float32)
     net = CarNet(spec, dtype=dtype, device=cuda, tune='measure').load_params(P)
+    pinned = pin_kernels(net, kernels)
     outs = [o.cpu().numpy() for o in net(torch.from_numpy(x).to(cuda))]
+    assert_plan_held(net, pinned, 'configs1_416_bs32_%s' % dtype)
     assert len({op[1].algo for op in net._last_plan.ops if op[0] == 'conv'}) > 3       # a mix of pinned variants
     sel = [0, 1, 31]
     ref = [r.numpy() for r in of.forward_torch(g, P, x[sel])]

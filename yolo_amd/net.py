@@ -82,6 +82,7 @@ class CarNet(object):
         else:
             self.fuse_tail_note = None
         self._algo_cache = {}
+        self.stale_choices = 0      # adopted choices (plan file / rank 0) this library no longer takes: dropped and measured again
         # optional JSON file remembering measured choices (so a profiled run launches only the chosen kernels)
         self._tune_cache = tune_cache
         if tune_cache and os.path.exists(tune_cache):
@@ -404,9 +405,21 @@ class CarNet(object):
         if d.x_pixel_stride or d.upsample2x or (d.y_pixel_stride and not d.out_f32):
             key = key + (int(d.x_pixel_stride), int(d.upsample2x), int(d.y_pixel_stride))
         key = key + tuple(key_extra)
-        if key in self._algo_cache:
-            return self._algo_cache[key]
         lib, st = self._lib, L.stream_ptr()
+        if key in self._algo_cache:
+            # a choice adopted from a plan file / another rank: dry-run it (host only, no launch) -- a library built after the
+            # plan was made may no longer take that variant for the shape (a tile's halo budget changed, an id was retired); such
+            # an entry is dropped and the shape measured again, which plans.new_keys() then counts as measured live
+            cached = self._algo_cache[key]
+            if fn is None and cached != 1:
+                d.algo = cached
+                ok = lib.yolo_conv_kernel_name(C.byref(d), C.create_string_buffer(256), 256) == 0
+                d.algo = 0
+                if not ok:
+                    del self._algo_cache[key]
+                    self.stale_choices += 1
+            if key in self._algo_cache:
+                return cached
         fn = fn or lib.yolo_conv_fwd
 
         def time_algo(algo, n):

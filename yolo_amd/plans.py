@@ -60,11 +60,13 @@ def save(path, state, meta=None):
 
 
 def load(path):
-    """-> (state, meta).  Raises if the file's md5 does not match its contents (a hand-edited plan)."""
+    """-> (state, meta).  Raises if the file carries no md5 or it does not match its contents (a hand-edited plan)."""
     with open(path) as f:
         obj = json.load(f)
     state = from_json(obj['plan'])
     meta = obj.get('meta', {})
-    if meta.get('md5') and meta['md5'] != md5(state):
+    if not meta.get('md5'):
+        raise ValueError('%s: no meta.md5 (write plans with plans.save())' % path)
+    if meta['md5'] != md5(state):
         raise ValueError('%s: md5 %s does not match its contents (%s)' % (path, meta['md5'], md5(state)))
     return state, meta
