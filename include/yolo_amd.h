@@ -25,15 +25,25 @@ extern "C" {
                           yolo_gluon.py:204-214).  Inference entry points only (pack, fold, nchw<->nhwc, conv_fwd, stem, res_block); the
                           training entries take YOLO_F32 | YOLO_BF16 */
 
+/* SPLIT bf16 ("bf16x3", round 6): the path on which the north-star tolerance (decoded boxes within 1e-3 of the fp32 reference) and the
+ * bf16 MFMA rate meet.  A value v is stored as TWO bf16 numbers, hi = bf16(v) and lo = bf16(v - hi) (16 significant bits), and every
+ * product w * x of a convolution is taken as w_hi x_hi + w_hi x_lo + w_lo x_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+ * (three MFMAs per product; the exact-fp32 MFMA of YOLO_F32 is sixteen times slower than one).  Storage of an (N,H,W,C) activation:
+ * per pixel the C hi values, then -- `lo offset` elements further (dense: C) -- the C lo values: dense pixel stride 2 * C elements of
+ * 2 bytes.  Inference entry points only: yolo_packed_weight_bytes / yolo_pack_conv_weights (image [w_hi | w_hi | w_lo] over
+ * 3 * Cin / 32 K-chunks), yolo_conv_fwd (Cin % 32 == 0, pipelined kernels; no stats / tail), yolo_stem_conv_fwd.  Everything else
+ * returns YOLO_EUNSUPPORTED / YOLO_EINVAL for it. */
+#define YOLO_BF16X3 3
+
 #define YOLO_OK 0
 #define YOLO_EINVAL (-1)
 #define YOLO_EUNSUPPORTED (-2)
 
 /* ABI revision = the layout of every struct and the argument list of every entry below.  A caller compiled against another
  * revision must not call anything else: the library reads the WHOLE yolo_conv_desc on every call (revision 2 appended the
- * tail_* fields, revision 3 added YOLO_F16), so a shorter struct from an older header would be read past its end.
+ * tail_* fields, revision 3 added YOLO_F16, revision 4 YOLO_BF16X3 and the *_lo_offset fields), so a shorter struct from an older header would be read past its end.
  * yolo_amd/lib.py:load() refuses a library whose yolo_version() differs from the YOLO_ABI_VERSION it was written against. */
-#define YOLO_ABI_VERSION 3
+#define YOLO_ABI_VERSION 4
 int yolo_version(void);
 
 /* ---- parameter preparation ------------------------------------------------------------- */
@@ -129,6 +139,12 @@ typedef struct yolo_conv_desc {
     float tail_slope;
     long long tail_y_batch_stride;
     long long tail_y_pixel_stride;
+    /* YOLO_BF16X3 only (ignored otherwise): elements between a pixel's hi plane and its lo plane in x and in y; 0 = dense (Cin,
+     * Cout).  A channel slice of a wider split buffer of Ctot channels (the halves of a concat buffer, car/utils.py:93) has pixel
+     * stride 2 * Ctot and lo offset Ctot.  Dense strides of a split tensor count both planes (pixel stride 2 * C); the residual
+     * is dense; y_lo_offset is not used when out_f32. */
+    long long x_lo_offset;
+    long long y_lo_offset;
 } yolo_conv_desc;
 
 int yolo_conv_fwd(const yolo_conv_desc* d, void* stream);
@@ -142,7 +158,9 @@ int yolo_conv_kernel_name(const yolo_conv_desc* d, char* buf, int len);
 /* The network's first _conv2d (basic_yolo.py:20) fused with the image layout change: Conv3x3 s1 p1 over
  * the (N,3,H,W) float32 NCHW image exactly as the reference feeds it (car/YOLO.py:381) + folded BN +
  * LeakyReLU -> (N,H,W,Cout) bf16 NHWC.  w_oihw: (Cout,3,3,3) float32 (unpacked); Cout % 4 == 0, <= 64;
- * dtype must be YOLO_BF16 (YOLO_F32 callers use yolo_nchw_to_nhwc + yolo_conv_fwd: EUNSUPPORTED here). */
+ * dtype YOLO_BF16 / YOLO_F16 (YOLO_F32 callers use yolo_nchw_to_nhwc + yolo_conv_fwd: EUNSUPPORTED here), or YOLO_BF16X3: a direct
+ * fp32 convolution on the vector pipe (K = 27: nothing for the matrix pipe to win) whose output is stored split, dense
+ * (N,H,W,[hi Cout | lo Cout]); Cout % 8 == 0 there. */
 int yolo_stem_conv_fwd(const float* x_nchw, const float* w_oihw, const float* scale, const float* bias,
                        void* y, int N, int H, int W, int Cin, int Cout, int dtype, float slope,
                        void* stream);

@@ -7,8 +7,15 @@ import torch.nn.functional as F
 
 from yolo_amd import lib as L
 
-TDT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}
-LDT = {'f32': L.F32, 'bf16': L.BF16, 'f16': L.F16}
+TDT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16, 'bf16x3': torch.bfloat16}
+LDT = {'f32': L.F32, 'bf16': L.BF16, 'f16': L.F16, 'bf16x3': L.BF16X3}
+SPLIT = ('bf16x3',)
+
+
+def split_planes(t, rdt=torch.bfloat16):
+    """fp32 tensor -> (hi, lo) in `rdt`: hi = round(t), lo = round(t - hi) -- the split types' storage (include/yolo_amd.h YOLO_BF16X3)."""
+    hi = t.to(rdt)
+    return hi, (t - hi.float()).to(rdt)
 
 
 KERNEL_SETS = ('measured', 'plan')
@@ -48,10 +55,15 @@ def assert_plan_held(obj, state, what):
 
 
 def to_nhwc(x_nchw, dtype, dev):
-    return torch.from_numpy(np.ascontiguousarray(x_nchw)).to(dev).permute(0, 2, 3, 1).contiguous().to(TDT[dtype])
+    t = torch.from_numpy(np.ascontiguousarray(x_nchw)).to(dev).permute(0, 2, 3, 1).contiguous()
+    if dtype in SPLIT:                                   # (N, H, W, 2, C): plane 0 = hi, plane 1 = lo
+        return torch.stack(split_planes(t.float(), TDT[dtype]), dim=3).contiguous()
+    return t.to(TDT[dtype])
 
 
 def from_nhwc(t):
+    if t.dim() == 5:                                     # a split activation: value = hi + lo
+        t = t[..., 0, :].float() + t[..., 1, :].float()
     return t.float().permute(0, 3, 1, 2).contiguous().cpu().numpy()
 
 
@@ -71,7 +83,8 @@ def run_conv(lib, dev, x, w, scale, bias, stride, slope, dtype, residual=None, o
     bi = torch.zeros(cp, device=dev); bi[:Cout] = torch.from_numpy(bias).to(dev)
     pad = k // 2
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    y = torch.full((N, Ho, Wo, Cout), float('nan'), dtype=torch.float32 if out_f32 else TDT[dtype], device=dev)
+    yshape = (N, Ho, Wo, 2, Cout) if (dtype in SPLIT and not out_f32) else (N, Ho, Wo, Cout)
+    y = torch.full(yshape, float('nan'), dtype=torch.float32 if out_f32 else TDT[dtype], device=dev)
     rd = to_nhwc(residual, dtype, dev) if residual is not None else None
     d = L.ConvDesc()
     d.x, d.w_packed, d.scale, d.bias = xd.data_ptr(), wp.data_ptr(), sc.data_ptr(), bi.data_ptr()
@@ -105,6 +118,24 @@ def ref_conv(x, w, scale, bias, stride, slope, residual=None, bf16=False):
         y = y + (rb(r) if bf16 else r)
     if bf16:
         y = rb(y)
+    return y.numpy()
+
+
+def ref_conv_split(x, w, scale, bias, stride, slope, residual=None, rdt=torch.bfloat16, out_f32=False):
+    """The split path's arithmetic restated: operands as (hi, lo) pairs, the product as w_hi x_hi + w_hi x_lo + w_lo x_hi (float64
+    sums: what the fp32 MFMA accumulation approximates), fp32 epilogue, the result stored as a pair again."""
+    sp = lambda a: [p.double() for p in split_planes(torch.from_numpy(np.ascontiguousarray(a)).float(), rdt)]
+    (xh, xl), (wh, wl) = sp(x), sp(w)
+    kw = dict(stride=stride, padding=w.shape[2] // 2)
+    y = (F.conv2d(xh, wh, None, **kw) + F.conv2d(xl, wh, None, **kw) + F.conv2d(xh, wl, None, **kw)).float()
+    y = y * torch.from_numpy(scale).view(1, -1, 1, 1) + torch.from_numpy(bias).view(1, -1, 1, 1)
+    y = torch.where(y > 0, y, y * slope)
+    if residual is not None:
+        rh, rl = sp(residual)
+        y = y + (rh + rl).float()
+    if not out_f32:
+        yh, yl = split_planes(y, rdt)
+        y = yh.float() + yl.float()
     return y.numpy()
 
 

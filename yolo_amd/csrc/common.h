@@ -87,6 +87,18 @@ template <> struct Elem<float> {
     static __device__ __forceinline__ float lo(uint32_t) { return 0.f; }
     static __device__ __forceinline__ float hi(uint32_t) { return 0.f; }
 };
+// SPLIT type (round 6; YOLO_BF16X3): a value v is carried as TWO 2-byte numbers, hi = round(v) and lo = round(v - hi)
+// -- 16 significant bits -- and a product w * x is taken as w_hi x_hi + w_hi x_lo + w_lo x_hi on the 2-byte MFMA
+// with fp32 accumulation (the w_lo x_lo term, 2^-18 of the product, is dropped): three MFMAs per product instead of the
+// sixteen-times-slower v_mfma_f32_32x32x2f32, decoded boxes inside the north-star 1e-3 (3e-4 max on the D53 random-BN nets).  Storage: a pixel holds its C hi values, then -- `lo offset` elements further -- its C lo
+// values; the convolution kernels see 3 * C / 32 K-chunks [x_hi | x_lo | x_hi] against the weight image [w_hi | w_hi | w_lo].
+struct bf16x3_t { uint16_t bits; };
+template <> struct Elem<bf16x3_t> : Elem<bf16_t> {
+    static constexpr const char* name = "bf16x3_t";
+    static constexpr int dtype = YOLO_BF16X3;
+};
+template <typename T> struct IsSplit { static constexpr bool value = false; };
+template <> struct IsSplit<bf16x3_t> { static constexpr bool value = true; };
 // one 32x32x16 MFMA step on 2-byte operands (A, B: 8 elements per lane as a uint4)
 template <typename T> __device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, const f32x16& c);
 template <> __device__ __forceinline__ f32x16 mfma16<bf16_t>(const uint4& a, const uint4& b, const f32x16& c) {
@@ -95,11 +107,20 @@ template <> __device__ __forceinline__ f32x16 mfma16<bf16_t>(const uint4& a, con
 template <> __device__ __forceinline__ f32x16 mfma16<f16_t>(const uint4& a, const uint4& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+template <> __device__ __forceinline__ f32x16 mfma16<bf16x3_t>(const uint4& a, const uint4& b, const f32x16& c) { return mfma16<bf16_t>(a, b, c); }
 template <typename T> struct IsBf16 { static constexpr bool value = false; };
 template <> struct IsBf16<bf16_t> { static constexpr bool value = true; };
 
-static inline int elem_size(int dtype) { return dtype == YOLO_F32 ? 4 : 2; }
-static inline bool dtype_valid(int dtype) { return dtype == YOLO_F32 || dtype == YOLO_BF16 || dtype == YOLO_F16; }
+// bytes of one stored element; 0 for an unknown dtype (every entry point checks dtype_valid first: a garbage dtype must not be
+// sized as a 2-byte type)
+static inline int elem_size(int dtype) { return dtype == YOLO_F32 ? 4 : (dtype == YOLO_BF16 || dtype == YOLO_F16 || dtype == YOLO_BF16X3) ? 2 : 0; }
+static inline bool dtype_valid(int dtype) { return dtype == YOLO_F32 || dtype == YOLO_BF16 || dtype == YOLO_F16 || dtype == YOLO_BF16X3; }
+// the single-plane dtypes (what the training / fused / streaming entries take)
+static inline bool dtype_plain(int dtype) { return dtype == YOLO_F32 || dtype == YOLO_BF16 || dtype == YOLO_F16; }
+static inline bool dtype_split(int dtype) { return dtype == YOLO_BF16X3; }
+// stored planes per activation element (split types: hi + lo) and K passes of a convolution over the input channels
+static inline int dtype_planes(int dtype) { return dtype_split(dtype) ? 2 : 1; }
+static inline int dtype_kpasses(int dtype) { return dtype_split(dtype) ? 3 : 1; }
 // channels held by one 64-byte K-chunk
 static inline int chunk_channels(int dtype) { return 64 / elem_size(dtype); }
 // packed weights / scale / bias are padded to a multiple of this many output channels

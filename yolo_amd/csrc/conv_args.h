@@ -61,6 +61,10 @@ struct ConvArgs {
     int t_cout, t_out_f32;
     float t_slope;
     long long t_y_bs, t_y_ps;
+    // split types (YOLO_BF16X3, common.h): the K loop walks 3 * x3_n chunks [x_hi | x_lo | x_hi] of a pixel whose lo plane sits
+    // x_lo bytes behind its hi plane: source byte offset of chunk c = c * 64 + (c >= x3_n ? x3_adj1 : 0) + (c >= 2 x3_n ? x3_adj2 : 0)
+    int x3_n, x3_adj1, x3_adj2;
+    long long y_lo, r_lo;   // ELEMENT offset of the lo plane in a pixel of y / of the residual
 };
 
 static inline void conv_args_fastdiv(ConvArgs& a) {

@@ -109,12 +109,25 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                             ((float*)a.y)[o + e] = t;
                         } else if constexpr (ES == 2) {
                             if (a.res) t += Elem<T>::lo(((const uint16_t*)a.res)[ro + e]);
+                            if constexpr (IsSplit<T>::value) {
+                                if (a.res) t += Elem<T>::lo(((const uint16_t*)a.res)[ro + e + a.r_lo]);
+                            }
                             const uint16_t b16 = (uint16_t)(Elem<T>::pack2(t, 0.f) & 0xffffu);
                             ((uint16_t*)a.y)[o + e] = b16;
                             if (a.up2) {
                                 ((uint16_t*)a.y)[o + e + a.y_ps] = b16;
                                 ((uint16_t*)a.y)[o + e + 2LL * a.Wo * a.y_ps] = b16;
                                 ((uint16_t*)a.y)[o + e + (2LL * a.Wo + 1) * a.y_ps] = b16;
+                            }
+                            if constexpr (IsSplit<T>::value) {          // the lo plane: what the hi value's rounding left
+                                const uint16_t l16 = (uint16_t)(Elem<T>::pack2(t - Elem<T>::lo(b16), 0.f) & 0xffffu);
+                                const long long ol = o + e + a.y_lo;
+                                ((uint16_t*)a.y)[ol] = l16;
+                                if (a.up2) {
+                                    ((uint16_t*)a.y)[ol + a.y_ps] = l16;
+                                    ((uint16_t*)a.y)[ol + 2LL * a.Wo * a.y_ps] = l16;
+                                    ((uint16_t*)a.y)[ol + (2LL * a.Wo + 1) * a.y_ps] = l16;
+                                }
                             }
                         } else {
                             if (a.res) t += ((const float*)a.res)[ro + e];
@@ -191,6 +204,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
         const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)(STATS == 2 ? a.s_y : a.y), 0, 0x7fffffff, 0x00020000);
         int yb[2][NPASS];                       // byte offset of the lane's 16-byte piece in y (-1: none)
         u32x4_t rb[2][NPASS], sb[2][NPASS];
+        u32x4_t rl[IsSplit<T>::value ? 2 : 1][IsSplit<T>::value ? NPASS : 1];      // split types: the residual's lo plane
+        const int ylo_b = IsSplit<T>::value ? (int)(a.y_lo * ES) : 0, rlo_b = IsSplit<T>::value ? (int)(a.r_lo * ES) : 0;
         // (round 5) The uniform decisions -- identity epilogue, residual, 2x2 up-sampled stores -- are taken ONCE around the slab loop:
         // the common combinations are compiled as specialisations (the flag a compile-time constant), the rest runs the generic
         // form with the flags read at run time (FLAG < 0).  Inside the loop the branches cut every pass into basic blocks: the
@@ -221,6 +236,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
 #else
                     rb[ni & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, ok ? (int)((r_ + cofs) * ES) : -1, 0, 0);
 #endif
+                    if constexpr (IsSplit<T>::value)
+                        rl[ni & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, ok ? (int)((r_ + cofs) * ES) + rlo_b : -1, 0, 0);
                 }
                 if constexpr (STATS == 2) sb[ni & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(srs, yb[ni & 1][k], 0, 0);
             }
@@ -275,9 +292,32 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                             v[2 * q] += Elem<T>::lo(w[q]);
                             v[2 * q + 1] += Elem<T>::hi(w[q]);
                         }
+                        if constexpr (IsSplit<T>::value) {
+                            const uint32_t wl[4] = {rl[ni & 1][k].x, rl[ni & 1][k].y, rl[ni & 1][k].z, rl[ni & 1][k].w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                v[2 * q] += Elem<T>::lo(wl[q]);
+                                v[2 * q + 1] += Elem<T>::hi(wl[q]);
+                            }
+                        }
                     }
                     ov.x = Elem<T>::pack2(v[0], v[1]); ov.y = Elem<T>::pack2(v[2], v[3]);
                     ov.z = Elem<T>::pack2(v[4], v[5]); ov.w = Elem<T>::pack2(v[6], v[7]);
+                    if constexpr (IsSplit<T>::value) {
+                        // the lo plane = what the hi values' rounding left, rounded once more: 16 significant bits per stored value
+                        const uint32_t hw[4] = {ov.x, ov.y, ov.z, ov.w};
+                        u32x4_t ol;
+                        ol.x = Elem<T>::pack2(v[0] - Elem<T>::lo(hw[0]), v[1] - Elem<T>::hi(hw[0]));
+                        ol.y = Elem<T>::pack2(v[2] - Elem<T>::lo(hw[1]), v[3] - Elem<T>::hi(hw[1]));
+                        ol.z = Elem<T>::pack2(v[4] - Elem<T>::lo(hw[2]), v[5] - Elem<T>::hi(hw[2]));
+                        ol.w = Elem<T>::pack2(v[6] - Elem<T>::lo(hw[3]), v[7] - Elem<T>::hi(hw[3]));
+                        __builtin_amdgcn_raw_buffer_store_b128(ol, yrs, ob >= 0 ? ob + ylo_b : -1, 0, 0);
+                        if (f_up2) {
+                            __builtin_amdgcn_raw_buffer_store_b128(ol, yrs, ob >= 0 ? ob + ylo_b + up_a : -1, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(ol, yrs, ob >= 0 ? ob + ylo_b + up_b : -1, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(ol, yrs, ob >= 0 ? ob + ylo_b + up_b + up_a : -1, 0, 0);
+                        }
+                    }
                     if constexpr (STATS != 0) {
                         const uint32_t ow[4] = {ov.x, ov.y, ov.z, ov.w};
                         float vr[8];
@@ -331,6 +371,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
     // 8-wave variants.)  Output offsets go through a small LDS table: the transpose changes which pixel a lane owns.
     long long yo[2][NPASS];
     uint4 rv[2][NPASS];
+    uint4 rvl[IsSplit<T>::value ? 2 : 1][IsSplit<T>::value ? NPASS : 1];      // split types: the residual's lo plane
     uint4 sv[2][NPASS];                     // STATS == 2: the forward raw outputs under this lane's gradients
     auto prefetch = [&](int ni) {
         if (h == 0) ytab[(ni & 1) * 32 + l31] = yoff[ni];
@@ -344,6 +385,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                 rv[ni & 1][k] = make_uint4(0, 0, 0, 0);
                 const long long ro = res_sep ? rtab[(ni & 1) * 32 + row0 + k * RPP] : yo[ni & 1][k];
                 if (yo[ni & 1][k] >= 0) rv[ni & 1][k] = *(const uint4*)(a.res + (ro + cofs) * ES);
+                if constexpr (IsSplit<T>::value) {
+                    rvl[ni & 1][k] = make_uint4(0, 0, 0, 0);
+                    if (yo[ni & 1][k] >= 0) rvl[ni & 1][k] = *(const uint4*)(a.res + (ro + cofs + a.r_lo) * ES);
+                }
             }
         }
         if constexpr (STATS == 2) {
@@ -391,9 +436,33 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], const long 
                         v[2 * q] += Elem<T>::lo(w[q]);
                         v[2 * q + 1] += Elem<T>::hi(w[q]);
                     }
+                    if constexpr (IsSplit<T>::value) {
+                        const uint32_t wl[4] = {rvl[ni & 1][k].x, rvl[ni & 1][k].y, rvl[ni & 1][k].z, rvl[ni & 1][k].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[2 * q] += Elem<T>::lo(wl[q]);
+                            v[2 * q + 1] += Elem<T>::hi(wl[q]);
+                        }
+                    }
                 }
                 ov = make_uint4(Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2], v[3]), Elem<T>::pack2(v[4], v[5]),
                                 Elem<T>::pack2(v[6], v[7]));
+                if constexpr (IsSplit<T>::value) {
+                    if (yo[ni & 1][k] >= 0) {
+                        const uint32_t hw[4] = {ov.x, ov.y, ov.z, ov.w};
+                        const uint4 ol = make_uint4(Elem<T>::pack2(v[0] - Elem<T>::lo(hw[0]), v[1] - Elem<T>::hi(hw[0])),
+                                                    Elem<T>::pack2(v[2] - Elem<T>::lo(hw[1]), v[3] - Elem<T>::hi(hw[1])),
+                                                    Elem<T>::pack2(v[4] - Elem<T>::lo(hw[2]), v[5] - Elem<T>::hi(hw[2])),
+                                                    Elem<T>::pack2(v[6] - Elem<T>::lo(hw[3]), v[7] - Elem<T>::hi(hw[3])));
+                        char* dl = a.y + (yo[ni & 1][k] + cofs + a.y_lo) * ES;
+                        *(uint4*)dl = ol;
+                        if (a.up2) {
+                            *(uint4*)(dl + a.y_ps * ES) = ol;
+                            *(uint4*)(dl + 2LL * a.Wo * a.y_ps * ES) = ol;
+                            *(uint4*)(dl + (2LL * a.Wo + 1) * a.y_ps * ES) = ol;
+                        }
+                    }
+                }
                 if constexpr (STATS != 0) {
                     // the statistics of the STORED (bf16-rounded) values: what the separate reduction pass would read
                     const uint32_t ow[4] = {ov.x, ov.y, ov.z, ov.w};

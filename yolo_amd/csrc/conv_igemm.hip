@@ -427,8 +427,11 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     if (!dtype_valid(d->dtype)) return YOLO_EINVAL;
     if (!(d->slope >= 0.f && d->slope <= 1.f)) return YOLO_EINVAL;       // LeakyReLU is computed as max(t, t*slope)
     const int es = elem_size(d->dtype);
+    const bool split = dtype_split(d->dtype);                         // (YOLO_BF16X3: common.h)
+    const int planes = dtype_planes(d->dtype);
     if ((d->Cin * es) % 16) return YOLO_EUNSUPPORTED;                 // 16-byte K units
     if (!d->out_f32 && (d->Cout % 4)) return YOLO_EUNSUPPORTED;       // 4-channel store groups
+    if (split && ((d->Cin * es) % 64 || d->stats || d->tail_w_packed || (!d->out_f32 && (d->Cout % 8)))) return YOLO_EUNSUPPORTED;
     const int pad = d->ksize / 2;
     ConvArgs a;
     a.x = (const char*)d->x;
@@ -441,18 +444,31 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     a.Ho = (d->H + 2 * pad - d->ksize) / d->stride + 1;
     a.Wo = (d->W + 2 * pad - d->ksize) / d->stride + 1;
     a.Cout_pad = round_up(d->Cout, YOLO_COUT_PAD);
-    a.nchunks = (d->Cin * es + 63) / 64;
+    a.nchunks = (d->Cin * es + 63) / 64 * dtype_kpasses(d->dtype);
     a.out_f32 = d->out_f32;
     a.d2s = 0;
     a.halo_strict = 0;
     a.up2 = d->upsample2x ? 1 : 0;
-    if (d->x_pixel_stride < 0 || (d->x_pixel_stride && d->x_pixel_stride < d->Cin) || d->x_pixel_stride > 0x7fffffffLL) return YOLO_EINVAL;
-    a.x_ps = d->x_pixel_stride ? (int)d->x_pixel_stride : d->Cin;
+    if (d->x_pixel_stride < 0 || (d->x_pixel_stride && d->x_pixel_stride < (long long)d->Cin * planes) || d->x_pixel_stride > 0x7fffffffLL) return YOLO_EINVAL;
+    a.x_ps = d->x_pixel_stride ? (int)d->x_pixel_stride : d->Cin * planes;
+    a.x3_n = 0; a.x3_adj1 = 0; a.x3_adj2 = 0; a.y_lo = 0; a.r_lo = 0;
+    if (split) {
+        const long long xlo = d->x_lo_offset ? d->x_lo_offset : d->Cin;
+        const long long ylo = d->y_lo_offset ? d->y_lo_offset : d->Cout;
+        if (xlo < d->Cin || xlo + d->Cin > a.x_ps || (xlo * es) % 16) return YOLO_EINVAL;
+        if (!d->out_f32 && (ylo < d->Cout || (ylo * es) % 16)) return YOLO_EINVAL;      // (fp32 logits are not split: y_lo unused)
+        a.x3_n = d->Cin * es / 64;
+        a.x3_adj1 = (int)(xlo * es) - a.x3_n * 64;
+        a.x3_adj2 = -a.x3_n * 64 - (int)(xlo * es);
+        a.y_lo = ylo; a.r_lo = d->Cout;
+    }
     if ((a.x_ps * es) % 16) return YOLO_EUNSUPPORTED;                 // 16-byte aligned pixel rows
     a.slope = d->slope;
-    a.y_ps = d->y_pixel_stride ? d->y_pixel_stride : d->Cout;
+    const int oplanes = d->out_f32 ? 1 : planes;                          // (fp32 logits are not split)
+    a.y_ps = d->y_pixel_stride ? d->y_pixel_stride : d->Cout * oplanes;
+    if (split && !d->out_f32 && a.y_lo + d->Cout > a.y_ps) return YOLO_EINVAL;
     a.y_bs = d->y_batch_stride ? d->y_batch_stride : (long long)a.Ho * a.Wo * a.y_ps * (a.up2 ? 4 : 1);
-    a.r_ps = d->Cout; a.r_bs = (long long)a.Ho * a.Wo * d->Cout;          // the residual is dense
+    a.r_ps = d->Cout * planes; a.r_bs = (long long)a.Ho * a.Wo * a.r_ps;  // the residual is dense
     if (a.res && d->out_f32) return YOLO_EUNSUPPORTED;
     if (a.up2 && (a.res || d->out_f32)) return YOLO_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -522,7 +538,7 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     if (d->algo == 0) {
         // small-channel 3x3 layers: the streaming kernel (measured 1.2-1.45x the generic one; the 1x1s and the
         // 64->128 stride-2 layer are a wash and stay where they were)
-        if (d->ksize == 3 && d->Cin <= 64 && !(d->stride == 2 && d->Cin == 64)) {
+        if (!split && d->ksize == 3 && d->Cin <= 64 && !(d->stride == 2 && d->Cin == 64)) {
             const int rc = conv_stream_dispatch(a, d->ksize, d->stride, d->dtype, 13, st, nm);
             if (rc != YOLO_EUNSUPPORTED) return rc;
         }
@@ -543,6 +559,7 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     }
     if (d->dtype == YOLO_BF16) return launch_dtype<bf16_t>(a, d->ksize, d->stride, st, nm);
     if (d->dtype == YOLO_F16) return launch_dtype<f16_t>(a, d->ksize, d->stride, st, nm);
+    if (split) return YOLO_EUNSUPPORTED;                                  // (split types: the pipelined kernels only)
     return launch_dtype<float>(a, d->ksize, d->stride, st, nm);
 }
 
@@ -567,6 +584,7 @@ extern "C" int yolo_conv_dgrad_s2(const yolo_conv_desc* d, void* stream) {
     a.halo_strict = 0;
     a.stats = nullptr; a.stats_mode = 0;
     a.t_wp = nullptr;
+    a.x3_n = 0; a.x3_adj1 = 0; a.x3_adj2 = 0; a.y_lo = 0; a.r_lo = 0;
     a.lab = 0;
     a.buf32 = ((long long)a.N * a.Ho * a.Wo * d->Cout * 2 < 0x7fffffffLL) ? conv_buf32_form() : 0;      // (dx: N x 2Ho x 2Wo x Cout/4, residual = dx)
     if (d->x_pixel_stride || d->upsample2x || d->stats) return YOLO_EUNSUPPORTED;
@@ -614,7 +632,14 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ w, T* __restr
     const int co = (int)(r % Cout_pad);
     r /= Cout_pad;
     const int tap = (int)(r % (ks * ks));
-    const int chunk = (int)(r / (ks * ks));
+    int chunk = (int)(r / (ks * ks));
+    // split types: three passes over the input channels -- chunks [w_hi | w_hi | w_lo] against the kernel's [x_hi | x_lo | x_hi]
+    int pass = 0;
+    if constexpr (IsSplit<T>::value) {
+        const int n = Cin / CH;              // (the host checks Cin % 32 == 0)
+        pass = chunk / n;
+        chunk -= pass * n;
+    }
     const int punit = e / UE, within = e % UE;
     const int lunit = punit ^ ((co >> 2) & 3);            // physical unit holds this logical unit
     const int ci = chunk * CH + lunit * UE + within;
@@ -637,7 +662,10 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ w, T* __restr
             if (ky >= 0 && kx >= 0) v = w[((long long)(ci * Cf + cf) * 3 + ky) * 3 + kx];
         }
     }
-    if constexpr (sizeof(T) == 2)
+    if constexpr (IsSplit<T>::value) {
+        const uint32_t hi = Elem<T>::pack2(v, 0.f) & 0xffffu;
+        ((uint16_t*)out)[idx] = (uint16_t)(pass < 2 ? hi : (Elem<T>::pack2(v - Elem<T>::lo(hi), 0.f) & 0xffffu));
+    } else if constexpr (sizeof(T) == 2)
         ((uint16_t*)out)[idx] = (uint16_t)(Elem<T>::pack2(v, 0.f) & 0xffffu);
     else
         out[idx] = v;
@@ -682,6 +710,7 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackItem*
 }
 
 extern "C" long long yolo_pack_batch_blocks(int Cout, int Cin, int ksize, int dtype) {
+    if (!dtype_plain(dtype)) return dtype_valid(dtype) ? YOLO_EUNSUPPORTED : YOLO_EINVAL;      // (the training step's batched re-pack)
     const long long bytes = yolo_packed_weight_bytes(Cout, Cin, ksize, dtype);
     if (bytes < 0) return bytes;
     return (bytes / elem_size(dtype) + PACK_BLOCK_ELEMS - 1) / PACK_BLOCK_ELEMS;
@@ -779,7 +808,8 @@ extern "C" int yolo_pack_conv_weights_pairs(const void* items_device, const long
 extern "C" long long yolo_packed_weight_bytes(int Cout, int Cin, int ksize, int dtype) {
     if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 2 && ksize != 3)) return YOLO_EINVAL;
     if (!dtype_valid(dtype)) return YOLO_EINVAL;
-    const int nchunks = (Cin * elem_size(dtype) + 63) / 64;
+    if (dtype_split(dtype) && ((Cin * elem_size(dtype)) % 64 || ksize == 2)) return YOLO_EUNSUPPORTED;
+    const int nchunks = (Cin * elem_size(dtype) + 63) / 64 * dtype_kpasses(dtype);
     return (long long)nchunks * ksize * ksize * round_up(Cout, YOLO_COUT_PAD) * 64;
 }
 
@@ -815,7 +845,8 @@ static int pack_impl(const float* w_oihw, void* packed, int Cout, int Cin, int k
     const long long bytes = yolo_packed_weight_bytes(Cout, Cin, ksize, dtype);
     if (bytes < 0) return (int)bytes;
     const int Cout_pad = round_up(Cout, YOLO_COUT_PAD);
-    const int nchunks = (Cin * elem_size(dtype) + 63) / 64;
+    if (dtype_split(dtype) && dgrad) return YOLO_EUNSUPPORTED;
+    const int nchunks = (Cin * elem_size(dtype) + 63) / 64 * dtype_kpasses(dtype);
     const long long total = bytes / elem_size(dtype);
     const int grid = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
     if (dtype == YOLO_BF16)
@@ -824,6 +855,9 @@ static int pack_impl(const float* w_oihw, void* packed, int Cout, int Cin, int k
     else if (dtype == YOLO_F16)
         YOLO_LAUNCH(pack_weights_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
                            (f16_t*)packed, Cout, Cin, ksize, Cout_pad, nchunks, dgrad);
+    else if (dtype == YOLO_BF16X3)
+        YOLO_LAUNCH(pack_weights_kernel<bf16x3_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                           (bf16x3_t*)packed, Cout, Cin, ksize, Cout_pad, nchunks, dgrad);
     else
         YOLO_LAUNCH(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
                            (float*)packed, Cout, Cin, ksize, Cout_pad, nchunks, dgrad);

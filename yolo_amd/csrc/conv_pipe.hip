@@ -31,10 +31,11 @@
 //                  2: 3x3 kernels, f16 and f32 (.._dispatch_c)   3: 1x1 kernels, f16 and f32 (conv_pipe_dispatch_d)
 //                  4: 3x3 stride-2 kernels, bf16 (conv_pipe_dispatch_e)
 //                  5: 3x3 stride-1 kernels, bf16, the second half of the tile variants (conv_pipe_dispatch_f)
-#define YOLO_PIPE_3X3 (YOLO_PIPE_PART == 0 || YOLO_PIPE_PART == 2 || YOLO_PIPE_PART == 4 || YOLO_PIPE_PART == 5)
+//                  6: 3x3 kernels, split bf16 (YOLO_BF16X3; conv_pipe_dispatch_g)      7: 1x1 kernels, split bf16 (conv_pipe_dispatch_h)
+#define YOLO_PIPE_3X3 (YOLO_PIPE_PART == 0 || YOLO_PIPE_PART == 2 || YOLO_PIPE_PART == 4 || YOLO_PIPE_PART == 5 || YOLO_PIPE_PART == 6)
 // (which stride-1 3x3 variants a unit holds: bf16 is split over units 0 and 5)
-#define YOLO_PIPE_S1A (YOLO_PIPE_PART == 0 || YOLO_PIPE_PART == 2)
-#define YOLO_PIPE_S1B (YOLO_PIPE_PART == 5 || YOLO_PIPE_PART == 2)
+#define YOLO_PIPE_S1A (YOLO_PIPE_PART == 0 || YOLO_PIPE_PART == 2 || YOLO_PIPE_PART == 6)
+#define YOLO_PIPE_S1B (YOLO_PIPE_PART == 5 || YOLO_PIPE_PART == 2 || YOLO_PIPE_PART == 6)
 namespace { __device__ __attribute__((aligned(64))) unsigned int yolo_zero_page[16]; }
 
 typedef __attribute__((address_space(3))) char lds_char;
@@ -82,6 +83,7 @@ template <> struct FragP<f16_t> {
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
 };
+template <> struct FragP<bf16x3_t> : FragP<bf16_t> {};
 template <> struct FragP<float> {
     static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16& c) {
         c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
@@ -205,6 +207,12 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
 
     unsigned xo[XL1];
     const int nchunks = a.nchunks;
+    // split types: byte offset of K-chunk c inside a pixel -- the passes [x_hi | x_lo | x_hi] over the pixel's two planes (conv_args.h)
+    const int x3n = IsSplit<T>::value ? a.x3_n : 0, x3a1 = IsSplit<T>::value ? a.x3_adj1 : 0, x3a2 = IsSplit<T>::value ? a.x3_adj2 : 0;
+    auto chunk_off = [&](int cc) -> long long {
+        if constexpr (IsSplit<T>::value) return (long long)(cc * 64 + (cc >= x3n ? x3a1 : 0) + (cc >= 2 * x3n ? x3a2 : 0));
+        else return (long long)cc * 64;
+    };
     const int nphase = nchunks * PPC / KC;
     const uint32_t wave_lds = lds0 + wave * 1024;        // this wave's 1 KiB lane-linear window per DMA
 
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
 #endif
         const int kc = j / XL1, jj = j - kc * XL1;
         const int cc = (KS != 1) ? min(c, nchunks - 1) : min(c, nphase - 1) * KC + kc;      // (1x1: c counts phases)
-        const char* src = (xo[jj] != 0xffffffffu) ? ax + ((size_t)xo[jj] + (size_t)cc * 64) : zero_page;
+        const char* src = (xo[jj] != 0xffffffffu) ? ax + ((long long)xo[jj] + chunk_off(cc)) : zero_page;
         glds16_m0(src, wave_lds + buf * X_STAGE + kc * X_STAGE1 + jj * NT * 16);
     };
     static_assert(KS == 1 || XL <= PPC, "3x3: at most one input DMA per phase");
@@ -432,7 +440,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
             for (int j = 0; j < XL; ++j) {
                 const int kc = j / XL1, jj = j - kc * XL1;
                 const bool ok = xo[jj] != 0xffffffffu;
-                xq[j] = ok ? ax + ((size_t)xo[jj] + (size_t)(g0 + kc) * 64) : (const char*)yolo_zero_page;
+                xq[j] = ok ? ax + ((long long)xo[jj] + chunk_off(g0 + kc)) : (const char*)yolo_zero_page;
                 if (kc == 0) xinc[jj] = ok ? 64u * KC : 0u;
             }
         }
@@ -481,6 +489,16 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
                 for (int j = 0; j < WL; ++j) wq[j] += winc;
 #pragma unroll
                 for (int j = 0; j < XL; ++j) xq[j] += xinc[j % XL1];
+                if constexpr (IsSplit<T>::value) {
+                    // the pointers now address the phase that starts at chunk g: entering the lo pass / the second hi pass they
+                    // jump by the plane adjustment (the host checks that a phase of KC chunks never straddles two passes)
+                    const int g = (gp + R1) * KC;
+                    if (g == x3n || g == 2 * x3n) {
+                        const int adj = g == x3n ? x3a1 : x3a2;
+#pragma unroll
+                        for (int j = 0; j < XL; ++j) xq[j] += xinc[j % XL1] ? adj : 0;
+                    }
+                }
             }
             wait_vmcnt<(R1 - 2) * (WL + XL)>();
             __builtin_amdgcn_s_barrier();
@@ -755,6 +773,7 @@ template <typename T, int KS, int WAVES_P, int WAVES_C, int MI, int NI, int XSLO
 static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     constexpr int BP = WAVES_P * NI * 32, BC = WAVES_C * MI * 32;
     if (KC > 1 && (a.nchunks % KC || a.nchunks < 2 * KC)) return YOLO_EUNSUPPORTED;
+    if (IsSplit<T>::value && KC > 1 && (a.x3_n % KC)) return YOLO_EUNSUPPORTED;      // (a phase must not straddle two K passes)
     if (LEAN && a.nchunks / KC < 4) return YOLO_EUNSUPPORTED;       // the lean loop starts after a full ring of phases
     a.row_swz = 0;
     if (KS != 1) {
@@ -806,7 +825,7 @@ static int launch_pipe(ConvArgs& a, hipStream_t st, const NameOut* name) {
     if (a.stats && !stats_ok) return YOLO_EUNSUPPORTED;
     // fused tail 1x1 (kernel flag 3): bf16 3x3 tiles that hold all the channels of a pixel (tiles_c == 1: Cout <= the tile's 128 or
     // 256 couts) and have four cout waves (each takes 32 of the tail's <= 128 couts)
-    constexpr bool kTail = sizeof(T) == 2 && KS == 3 && WAVES_C == 4 && RD == 0 && KC == 1 && LEAN == 0;       // (128- or 256-cout tiles of 8 waves)
+    constexpr bool kTail = sizeof(T) == 2 && !IsSplit<T>::value && KS == 3 && WAVES_C == 4 && RD == 0 && KC == 1 && LEAN == 0;       // (128- or 256-cout tiles of 8 waves)
     if (a.t_wp) {
         if (!kTail || a.stats || a.out_f32 || a.up2 || a.d2s || a.tiles_c != 1 || (a.Cout % 32) || a.t_cout < 1 || a.t_cout > 128)
             return YOLO_EUNSUPPORTED;
@@ -861,13 +880,15 @@ int conv_pipe_dispatch_c(ConvArgs& a, int ks, int stride, int dtype, int algo, h
 int conv_pipe_dispatch_d(ConvArgs& a, int ks, int dtype, int algo, hipStream_t st, const NameOut* nm);                 // (unit 3)
 int conv_pipe_dispatch_e(ConvArgs& a, int algo, hipStream_t st, const NameOut* nm);                                    // (unit 4)
 int conv_pipe_dispatch_f(ConvArgs& a, int algo, hipStream_t st, const NameOut* nm);                                    // (unit 5)
+int conv_pipe_dispatch_g(ConvArgs& a, int ks, int stride, int algo, hipStream_t st, const NameOut* nm);                // (unit 6)
+int conv_pipe_dispatch_h(ConvArgs& a, int ks, int algo, hipStream_t st, const NameOut* nm);                            // (unit 7)
 
 template <typename T>
 static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_t st, const NameOut* nm) {
 #if YOLO_PIPE_PART == 0
     if (ks == 3 && stride == 2) return conv_pipe_dispatch_e(a, algo, st, nm);      // (bf16: a unit of its own)
 #endif
-#if YOLO_PIPE_PART == 2 || YOLO_PIPE_PART == 4
+#if YOLO_PIPE_PART == 2 || YOLO_PIPE_PART == 4 || YOLO_PIPE_PART == 6
     if (ks == 3 && stride == 2) {
         // stride 2: the input footprint is ~4x the output tile, so tiles are 128 output pixels
         switch (algo) {
@@ -908,7 +929,8 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
             case 27: return launch_pipe<T, 3, 4, 2, 2, 3, 768>(a, st, nm);     // 8 waves, 384 px x 128 cout (wave tile 96x64)
             case 28: return launch_pipe<T, 3, 4, 2, 2, 4, 1024>(a, st, nm);    // 8 waves, 512 px x 128 cout (wave tile 128x64)
             case 26:                                                            // 4 waves, 256 px x 256 cout (wave tile 128x128)
-                if constexpr (sizeof(T) == 2) return launch_pipe<T, 3, 2, 2, 4, 4, 512>(a, st, nm);
+                // (not for the split type: beside the split epilogue's second plane the 256-register accumulator spills)
+                if constexpr (sizeof(T) == 2 && !IsSplit<T>::value) return launch_pipe<T, 3, 2, 2, 4, 4, 512>(a, st, nm);
                 break;
 #endif
         }
@@ -918,6 +940,8 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
     return YOLO_EUNSUPPORTED;
 #elif YOLO_PIPE_PART == 0
     return conv_pipe_dispatch_b(a, ks, Elem<T>::dtype, algo, st, nm);
+#elif YOLO_PIPE_PART == 6
+    return conv_pipe_dispatch_h(a, ks, algo, st, nm);
 #else
     return conv_pipe_dispatch_d(a, ks, Elem<T>::dtype, algo, st, nm);
 #endif
@@ -987,6 +1011,10 @@ int conv_pipe_dispatch_d(ConvArgs& a, int ks, int dtype, int algo, hipStream_t s
     if (dtype == YOLO_F16) return pipe_dispatch_t<f16_t>(a, ks, 1, algo, st, nm);
     return pipe_dispatch_t<float>(a, ks, 1, algo, st, nm);
 }
+#elif YOLO_PIPE_PART == 6
+int conv_pipe_dispatch_g(ConvArgs& a, int ks, int stride, int algo, hipStream_t st, const NameOut* nm) { return pipe_dispatch_t<bf16x3_t>(a, ks, stride, algo, st, nm); }
+#elif YOLO_PIPE_PART == 7
+int conv_pipe_dispatch_h(ConvArgs& a, int ks, int algo, hipStream_t st, const NameOut* nm) { return pipe_dispatch_t<bf16x3_t>(a, ks, 1, algo, st, nm); }
 #elif YOLO_PIPE_PART == 2
 int conv_pipe_dispatch_c(ConvArgs& a, int ks, int stride, int dtype, int algo, hipStream_t st, const NameOut* nm) {
     if (dtype == YOLO_F16) return pipe_dispatch_t<f16_t>(a, ks, stride, algo, st, nm);
@@ -1000,6 +1028,7 @@ int conv_pipe_dispatch(ConvArgs& a, int ks, int stride, int dtype, int algo, hip
     if (ks == 1 && a.nchunks < 2) return YOLO_EUNSUPPORTED;     // a 1x1 needs >= 2 phases; a 3x3 has 9 per chunk
     if ((long long)a.N * a.H * a.W * a.x_ps * elem_size(dtype) >= 0xffffff00LL) return YOLO_EUNSUPPORTED;
     if (dtype == YOLO_BF16) return pipe_dispatch_t<bf16_t>(a, ks, stride, algo, st, nm);
+    if (dtype == YOLO_BF16X3) return ks == 2 ? YOLO_EUNSUPPORTED : conv_pipe_dispatch_g(a, ks, stride, algo, st, nm);
     return conv_pipe_dispatch_c(a, ks, stride, dtype, algo, st, nm);
 }
 #endif

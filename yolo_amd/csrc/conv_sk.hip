@@ -249,7 +249,7 @@ static int sk_dispatch_t(ConvArgs& a, int algo, hipStream_t st, const NameOut* n
 }
 
 int conv_sk_dispatch(ConvArgs& a, int ks, int stride, int dtype, int algo, hipStream_t st, const NameOut* nm) {
-    if (ks != 1 || stride != 1) return YOLO_EUNSUPPORTED;
+    if (ks != 1 || stride != 1 || !dtype_plain(dtype)) return YOLO_EUNSUPPORTED;
     if ((a.Cin * elem_size(dtype)) % 64) return YOLO_EUNSUPPORTED;
     if ((long long)a.N * a.H * a.W * a.x_ps * elem_size(dtype) >= 0xffffff00LL) return YOLO_EUNSUPPORTED;
     if (dtype == YOLO_BF16) return sk_dispatch_t<bf16_t>(a, algo, st, nm);

@@ -163,7 +163,7 @@ __global__ void upsample_concat_kernel(const uint4* __restrict__ up, const uint4
 extern "C" int yolo_upsample2x_concat(const void* up, const void* route, void* y, int N, int H, int W, int C1,
                                       int C2, int dtype, void* stream) {
     if (!up || !route || !y || N <= 0 || H <= 0 || W <= 0 || C1 <= 0 || C2 <= 0) return YOLO_EINVAL;
-    if ((H & 1) || (W & 1)) return YOLO_EINVAL;
+    if ((H & 1) || (W & 1) || !dtype_plain(dtype)) return YOLO_EINVAL;
     const int es = elem_size(dtype);
     if ((C1 * es) % 16 || (C2 * es) % 16) return YOLO_EUNSUPPORTED;
     const int U1 = C1 * es / 16, U2 = C2 * es / 16;

@@ -198,12 +198,78 @@ extern "C" int yolo_stem_conv_fwd_stats(const float* x_nchw, const float* w_oihw
     return YOLO_OK;
 }
 
+// ---- split types (YOLO_BF16X3): the stem as a DIRECT fp32 convolution on the vector pipe -------------------------------------
+// K = 27: three MFMA passes over a K padded to 32 would buy nothing, and exact fp32 products cost the stem ~0.1 ms at 416x416 bs 32
+// against the ~12 ms of the split pass.  A thread owns 8 couts of one pixel (Cout / 8 adjacent lanes share a pixel: their image
+// loads are one request), the 27 x Cout weights sit in LDS as [tap][cout], and the output leaves split: hi = round(v),
+// lo = round(v - hi) at +Cout elements (dense (N,H,W,[hi | lo]): a wave writes whole 16-byte pieces of consecutive pixels).
+template <typename T>
+__global__ __launch_bounds__(256) void stem_split_kernel(const float* __restrict__ x, const float* __restrict__ w_oihw,
+                                                         const float* __restrict__ scale, const float* __restrict__ bias,
+                                                         uint16_t* __restrict__ y, int H, int W, int Cout, int tpp_shift, float slope,
+                                                         long long total) {
+    __shared__ __attribute__((aligned(16))) float wl[27 * 64];
+    for (int i = threadIdx.x; i < 27 * Cout; i += 256) {
+        const int tap = i / Cout, co = i - tap * Cout;
+        wl[i] = w_oihw[co * 27 + tap];                      // OIHW: [co][c][kh][kw] -> [c * 9 + kh * 3 + kw][co]
+    }
+    __syncthreads();
+    const long long g = blockIdx.x * 256LL + threadIdx.x;
+    if (g >= total) return;
+    const long long p = g >> tpp_shift;
+    const int q = (int)(g & ((1 << tpp_shift) - 1));
+    const long long HW = (long long)H * W;
+    const long long n = p / HW;
+    const int r = (int)(p - n * HW);
+    const int yy = r / W, xx = r - yy * W;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const float* xn = x + n * 3 * HW;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iy = yy + kh - 1, ix = xx + kw - 1;
+                const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                const float v = in ? xn[c * HW + (long long)iy * W + ix] : 0.f;
+                const float* wr = wl + (c * 9 + kh * 3 + kw) * Cout + q * 8;
+                const f32x4 w0 = *(const f32x4*)wr, w1 = *(const f32x4*)(wr + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[e] = fmaf(v, w0[e], acc[e]); acc[4 + e] = fmaf(v, w1[e], acc[4 + e]); }
+            }
+    const int co = q * 8;
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a0 = leaky(acc[2 * e] * scale[co + 2 * e] + bias[co + 2 * e], slope);
+        const float a1 = leaky(acc[2 * e + 1] * scale[co + 2 * e + 1] + bias[co + 2 * e + 1], slope);
+        hi[e] = Elem<T>::pack2(a0, a1);
+        lo[e] = Elem<T>::pack2(a0 - Elem<T>::lo(hi[e]), a1 - Elem<T>::hi(hi[e]));
+    }
+    uint16_t* yp = y + p * 2 * Cout + co;
+    *(uint4*)yp = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    *(uint4*)(yp + Cout) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
 extern "C" int yolo_stem_conv_fwd(const float* x_nchw, const float* w_oihw, const float* scale, const float* bias,
                                   void* y, int N, int H, int W, int Cin, int Cout, int dtype, float slope,
                                   void* stream) {
     if (!x_nchw || !w_oihw || !scale || !bias || !y || N <= 0 || H <= 0 || W <= 0) return YOLO_EINVAL;
     if (!(slope >= 0.f && slope <= 1.f)) return YOLO_EINVAL;
     if (Cin != 3 || Cout <= 0 || (Cout % 4) || Cout > 64) return YOLO_EUNSUPPORTED;
+    if (dtype == YOLO_BF16X3) {
+        if (Cout != 8 && Cout != 16 && Cout != 32 && Cout != 64) return YOLO_EUNSUPPORTED;
+        const int sh = Cout == 8 ? 0 : Cout == 16 ? 1 : Cout == 32 ? 2 : 3;
+        const long long total = ((long long)N * H * W) << sh;
+        if ((total + 255) / 256 > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
+        YOLO_LAUNCH(stem_split_kernel<bf16x3_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_nchw, w_oihw,
+                    scale, bias, (uint16_t*)y, H, W, Cout, sh, slope, total);
+        YOLO_LAUNCH_CHECK();
+        return YOLO_OK;
+    }
     if (dtype != YOLO_BF16 && dtype != YOLO_F16) return YOLO_EUNSUPPORTED;      // the fp32 path goes through the generic kernel
     const int tiles_x = (W + STEM_TW - 1) / STEM_TW, tiles_y = (H + STEM_TH - 1) / STEM_TH;
     const long long grid = (long long)N * tiles_x * tiles_y;

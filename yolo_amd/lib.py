@@ -11,8 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('YOLO_AMD_LIB') or os.path.join(CSRC, 'libyolo_amd.so')   # override: experiment builds
 
-F32, BF16, F16 = 0, 1, 2
-ABI_VERSION = 3            # include/yolo_amd.h: YOLO_ABI_VERSION (the struct layouts below are revision 3's)
+F32, BF16, F16, BF16X3 = 0, 1, 2, 3
+ABI_VERSION = 4            # include/yolo_amd.h: YOLO_ABI_VERSION (the struct layouts below are revision 4's)
 OK, EINVAL, EUNSUPPORTED = 0, -1, -2
 
 
@@ -43,7 +43,9 @@ class ConvDesc(C.Structure):
                 # fused tail 1x1 (include/yolo_amd.h: tail_*)
                 ('tail_w_packed', C.c_void_p), ('tail_scale', C.c_void_p), ('tail_bias', C.c_void_p), ('tail_y', C.c_void_p),
                 ('tail_cout', C.c_int), ('tail_out_f32', C.c_int), ('tail_slope', C.c_float),
-                ('tail_y_batch_stride', C.c_longlong), ('tail_y_pixel_stride', C.c_longlong)]
+                ('tail_y_batch_stride', C.c_longlong), ('tail_y_pixel_stride', C.c_longlong),
+                # YOLO_BF16X3: element offset of the lo plane inside a pixel of x / y (0 = dense)
+                ('x_lo_offset', C.c_longlong), ('y_lo_offset', C.c_longlong)]
 
 
 class GridDesc(C.Structure):

@@ -15,8 +15,13 @@ import torch
 from . import lib as L
 from .spec import NetGraph, BN_EPS, LEAKY_SLOPE, xavier_bound
 
-_TORCH_DT = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}
-_LIB_DT = {'bf16': L.BF16, 'f16': L.F16, 'f32': L.F32}
+_TORCH_DT = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32, 'bf16x3': torch.bfloat16}
+_LIB_DT = {'bf16': L.BF16, 'f16': L.F16, 'f32': L.F32, 'bf16x3': L.BF16X3}
+# 'bf16x3' (round 6): SPLIT bf16 -- every activation and weight is a (hi, lo) pair of bf16 numbers, every product three bf16 MFMAs
+# (include/yolo_amd.h: YOLO_BF16X3).  The path on which the north-star tolerance and the MFMA rate meet: decoded boxes within
+# 1e-3 of the fp32 oracle (~3e-4 on the random-BN D53 nets, tests/test_gpu_boxes.py) at ~1/3 of the bf16 path's speed, where
+# the exact-fp32 MFMA of dtype 'f32' runs at ~1/8.  A split activation is a (N, H, W, 2, C) bf16 tensor: plane 0 = hi, 1 = lo.
+_SPLIT = ('bf16x3',)
 
 
 class _Plan(object):
@@ -40,7 +45,7 @@ class CarNet(object):
         # num_sync_bn_devices is accepted for signature parity; the reference always passes -1
         # (no SyncBN, car/YOLO.py:94-96).
         if dtype not in _TORCH_DT:
-            raise ValueError('dtype must be bf16, f16 or f32')
+            raise ValueError('dtype must be bf16, f16, f32 or bf16x3')
         self.graph = NetGraph(spec)
         # 'f16' = the reference's own reduced precision (use_fp16 -> net.cast('float16'), car/YOLO.py:98-100; the executor's fp16
         # flag, yolo_gluon.py:204-214): fp16 activations and weights on v_mfma_f32_32x32x16_f16 -- the bf16 MFMA rate with three more
@@ -177,9 +182,12 @@ class CarNet(object):
         lib, st, dt = self._lib, L.stream_ptr(), _LIB_DT[self.dtype]
         for c in self.graph.convs():
             w = self.params[c.name + '.weight']
-            nbytes = lib.yolo_packed_weight_bytes(c.cout, c.cin, c.k, dt)
+            # (split types: the stem runs as a direct convolution on its OIHW weights -- yolo_stem_conv_fwd -- and has no packed image)
+            raw_stem = self.dtype in _SPLIT and c is self.graph.stem and c.cin == 3
+            nbytes = 0 if raw_stem else lib.yolo_packed_weight_bytes(c.cout, c.cin, c.k, dt)
             if nbytes < 0:
-                raise L.YoloError('unsupported conv %s' % c.name)
+                raise L.YoloError('unsupported conv %s%s' % (c.name, " (dtype 'bf16x3' needs input channels in multiples of 32)"
+                                                             if self.dtype in _SPLIT else ''))
             cp = lib.yolo_padded_channels(c.cout)
             if c.name in self._prepared:
                 wp, scale, bias = self._prepared[c.name]      # refreshed in place: the launch plans point at them
@@ -187,7 +195,8 @@ class CarNet(object):
                 wp = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
                 scale = torch.empty(cp, dtype=torch.float32, device=self.device)
                 bias = torch.empty(cp, dtype=torch.float32, device=self.device)
-            L.check(lib.yolo_pack_conv_weights(L.ptr(w), L.ptr(wp), c.cout, c.cin, c.k, dt, st), 'pack ' + c.name)
+            if not raw_stem:
+                L.check(lib.yolo_pack_conv_weights(L.ptr(w), L.ptr(wp), c.cout, c.cin, c.k, dt, st), 'pack ' + c.name)
             if c.bn:
                 p = lambda s: L.ptr(self.params[c.name + s])
                 L.check(lib.yolo_fold_bn(p('.gamma'), p('.beta'), p('.running_mean'), p('.running_var'),
@@ -204,6 +213,12 @@ class CarNet(object):
             self.prepare()
 
     # ---- plan construction --------------------------------------------------------------------------
+    def _act(self, N, H, W, Cc):
+        """An activation buffer of logical shape (N, H, W, C): NHWC in the net's element type; a split type (bf16x3) carries the
+        hi and lo planes of a pixel side by side -- (N, H, W, 2, C)."""
+        shape = (N, H, W, 2, Cc) if self.dtype in _SPLIT else (N, H, W, Cc)
+        return torch.empty(shape, dtype=_TORCH_DT[self.dtype], device=self.device)
+
     def _conv_op(self, plan, c, x, xshape, residual=None, out=None, out_f32=False, y_bs=0, y_ps=0, cin=None, x_ps=0, up2=False,
                  tail=None):
         """tail: (1x1 conv spec, its output tensor or pointer, out_f32, batch stride, pixel stride) computed by the same launch
@@ -211,7 +226,7 @@ class CarNet(object):
         N, H, W, _ = xshape
         ho, wo = c.out_hw(H, W)
         if out is None:
-            out = torch.empty((N, ho, wo, c.cout), dtype=_TORCH_DT[self.dtype], device=self.device)
+            out = self._act(N, ho, wo, c.cout)
             plan.buffers.append(out)
         d = self._conv_desc(c, x, xshape, out, residual, out_f32, y_bs, y_ps, cin, x_ps, up2)
         if tail is not None:
@@ -376,15 +391,20 @@ class CarNet(object):
     def _conv_desc(self, c, x, xshape, out, residual=None, out_f32=False, y_bs=0, y_ps=0, cin=None, x_ps=0, up2=False):
         N, H, W, _ = xshape
         wp, scale, bias = self._prepared[c.name]
-        if isinstance(x, torch.Tensor) and x.dim() == 4 and not x.is_contiguous():
-            # a channel slice of a wider NHWC buffer (the route half of a concat buffer)
-            if x.stride(3) != 1 or x.stride(1) != W * x.stride(2) or x.stride(0) != H * W * x.stride(2):
+        x_lo = y_lo = 0
+        if isinstance(x, torch.Tensor) and x.dim() >= 4 and not x.is_contiguous():
+            # a channel slice of a wider NHWC buffer (the route half of a concat buffer); split types: (N, H, W, 2, C) views
+            if x.stride(-1) != 1 or x.stride(1) != W * x.stride(2) or x.stride(0) != H * W * x.stride(2):
                 raise L.YoloError('unsupported input view for %s' % c.name)
             x_ps = x.stride(2)
-        if isinstance(out, torch.Tensor) and out.dim() == 4 and not out.is_contiguous():
-            if out.stride(3) != 1 or out.stride(1) != out.shape[2] * out.stride(2):
+            if x.dim() == 5:
+                x_lo = x.stride(3)
+        if isinstance(out, torch.Tensor) and out.dim() >= 4 and not out.is_contiguous():
+            if out.stride(-1) != 1 or out.stride(1) != out.shape[2] * out.stride(2):
                 raise L.YoloError('unsupported output view for %s' % c.name)
             y_ps, y_bs = out.stride(2), out.stride(0)
+            if out.dim() == 5:
+                y_lo = out.stride(3)
         d = L.ConvDesc()
         d.x, d.w_packed, d.scale, d.bias = L.ptr(x), L.ptr(wp), L.ptr(scale), L.ptr(bias)
         d.residual = L.ptr(residual)
@@ -395,6 +415,7 @@ class CarNet(object):
         d.slope = LEAKY_SLOPE if c.bn else 1.0
         d.y_batch_stride, d.y_pixel_stride = y_bs, y_ps
         d.x_pixel_stride, d.upsample2x = x_ps, 1 if up2 else 0
+        d.x_lo_offset, d.y_lo_offset = x_lo, y_lo
         return d
 
     def _measure_algo(self, d, iters=5, fn=None, algos=None, key_extra=()):
@@ -524,15 +545,19 @@ class CarNet(object):
                                            L.ptr(s2), L.ptr(b2), L.ptr(x), B, H, W, g.stem.cout, d0.cout), d0.name))
             plan.act[d0.name] = (x, shp)
             fused_down = d0
-        elif g.stem.cin == 3 and g.stem.cout % 4 == 0 and g.stem.cout <= 64 and self.dtype in ('bf16', 'f16'):
+        elif g.stem.cin == 3 and g.stem.k == 3 and g.stem.stride == 1 and g.stem.bn and (
+                (g.stem.cout % 4 == 0 and g.stem.cout <= 64 and self.dtype in ('bf16', 'f16')) or
+                (g.stem.cout in (8, 16, 32, 64) and self.dtype in _SPLIT)):
             # fused image-layout change + first conv (yolo_stem_conv_fwd): reads the NCHW image directly
             _, sscale, sbias = self._prepared[g.stem.name]
-            x = torch.empty((B, H, W, g.stem.cout), dtype=tdt, device=self.device)
+            x = self._act(B, H, W, g.stem.cout)
             shp = (B, H, W, g.stem.cout)
             plan.buffers.append(x)
             plan.ops.append(('stem', (L.ptr(self.params[g.stem.name + '.weight']), L.ptr(sscale), L.ptr(sbias),
                                       L.ptr(x), B, H, W, 3, g.stem.cout), g.stem.name))
             plan.act[g.stem.name] = (x, shp)
+        elif self.dtype in _SPLIT:
+            raise L.YoloError("dtype 'bf16x3' needs a 3 -> 8 / 16 / 32 / 64-channel 3x3 stem (use dtype='f32' for this spec)")
         else:
             plan.x_nhwc = torch.empty((B, H, W, 8), dtype=tdt, device=self.device)
             x, shp = self._conv_op(plan, g.stem, plan.x_nhwc, (B, H, W, 8), cin=8)
@@ -547,7 +572,7 @@ class CarNet(object):
                     and last_of_stage is not fused_down and not (res and self._res_block_eligible(res[-1][0], res[-1][1]))):
                 ho, wo = down.out_hw(shp[1], shp[2])
                 up_ch = g.transitions[t_idx].cout
-                cat = torch.empty((B, ho, wo, up_ch + last_of_stage.cout), dtype=tdt, device=self.device)
+                cat = self._act(B, ho, wo, up_ch + last_of_stage.cout)
                 plan.buffers.append(cat)
                 cats[i] = (cat, up_ch)
                 cat_view = cat[..., up_ch:]
@@ -614,8 +639,10 @@ class CarNet(object):
                 # every pixel to its 2x2 patch (nearest 2x up-sampling)
                 cat, up_ch = rcat
                 self._conv_op(plan, g.transitions[i], route, rshp, out=cat[..., :up_ch], up2=True)
-                x, shp = cat, tuple(cat.shape)
+                x, shp = cat, tuple(cat.shape[:3]) + (cat.shape[-1],)
                 continue
+            if self.dtype in _SPLIT:
+                raise L.YoloError("dtype 'bf16x3' needs fuse_concat=True (the up-sample + concat copy kernel takes single-plane types)")
             x, shp = self._conv_op(plan, g.transitions[i], route, rshp)
             cat = torch.empty((rs[0], rs[1], rs[2], shp[3] + rs[3]), dtype=tdt, device=self.device)
             plan.buffers.append(cat)
@@ -776,7 +803,7 @@ class CarNet(object):
         self.plan_kernels(B, H, W)
         plan = self._plans[(B, H, W)]
         by_name = {c.name: c for c in self.graph.convs()}
-        es = 2 if self.dtype != 'f32' else 4
+        es = 2 if self.dtype in ('bf16', 'f16') else 4       # (bf16x3: two 2-byte planes per value, weights as a hi + lo pair)
         out = {}
         for kind, d, name in plan.ops:
             if kind != 'conv':
@@ -822,6 +849,8 @@ class CarNet(object):
     def activation_nchw(self, name):
         """float32 NCHW copy of a named conv output of the last forward (parity taps)."""
         t, (N, H, W, Cc) = self._last_plan.act[name]
+        if self.dtype in _SPLIT:                              # (parity tap: value = hi + lo, exact in fp32)
+            return (t[..., 0, :].float() + t[..., 1, :].float()).permute(0, 3, 1, 2).contiguous()
         t = t.contiguous()                                   # (a channel slice of a concat buffer is a strided view)
         out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=self.device)
         L.check(self._lib.yolo_nhwc_to_nchw(L.ptr(t), L.ptr(out), N, Cc, H, W, _LIB_DT[self.dtype], L.stream_ptr()),
