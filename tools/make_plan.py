@@ -19,13 +19,21 @@ ap.add_argument('--out', default=plans.DEFAULT)
 ap.add_argument('--commit', default=None)
 ap.add_argument('--train-batches', default='64,32,128')
 ap.add_argument('--no-f32', action='store_true')
+ap.add_argument('--base', default=None, help='an existing plan file: its choices are kept, only shapes it does not hold are measured')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 torch.cuda.set_device(0)
 spec = darknet53_spec()
 states, shapes, t0 = [], [], time.time()
+base_workloads = []
+if a.base:
+    bstate, bmeta = plans.load(a.base)
+    states.append(bstate)
+    base_workloads = list(bmeta.get('workloads', []))
 
 net = CarNet(spec, dtype='bf16', device=dev, tune='measure').initialize(seed=1234)
+if states:
+    net.load_tuning_state(plans.merge(*states))
 net.prepare()
 for B, S in ((32, 416), (64, 608)):
     net.plan_signature(B, S, S)
@@ -36,6 +44,7 @@ del net
 torch.cuda.empty_cache()
 if not a.no_f32:
     net = CarNet(spec, dtype='f32', device=dev, tune='measure').initialize(seed=1234)
+    net.load_tuning_state(plans.merge(*states))
     net.prepare()
     net.plan_signature(32, 416, 416)
     states.append(net.tuning_state())
@@ -43,15 +52,17 @@ if not a.no_f32:
     print(shapes[-1], '%.0f s' % (time.time() - t0), flush=True)
     del net
     torch.cuda.empty_cache()
-net = CarNet(spec, dtype='f16', device=dev, tune='measure').initialize(seed=1234)
-net.prepare()
-for B, S in ((32, 416), (64, 608)):
-    net.plan_signature(B, S, S)
-    shapes.append('infer f16 %dx%d bs %d' % (S, S, B))
-    print(shapes[-1], '%.0f s' % (time.time() - t0), flush=True)
-states.append(net.tuning_state())
-del net
-torch.cuda.empty_cache()
+for dt in ('f16', 'bf16x3'):              # (bf16x3: the split bf16 parity path, bench.py's `parity_path` key and --dtype bf16x3)
+    net = CarNet(spec, dtype=dt, device=dev, tune='measure').initialize(seed=1234)
+    net.load_tuning_state(plans.merge(*states))
+    net.prepare()
+    for B, S in ((32, 416), (64, 608)):
+        net.plan_signature(B, S, S)
+        shapes.append('infer %s %dx%d bs %d' % (dt, S, S, B))
+        print(shapes[-1], '%.0f s' % (time.time() - t0), flush=True)
+    states.append(net.tuning_state())
+    del net
+    torch.cuda.empty_cache()
 for B in [int(v) for v in a.train_batches.split(',') if v]:
     net = CarNet(spec, dtype='bf16', device=dev, tune='measure').initialize(seed=1234)
     tr = Trainer(net, (416, 416))
@@ -64,7 +75,7 @@ for B in [int(v) for v in a.train_batches.split(',') if v]:
     del tr, net, x
     torch.cuda.empty_cache()
 state = plans.merge(*states)
-meta = {'commit': a.commit, 'workloads': shapes, 'device': torch.cuda.get_device_name(0), 'made': time.strftime('%Y-%m-%d %H:%M:%S'),
+meta = {'commit': a.commit, 'workloads': shapes, 'base': (a.base and os.path.basename(a.base)), 'base_workloads': base_workloads, 'device': torch.cuda.get_device_name(0), 'made': time.strftime('%Y-%m-%d %H:%M:%S'),
         'choices': {s: len(state[s]) for s in plans.SECTIONS}}
 plans.save(a.out, state, meta)
 print('wrote %s  md5 %s  %s' % (a.out, plans.md5(state), meta['choices']))
