@@ -97,6 +97,7 @@ class Trainer(object):
         # two BatchNorm workspaces used alternately (yolo_bn_train_*_pp: a call leaves its own dirty and zeroes the next one's)
         self.ws2 = [torch.zeros(2 * cmax, dtype=torch.float64, device=self.dev) for _ in range(2)]
         self._ws_i = 0
+        self.probe = None         # a list: _backward appends (family, layer, elements, start event, end event) per BatchNorm backward call
         self._bn3 = bool(L.lab_knob('YOLO_TRAIN_BN3'))      # (the knob: separate finalize launches, for A/B runs)
         self.ws = torch.zeros(2 * cmax, dtype=torch.float64, device=self.dev)
         wsb = max(self.lib.yolo_conv_wgrad_workspace_bytes(max(c.cin, 8), c.cout, c.k, self.ldt) for c in g.convs())
@@ -618,10 +619,18 @@ class Trainer(object):
                             'bn bwd (partials) ' + c.name)
                 else:
                     ws, wn = self._next_ws()
+                    pr = self.probe
+                    if pr is not None:                  # (measurement only, bench.py's training roofline: HIP events around the call)
+                        e0 = torch.cuda.Event(enable_timing=True)
+                        e0.record()
                     L.check(lib.yolo_bn_train_bwd_pp(L.ptr(dz), L.ptr(y.val), L.ptr(op['mean']), L.ptr(op['invstd']),
                                                      L.ptr(p[c.name + '.gamma']), L.ptr(p[c.name + '.beta']), L.ptr(dy),
                                                      L.ptr(self.gview[c.name + '.gamma']), L.ptr(self.gview[c.name + '.beta']),
                                                      ws, wn, self.ws2[0].numel(), npix, c.cout, LEAKY_SLOPE, self.ldt, st), 'bn bwd ' + c.name)
+                    if pr is not None:
+                        e1 = torch.cuda.Event(enable_timing=True)
+                        e1.record()
+                        pr.append(('bn_bwd', c.name, npix * c.cout, e0, e1))
                 if capture is not None:
                     capture[c.name] = dict(dz=dz.clone(), dy=dy)
                 if op['res'] is not None:
