@@ -29,10 +29,12 @@ extern "C" {
  * bf16 MFMA rate meet.  A value v is stored as TWO bf16 numbers, hi = bf16(v) and lo = bf16(v - hi) (16 significant bits), and every
  * product w * x of a convolution is taken as w_hi x_hi + w_hi x_lo + w_lo x_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
  * (three MFMAs per product; the exact-fp32 MFMA of YOLO_F32 is sixteen times slower than one).  Storage of an (N,H,W,C) activation:
- * per pixel the C hi values, then -- `lo offset` elements further (dense: C) -- the C lo values: dense pixel stride 2 * C elements of
- * 2 bytes.  Inference entry points only: yolo_packed_weight_bytes / yolo_pack_conv_weights (image [w_hi | w_hi | w_lo] over
- * 3 * Cin / 32 K-chunks), yolo_conv_fwd (Cin % 32 == 0, pipelined kernels; no stats / tail), yolo_stem_conv_fwd.  Everything else
- * returns YOLO_EUNSUPPORTED / YOLO_EINVAL for it. */
+ * per pixel a hi PLANE of Cp = round_up(C, 32) values (C real, the rest zero: whole 32-channel K-chunks), then -- `lo offset`
+ * elements further (dense: Cp) -- the lo plane: dense pixel stride 2 * Cp elements of 2 bytes.  The kernels never write the pad
+ * channels and read them as operands of zero weights: THE CALLER ZEROES A BUFFER WITH C % 32 != 0 ONCE (a NaN there would poison the
+ * sums).  Inference entry points only: yolo_packed_weight_bytes / yolo_pack_conv_weights (image [w_hi | w_hi | w_lo] over
+ * 3 * Cp / 32 K-chunks; Cin % 8 == 0), yolo_conv_fwd (pipelined kernels; Cout % 8 == 0 unless out_f32; no stats / tail),
+ * yolo_stem_conv_fwd.  Everything else returns YOLO_EUNSUPPORTED / YOLO_EINVAL for it. */
 #define YOLO_BF16X3 3
 
 #define YOLO_OK 0
@@ -139,10 +141,10 @@ typedef struct yolo_conv_desc {
     float tail_slope;
     long long tail_y_batch_stride;
     long long tail_y_pixel_stride;
-    /* YOLO_BF16X3 only (ignored otherwise): elements between a pixel's hi plane and its lo plane in x and in y; 0 = dense (Cin,
-     * Cout).  A channel slice of a wider split buffer of Ctot channels (the halves of a concat buffer, car/utils.py:93) has pixel
-     * stride 2 * Ctot and lo offset Ctot.  Dense strides of a split tensor count both planes (pixel stride 2 * C); the residual
-     * is dense; y_lo_offset is not used when out_f32. */
+    /* YOLO_BF16X3 only (ignored otherwise): elements between a pixel's hi plane and its lo plane in x and in y; 0 = dense
+     * (round_up(Cin, 32), round_up(Cout, 32)).  A channel slice of a wider split buffer of Ctot channels (the halves of a concat
+     * buffer, car/utils.py:93) has pixel stride 2 * Ctot and lo offset Ctot.  Dense strides of a split tensor count both padded
+     * planes (pixel stride 2 * round_up(C, 32)); the residual is dense; y_lo_offset is not used when out_f32. */
     long long x_lo_offset;
     long long y_lo_offset;
 } yolo_conv_desc;

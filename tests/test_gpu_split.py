@@ -6,8 +6,8 @@
     ref_conv_split) to a few units of the 16-bit storage, AND against the plain fp32 oracle at 2e-4;
   * the strided forms the net uses: a channel slice of a concat buffer as input, an up-sampled / sliced output, fp32 head logits;
   * the stem (direct fp32 convolution, split store);
-  * whole nets: the micro / test.yaml-width nets cannot run (their channel counts are not multiples of 32) and are refused loudly;
-    the D53 spec against the fp32 oracle's logits <= 1e-3 (tests/test_gpu_boxes.py holds the decoded boxes at 416 / 608).
+  * whole nets: the D53 spec, the reference's car/v1 spec at its native 320x512, test.yaml and the micro spec (8 / 16-channel maps:
+    padded planes) against the fp32 oracle's logits <= 1e-3 (tests/test_gpu_boxes.py holds the decoded boxes at 416 / 608).
 """
 import ctypes as C
 
@@ -37,6 +37,14 @@ CASES = [
     (2, 128, 38, 38, 256, 3, 2, False),
     (2, 64, 20, 20, 32, 1, 1, False),      # 1x1, two chunks per pass
     (2, 96, 16, 16, 64, 1, 1, False),      # 1x1, three chunks per pass: a two-chunk phase would straddle the passes
+    # planes padded to whole chunks (car/v1/spec.yaml's 16-channel maps, test.yaml's 8 / 16)
+    (2, 16, 24, 24, 32, 3, 1, True),
+    (2, 16, 20, 20, 32, 3, 2, False),
+    (1, 8, 16, 16, 16, 3, 2, False),
+    (2, 32, 16, 16, 16, 1, 1, False),      # padded OUTPUT planes
+    (2, 16, 12, 12, 8, 1, 1, False),
+    (2, 48, 13, 13, 64, 1, 1, False),
+    (2, 8, 16, 16, 16, 3, 1, True),        # padded input, output and residual
 ]
 ALGOS = [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 27, 28, 36, 37, 38, 39]
 
@@ -78,10 +86,11 @@ def test_split_conv_auto(lib, cuda, case):
 
 
 def test_split_refusals(lib, cuda):
-    """What the type does not cover fails loudly: K-chunks that are not whole (Cin % 32), the generic / streaming / split-K kernels,
+    """What the type does not cover fails loudly: channel counts that are not multiples of 8, the generic / streaming / split-K kernels,
     statistics and fused tails, the training entries."""
-    x, w, scale, bias, _ = _mk((1, 16, 8, 8, 32, 3, 1, False), 1)
-    assert lib.yolo_packed_weight_bytes(32, 16, 3, L.BF16X3) == L.EUNSUPPORTED
+    x, w, scale, bias, _ = _mk((1, 64, 13, 13, 20, 1, 1, False), 1)
+    run_conv(lib, cuda, x, w, scale, bias, 1, 0.1, 'bf16x3', expect_rc=L.EUNSUPPORTED)      # Cout % 8 (16-byte store pieces)
+    assert lib.yolo_packed_weight_bytes(32, 12, 3, L.BF16X3) == L.EUNSUPPORTED
     x, w, scale, bias, _ = _mk((1, 64, 13, 13, 64, 1, 1, False), 1)
     for algo in (1, 13, 30, 31, 26):
         run_conv(lib, cuda, x, w, scale, bias, 1, 0.1, 'bf16x3', algo=algo, expect_rc=L.EUNSUPPORTED)
@@ -144,25 +153,35 @@ def test_split_stem(lib, cuda):
         x = rng.random((N, 3, H, W), dtype=np.float32)
         w = (rng.standard_normal((Cout, 3, 3, 3)) / 5).astype(np.float32)
         sc, bi = rng.uniform(0.5, 1.5, Cout).astype(np.float32), (rng.standard_normal(Cout) * 0.1).astype(np.float32)
-        y = torch.full((N, H, W, 2, Cout), float('nan'), dtype=torch.bfloat16, device=cuda)
+        Cp = -(-Cout // 32) * 32
+        y = torch.zeros((N, H, W, 2, Cp), dtype=torch.bfloat16, device=cuda)
         t = lambda a: torch.from_numpy(a).to(cuda)
         xd, wd, sd, bd = t(x), t(w), t(sc), t(bi)
         L.check(lib.yolo_stem_conv_fwd(xd.data_ptr(), wd.data_ptr(), sd.data_ptr(), bd.data_ptr(), y.data_ptr(), N, H, W, 3, Cout,
                                        L.BF16X3, 0.1, st), 'stem')
         torch.cuda.synchronize()
         ref = ref_conv(x, w, sc, bi, 1, 0.1)
-        np.testing.assert_allclose(from_nhwc(y), ref, rtol=2e-5, atol=2e-5)   # exact fp32 products; the storage's 2^-17
+        np.testing.assert_allclose(from_nhwc(y)[:, :Cout], ref, rtol=2e-5, atol=2e-5)   # exact fp32 products; the storage's 2^-17
+        assert bool((y[..., Cout:] == 0).all())                                      # the planes' pad channels stay as the caller zeroed them
     assert lib.yolo_stem_conv_fwd(xd.data_ptr(), wd.data_ptr(), sd.data_ptr(), bd.data_ptr(), y.data_ptr(), 1, 8, 8, 3, 12,
                                   L.BF16X3, 0.1, st) == L.EUNSUPPORTED
 
 
-def test_split_net_refuses_narrow_specs(cuda):
+@pytest.mark.parametrize('which,size,B', [('micro', (64, 64), 3), ('test_yaml', (192, 256), 2), ('car_v1', (320, 512), 2)])
+def test_split_net_narrow_specs(cuda, which, size, B):
+    """Nets whose early maps have 8 / 16 channels -- the reference's own car/v1/spec.yaml at its native 320x512, yolo_modules/
+    test.yaml at 192x256 (basic_yolo.py:129-133), the micro spec: split planes are padded to whole 32-channel chunks.  Logits within
+    1e-3 of the fp32 oracle."""
     from yolo_amd.net import CarNet
-    spec = og.spec_micro()
+    spec = {'micro': og.spec_micro, 'test_yaml': og.spec_test_yaml, 'car_v1': og.spec_car_v1}[which]()
     g = og.build_graph(spec)
-    net = CarNet(spec, dtype='bf16x3', device=cuda).load_params(og.init_params(g, seed=0, bn='random'))
-    with pytest.raises(L.YoloError):
-        net(torch.rand((1, 3, 64, 64), device=cuda))
+    P = og.init_params(g, seed=0, bn='random')
+    x = np.random.default_rng(3).random((B, 3) + size, dtype=np.float32)
+    ref = [r.numpy() for r in of.forward_torch(g, P, x)]
+    net = CarNet(spec, dtype='bf16x3', device=cuda).load_params(P)
+    outs = net(torch.from_numpy(x).to(cuda))
+    for o, r in zip(outs, ref):
+        np.testing.assert_allclose(o.cpu().numpy(), r, rtol=0, atol=1e-3)
 
 
 @pytest.mark.parametrize('tune', ['auto', 'measure'])

@@ -56,8 +56,11 @@ def assert_plan_held(obj, state, what):
 
 def to_nhwc(x_nchw, dtype, dev):
     t = torch.from_numpy(np.ascontiguousarray(x_nchw)).to(dev).permute(0, 2, 3, 1).contiguous()
-    if dtype in SPLIT:                                   # (N, H, W, 2, C): plane 0 = hi, plane 1 = lo
-        return torch.stack(split_planes(t.float(), TDT[dtype]), dim=3).contiguous()
+    if dtype in SPLIT:                                   # (N, H, W, 2, Cp): plane 0 = hi, plane 1 = lo, each padded with zeros to whole 32-channel chunks
+        Cc = t.shape[-1]
+        out = torch.zeros(t.shape[:3] + (2, -(-Cc // 32) * 32), dtype=TDT[dtype], device=t.device)
+        out[..., :Cc] = torch.stack(split_planes(t.float(), TDT[dtype]), dim=3)
+        return out
     return t.to(TDT[dtype])
 
 
@@ -83,7 +86,7 @@ def run_conv(lib, dev, x, w, scale, bias, stride, slope, dtype, residual=None, o
     bi = torch.zeros(cp, device=dev); bi[:Cout] = torch.from_numpy(bias).to(dev)
     pad = k // 2
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    yshape = (N, Ho, Wo, 2, Cout) if (dtype in SPLIT and not out_f32) else (N, Ho, Wo, Cout)
+    yshape = (N, Ho, Wo, 2, -(-Cout // 32) * 32) if (dtype in SPLIT and not out_f32) else (N, Ho, Wo, Cout)
     y = torch.full(yshape, float('nan'), dtype=torch.float32 if out_f32 else TDT[dtype], device=dev)
     rd = to_nhwc(residual, dtype, dev) if residual is not None else None
     d = L.ConvDesc()
@@ -99,6 +102,9 @@ def run_conv(lib, dev, x, w, scale, bias, stride, slope, dtype, residual=None, o
     else:
         assert rc == expect_rc, 'yolo_conv_fwd rc=%d' % rc
     torch.cuda.synchronize()
+    if y.dim() == 5 and y.shape[-1] != Cout:
+        assert bool(torch.isnan(y[..., Cout:]).all()), 'the pad channels of a split plane were written'
+        y = y[..., :Cout]
     return from_nhwc(y)
 
 

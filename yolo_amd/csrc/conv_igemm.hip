@@ -370,7 +370,7 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
 // reference's batch sizes tile quantisation on the 13x13 / 26x26 maps costs more than any difference
 // between the variants' inner loops.  The per-variant factors are measured (tools/conv_bench.py).
 static int conv_auto_algo(const ConvArgs& a, int ks, int stride, int dtype, bool px_heavy = true) {
-    if ((a.Cin * elem_size(dtype)) % 64 || (ks == 1 && a.nchunks < 2)) return 1;
+    if ((!dtype_split(dtype) && (a.Cin * elem_size(dtype)) % 64) || (ks == 1 && a.nchunks < 2)) return 1;      // (split planes are padded to whole chunks)
     if (stride == 2) return ks == 3 ? (a.Cout > 128 ? 18 : 9) : 1;      // (18 = 10 with the 4-slot weight ring)
     struct V { int algo, bp, bc, bpc; float f; bool k1; };
     // (round 5: the pixel-heavy 3x3 tiles 27 / 28 -- ~40 % less L2 -> LDS weight stream per output, measured 0.5-3.4 % faster than
@@ -431,7 +431,9 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     const int planes = dtype_planes(d->dtype);
     if ((d->Cin * es) % 16) return YOLO_EUNSUPPORTED;                 // 16-byte K units
     if (!d->out_f32 && (d->Cout % 4)) return YOLO_EUNSUPPORTED;       // 4-channel store groups
-    if (split && ((d->Cin * es) % 64 || d->stats || d->tail_w_packed || (!d->out_f32 && (d->Cout % 8)))) return YOLO_EUNSUPPORTED;
+    if (split && (d->stats || d->tail_w_packed || (!d->out_f32 && (d->Cout % 8)))) return YOLO_EUNSUPPORTED;
+    // split tensors: each plane of a pixel is padded to whole 32-channel K-chunks (include/yolo_amd.h); the pad channels read zeros
+    const int cin_p = split ? round_up(d->Cin, 32) : d->Cin, cout_p = (split && !d->out_f32) ? round_up(d->Cout, 32) : d->Cout;
     const int pad = d->ksize / 2;
     ConvArgs a;
     a.x = (const char*)d->x;
@@ -444,31 +446,31 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     a.Ho = (d->H + 2 * pad - d->ksize) / d->stride + 1;
     a.Wo = (d->W + 2 * pad - d->ksize) / d->stride + 1;
     a.Cout_pad = round_up(d->Cout, YOLO_COUT_PAD);
-    a.nchunks = (d->Cin * es + 63) / 64 * dtype_kpasses(d->dtype);
+    a.nchunks = (cin_p * es + 63) / 64 * dtype_kpasses(d->dtype);
     a.out_f32 = d->out_f32;
     a.d2s = 0;
     a.halo_strict = 0;
     a.up2 = d->upsample2x ? 1 : 0;
-    if (d->x_pixel_stride < 0 || (d->x_pixel_stride && d->x_pixel_stride < (long long)d->Cin * planes) || d->x_pixel_stride > 0x7fffffffLL) return YOLO_EINVAL;
-    a.x_ps = d->x_pixel_stride ? (int)d->x_pixel_stride : d->Cin * planes;
+    if (d->x_pixel_stride < 0 || (d->x_pixel_stride && d->x_pixel_stride < (long long)cin_p * planes) || d->x_pixel_stride > 0x7fffffffLL) return YOLO_EINVAL;
+    a.x_ps = d->x_pixel_stride ? (int)d->x_pixel_stride : cin_p * planes;
     a.x3_n = 0; a.x3_adj1 = 0; a.x3_adj2 = 0; a.y_lo = 0; a.r_lo = 0;
     if (split) {
-        const long long xlo = d->x_lo_offset ? d->x_lo_offset : d->Cin;
-        const long long ylo = d->y_lo_offset ? d->y_lo_offset : d->Cout;
-        if (xlo < d->Cin || xlo + d->Cin > a.x_ps || (xlo * es) % 16) return YOLO_EINVAL;
+        const long long xlo = d->x_lo_offset ? d->x_lo_offset : cin_p;
+        const long long ylo = d->y_lo_offset ? d->y_lo_offset : cout_p;
+        if (xlo < cin_p || xlo + d->Cin > a.x_ps || (xlo * es) % 16) return YOLO_EINVAL;
         if (!d->out_f32 && (ylo < d->Cout || (ylo * es) % 16)) return YOLO_EINVAL;      // (fp32 logits are not split: y_lo unused)
-        a.x3_n = d->Cin * es / 64;
+        a.x3_n = cin_p * es / 64;
         a.x3_adj1 = (int)(xlo * es) - a.x3_n * 64;
         a.x3_adj2 = -a.x3_n * 64 - (int)(xlo * es);
-        a.y_lo = ylo; a.r_lo = d->Cout;
+        a.y_lo = ylo; a.r_lo = cout_p;
     }
     if ((a.x_ps * es) % 16) return YOLO_EUNSUPPORTED;                 // 16-byte aligned pixel rows
     a.slope = d->slope;
     const int oplanes = d->out_f32 ? 1 : planes;                          // (fp32 logits are not split)
-    a.y_ps = d->y_pixel_stride ? d->y_pixel_stride : d->Cout * oplanes;
+    a.y_ps = d->y_pixel_stride ? d->y_pixel_stride : cout_p * oplanes;
     if (split && !d->out_f32 && a.y_lo + d->Cout > a.y_ps) return YOLO_EINVAL;
     a.y_bs = d->y_batch_stride ? d->y_batch_stride : (long long)a.Ho * a.Wo * a.y_ps * (a.up2 ? 4 : 1);
-    a.r_ps = d->Cout * planes; a.r_bs = (long long)a.Ho * a.Wo * a.r_ps;  // the residual is dense
+    a.r_ps = cout_p * planes; a.r_bs = (long long)a.Ho * a.Wo * a.r_ps;  // the residual is dense
     if (a.res && d->out_f32) return YOLO_EUNSUPPORTED;
     if (a.up2 && (a.res || d->out_f32)) return YOLO_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -636,7 +638,7 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ w, T* __restr
     // split types: three passes over the input channels -- chunks [w_hi | w_hi | w_lo] against the kernel's [x_hi | x_lo | x_hi]
     int pass = 0;
     if constexpr (IsSplit<T>::value) {
-        const int n = Cin / CH;              // (the host checks Cin % 32 == 0)
+        const int n = (Cin + CH - 1) / CH;   // (chunks per pass: the planes are padded to whole chunks, the pad channels' weights are zero)
         pass = chunk / n;
         chunk -= pass * n;
     }
@@ -808,7 +810,7 @@ extern "C" int yolo_pack_conv_weights_pairs(const void* items_device, const long
 extern "C" long long yolo_packed_weight_bytes(int Cout, int Cin, int ksize, int dtype) {
     if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 2 && ksize != 3)) return YOLO_EINVAL;
     if (!dtype_valid(dtype)) return YOLO_EINVAL;
-    if (dtype_split(dtype) && ((Cin * elem_size(dtype)) % 64 || ksize == 2)) return YOLO_EUNSUPPORTED;
+    if (dtype_split(dtype) && ((Cin % 8) || ksize == 2)) return YOLO_EUNSUPPORTED;
     const int nchunks = (Cin * elem_size(dtype) + 63) / 64 * dtype_kpasses(dtype);
     return (long long)nchunks * ksize * ksize * round_up(Cout, YOLO_COUT_PAD) * 64;
 }

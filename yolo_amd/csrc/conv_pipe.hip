@@ -1024,7 +1024,7 @@ int conv_pipe_dispatch_c(ConvArgs& a, int ks, int stride, int dtype, int algo, h
 int conv_pipe_dispatch(ConvArgs& a, int ks, int stride, int dtype, int algo, hipStream_t st, const NameOut* nm) {
     if ((ks != 1 && ks != 2 && ks != 3) || (stride != 1 && !(ks == 3 && stride == 2))) return YOLO_EUNSUPPORTED;
     if (a.d2s && ks != 2) return YOLO_EUNSUPPORTED;
-    if ((a.Cin * elem_size(dtype)) % 64) return YOLO_EUNSUPPORTED;
+    if (!dtype_split(dtype) && (a.Cin * elem_size(dtype)) % 64) return YOLO_EUNSUPPORTED;      // (split planes are padded to whole chunks by the caller)
     if (ks == 1 && a.nchunks < 2) return YOLO_EUNSUPPORTED;     // a 1x1 needs >= 2 phases; a 3x3 has 9 per chunk
     if ((long long)a.N * a.H * a.W * a.x_ps * elem_size(dtype) >= 0xffffff00LL) return YOLO_EUNSUPPORTED;
     if (dtype == YOLO_BF16) return pipe_dispatch_t<bf16_t>(a, ks, stride, algo, st, nm);

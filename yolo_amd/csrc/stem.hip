@@ -202,7 +202,8 @@ extern "C" int yolo_stem_conv_fwd_stats(const float* x_nchw, const float* w_oihw
 // K = 27: three MFMA passes over a K padded to 32 would buy nothing, and exact fp32 products cost the stem ~0.1 ms at 416x416 bs 32
 // against the ~12 ms of the split pass.  A thread owns 8 couts of one pixel (Cout / 8 adjacent lanes share a pixel: their image
 // loads are one request), the 27 x Cout weights sit in LDS as [tap][cout], and the output leaves split: hi = round(v),
-// lo = round(v - hi) at +Cout elements (dense (N,H,W,[hi | lo]): a wave writes whole 16-byte pieces of consecutive pixels).
+// lo = round(v - hi) one padded plane (round_up(Cout, 32) elements) further (dense split layout: a wave writes whole 16-byte pieces of
+// consecutive pixels).
 template <typename T>
 __global__ __launch_bounds__(256) void stem_split_kernel(const float* __restrict__ x, const float* __restrict__ w_oihw,
                                                          const float* __restrict__ scale, const float* __restrict__ bias,
@@ -249,9 +250,10 @@ __global__ __launch_bounds__(256) void stem_split_kernel(const float* __restrict
         hi[e] = Elem<T>::pack2(a0, a1);
         lo[e] = Elem<T>::pack2(a0 - Elem<T>::lo(hi[e]), a1 - Elem<T>::hi(hi[e]));
     }
-    uint16_t* yp = y + p * 2 * Cout + co;
+    const int Cp = round_up(Cout, 32);                      // (a split plane is padded to whole 32-channel chunks; the pad stays as the caller zeroed it)
+    uint16_t* yp = y + p * 2 * Cp + co;
     *(uint4*)yp = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-    *(uint4*)(yp + Cout) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    *(uint4*)(yp + Cp) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
 extern "C" int yolo_stem_conv_fwd(const float* x_nchw, const float* w_oihw, const float* scale, const float* bias,

@@ -186,7 +186,7 @@ class CarNet(object):
             raw_stem = self.dtype in _SPLIT and c is self.graph.stem and c.cin == 3
             nbytes = 0 if raw_stem else lib.yolo_packed_weight_bytes(c.cout, c.cin, c.k, dt)
             if nbytes < 0:
-                raise L.YoloError('unsupported conv %s%s' % (c.name, " (dtype 'bf16x3' needs input channels in multiples of 32)"
+                raise L.YoloError('unsupported conv %s%s' % (c.name, " (dtype 'bf16x3' needs channel counts in multiples of 8)"
                                                              if self.dtype in _SPLIT else ''))
             cp = lib.yolo_padded_channels(c.cout)
             if c.name in self._prepared:
@@ -216,8 +216,13 @@ class CarNet(object):
     def _act(self, N, H, W, Cc):
         """An activation buffer of logical shape (N, H, W, C): NHWC in the net's element type; a split type (bf16x3) carries the
         hi and lo planes of a pixel side by side -- (N, H, W, 2, C)."""
-        shape = (N, H, W, 2, Cc) if self.dtype in _SPLIT else (N, H, W, Cc)
-        return torch.empty(shape, dtype=_TORCH_DT[self.dtype], device=self.device)
+        if self.dtype not in _SPLIT:
+            return torch.empty((N, H, W, Cc), dtype=_TORCH_DT[self.dtype], device=self.device)
+        # a split plane holds whole 32-channel K-chunks (include/yolo_amd.h): C real channels + zero pad the kernels never write
+        Cp = -(-Cc // 32) * 32
+        if Cp == Cc:
+            return torch.empty((N, H, W, 2, Cc), dtype=_TORCH_DT[self.dtype], device=self.device)
+        return torch.zeros((N, H, W, 2, Cp), dtype=_TORCH_DT[self.dtype], device=self.device)[..., :Cc]
 
     def _conv_op(self, plan, c, x, xshape, residual=None, out=None, out_f32=False, y_bs=0, y_ps=0, cin=None, x_ps=0, up2=False,
                  tail=None):
