@@ -868,6 +868,20 @@ def main():
                               'frac_of_bf16_peak_executed': round(3 * flx3 * vx3 / 1e12 / MFMA_PEAK_TFLOPS['bf16'], 4),
                               'vs_f32_path': round(vx3 / v32, 2),
                               'plan': plan_report(args, netx3.tuning_state()) if args.plan_state is not None else None}
+        if world == 1 and not args.no_northstar:
+            # ... and BASELINE configs[4]'s per-GPU shape on the same path: 608x608 bs 64 + decode + per-class NMS, inside the tolerance
+            size6, B6 = (608, 608), 64
+            det6x = Detector(spec, size6, netx3.graph.steps(), device=dev)
+            x6x = torch.rand((B6, 3) + size6, generator=gen).to(dev)
+            k6x = max(args.steps // 2, 5)
+            el6x = timed_pass(netx3, det6x, x6x, 'nms', k6x, 2, fence)[0]
+            v6x = B6 * k6x / el6x
+            fl6x = netx3.graph.flops(*size6)
+            out['parity_path']['northstar_608_nms'] = {'workload': 'D53 spec forward 608x608 bs=64 + decode/per-class NMS, dtype bf16x3',
+                                                       'value': round(v6x, 2), 'unit': 'images/s', 'steps': k6x, 'ms_per_step': round(el6x / k6x * 1e3, 4),
+                                                       'net_tflops': round(fl6x * v6x / 1e12, 1),
+                                                       'frac_of_bf16_peak_executed': round(3 * fl6x * v6x / 1e12 / MFMA_PEAK_TFLOPS['bf16'], 4)}
+            del x6x, det6x
         net32 = netx3
         # ... and the reference's own reduced precision (use_fp16, car/YOLO.py:98-100) on the same workload: the bf16 MFMA rate minus
         # what the power cap takes, 12x closer to the fp32 oracle on the decoded boxes (cpu_baseline.box_parity)

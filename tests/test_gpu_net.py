@@ -189,7 +189,9 @@ def _lp_spec():
     return spec
 
 
-def test_carlpnet_f32_vs_oracle(cuda):
+@pytest.mark.parametrize('dtype', ['f32', 'bf16x3'])
+def test_carlpnet_f32_vs_oracle(cuda, dtype):
+    """(bf16x3: the split bf16 parity path holds the same 1e-3 on the car logits and the LP branch, car_and_LP/YOLO.py:47-95)"""
     from yolo_amd.net import CarLPNet
     from yolo_amd.detect import predict_LP_batch
     from oracle import detect as od
@@ -197,7 +199,7 @@ def test_carlpnet_f32_vs_oracle(cuda):
     g = og.build_graph(spec)
     P = og.init_params(g, seed=3, bn='random')
     x = np.random.default_rng(4).random((3, 3) + size, dtype=np.float32)
-    net = CarLPNet(spec, dtype='f32', device=cuda).load_params(P)
+    net = CarLPNet(spec, dtype=dtype, device=cuda).load_params(P)
     outs, lp = net(torch.from_numpy(x).to(cuda))
     routs, rlp = of.forward_torch(g, P, x)
     assert lp[0].shape == tuple(rlp[0].shape) == (3, 8, 12, 10)

@@ -8,8 +8,8 @@
 #   one PMC pass (MFMA busy, GUI active, wave cycles)            -> _pmc_mfma.json          bench line last (traffic filled in)
 # then the training step: bench line + kernel stats.
 set -u
-TAG=${1:-r05}
-PT=${2:-r05}
+TAG=${1:-r06}
+PT=${2:-r06}
 OUT=gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -38,6 +38,24 @@ python bench.py --mode train --steps 20 --warmup 3 > $OUT/${PT}_train_bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_train -o p -- python bench.py --mode train --steps 10 --warmup 2 > $OUT/${PT}_train_bench_profiled.json 2>> $ERR
 cp $OUT/${TAG}_prof_train/p_kernel_stats.csv $OUT/${PT}_train_kernel_stats.csv 2>/dev/null
 rm -rf $OUT/${TAG}_prof_train
+# (round 6) the training step's counters: HBM traffic per kernel (two passes) and MFMA-busy, 1 warm-up + 3 steps each; bench.py's
+# train_416_bs64.roofline.traffic sums the BatchNorm-backward kernels of profiles/*_train_pmc_traffic.json
+MD5T=$(python -c "import sys,json; print(json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])['plan']['state_md5'])" $OUT/${PT}_train_bench_profiled.json)
+TR="--mode train --steps 3 --warmup 1 --no-roofline"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_tf -o p -- python bench.py $TR > /dev/null 2>> $ERR
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_tw -o p -- python bench.py $TR > /dev/null 2>> $ERR
+python tools/pmc_traffic.py $OUT/${TAG}_pmc_tf $OUT/${TAG}_pmc_tw 64 416 $OUT/${PT}_train_pmc_traffic.json $MD5T 4 >> $OUT/${TAG}_pmc_summary.txt 2>&1
+cp $OUT/${PT}_train_pmc_traffic.json profiles/${PT}_train_pmc_traffic.json
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_tm -o p -- python bench.py $TR > /dev/null 2>> $ERR
+python tools/pmc_mfma.py $OUT/${TAG}_pmc_tm $OUT/${PT}_train_pmc_mfma.json >> $OUT/${TAG}_pmc_summary.txt 2>&1
+rm -rf $OUT/${TAG}_pmc_tf $OUT/${TAG}_pmc_tw $OUT/${TAG}_pmc_tm
+cp $OUT/${TAG}_pmc_summary.txt $OUT/${PT}_pmc_summary.txt
+python bench.py --mode train --steps 20 --warmup 3 > $OUT/${PT}_train_bench.json 2>> $ERR        # (again: now with roofline.traffic)
+# (round 6) the split bf16 parity path (dtype bf16x3) on the headline workload: kernel trace + bench line
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_x3 -o p -- python bench.py --dtype bf16x3 --steps 20 --warmup 3 $LEAN > $OUT/${PT}_bench_x3_profiled.json 2>> $ERR
+cp $OUT/${TAG}_prof_x3/p_kernel_stats.csv $OUT/${PT}_x3_kernel_stats.csv 2>/dev/null
+rm -rf $OUT/${TAG}_prof_x3
+python bench.py --dtype bf16x3 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${PT}_bench_x3.json 2>> $ERR
 python bench.py --steps 20 --warmup 5 > $OUT/${PT}_bench.json 2>> $ERR
 ls -la $OUT | grep ${PT}_
 tail -c 1500 $OUT/${PT}_bench.json
