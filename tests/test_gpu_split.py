@@ -46,7 +46,7 @@ CASES = [
     (2, 48, 13, 13, 64, 1, 1, False),
     (2, 8, 16, 16, 16, 3, 1, True),        # padded input, output and residual
 ]
-ALGOS = [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 27, 28, 36, 37, 38, 39]
+ALGOS = [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 27, 28, 36, 37, 38, 39, 40, 41]
 
 
 def _mk(case, seed):

@@ -20,6 +20,7 @@ ap.add_argument('--commit', default=None)
 ap.add_argument('--train-batches', default='64,32,128')
 ap.add_argument('--no-f32', action='store_true')
 ap.add_argument('--base', default=None, help='an existing plan file: its choices are kept, only shapes it does not hold are measured')
+ap.add_argument('--remeasure', default='', help="comma-separated dtypes whose forward choices of --base are dropped and measured again (e.g. 'bf16x3' after new variants for it)")
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 torch.cuda.set_device(0)
@@ -28,6 +29,10 @@ states, shapes, t0 = [], [], time.time()
 base_workloads = []
 if a.base:
     bstate, bmeta = plans.load(a.base)
+    from yolo_amd import lib as L_
+    drop = {{'f32': L_.F32, 'bf16': L_.BF16, 'f16': L_.F16, 'bf16x3': L_.BF16X3}[d_] for d_ in a.remeasure.split(',') if d_}
+    # (a forward conv key is (N, H, W, Cin, Cout, ksize, stride, out_f32, residual, dtype, ...): plans of net.py _measure_algo)
+    bstate['algo'] = {k: v for k, v in bstate['algo'].items() if not (isinstance(k[0], int) and len(k) >= 10 and k[9] in drop)}
     states.append(bstate)
     base_workloads = list(bmeta.get('workloads', []))
 

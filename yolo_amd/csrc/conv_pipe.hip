@@ -928,6 +928,9 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
             // probe that drops the weight DMAs (wrong results, timing only: tools/ab_kloop.sh) runs these kernels 8-12 % faster.
             case 27: return launch_pipe<T, 3, 4, 2, 2, 3, 768>(a, st, nm);     // 8 waves, 384 px x 128 cout (wave tile 96x64)
             case 28: return launch_pipe<T, 3, 4, 2, 2, 4, 1024>(a, st, nm);    // 8 waves, 512 px x 128 cout (wave tile 128x64)
+            case 41:                                                            // (split type: 64-cout tiles, see algo 40)
+                if constexpr (IsSplit<T>::value) return launch_pipe<T, 3, 4, 1, 2, 2, 512>(a, st, nm);      // 4 waves, 256 px x 64 cout
+                break;
             case 26:                                                            // 4 waves, 256 px x 256 cout (wave tile 128x128)
                 // (not for the split type: beside the split epilogue's second plane the 256-register accumulator spills)
                 if constexpr (sizeof(T) == 2 && !IsSplit<T>::value) return launch_pipe<T, 3, 2, 2, 4, 4, 512>(a, st, nm);
@@ -976,6 +979,14 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
             case 8: YOLO_PIPE1(2, 2, 2, 3, 192)
             case 11: YOLO_PIPE1(2, 2, 2, 1, 64)
             case 12: YOLO_PIPE1(1, 4, 2, 2, 64)
+            // (round 6, split type only) 64-cout tiles for the first stages' 32- / 64-channel layers: every other variant stages >= 128
+            // weight rows per phase, and on the split path -- where these layers are not covered by the fused stem / residual-block /
+            // streaming kernels of the 2-byte paths -- a 1x1 64 -> 32 at 208x208 moved twice its input bytes in zero weight rows
+            // (567 us against an HBM floor of ~120).  41: the 3x3 stride-1 sibling (a stride-2 one would need more than one input DMA per
+            // phase: the halo of 128 output pixels does not fit the 576 slots four waves can stage).
+            case 40:
+                if constexpr (IsSplit<T>::value) YOLO_PIPE1(4, 1, 2, 2, 256)        // 4 waves, 256 px x 64 cout
+                break;
 #undef YOLO_PIPE1
             // deep-ring variants (one block per CU, 5-7 phases of loads in flight; generic loop)
             case 19: return launch_pipe<T, 1, 1, 4, 2, 2, 64, 1, 7>(a, st, nm);      // 64 px x 256 cout

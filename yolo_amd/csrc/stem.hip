@@ -208,39 +208,55 @@ template <typename T>
 __global__ __launch_bounds__(256) void stem_split_kernel(const float* __restrict__ x, const float* __restrict__ w_oihw,
                                                          const float* __restrict__ scale, const float* __restrict__ bias,
                                                          uint16_t* __restrict__ y, int H, int W, int Cout, int tpp_shift, float slope,
-                                                         long long total) {
+                                                         int tiles_x, int tiles_y) {
+    // A block = 16 columns x TH rows of one image (256 threads = 256 >> tpp_shift pixels x Cout / 8 threads per pixel).  The input
+    // tile + halo is staged in LDS once (the first version read its 27 inputs per thread from global memory: 9.3 M wave-wide load
+    // instructions per bs-32 pass through the address unit -- 700 us, 6 % of the split pass; staged: one or two loads per thread).
+    constexpr int TW = 16, XP = TW + 2 + 1;                 // padded pitch
     __shared__ __attribute__((aligned(16))) float wl[27 * 64];
-    for (int i = threadIdx.x; i < 27 * Cout; i += 256) {
+    __shared__ float xs[3 * 18 * XP];
+    const int TH = 16 >> tpp_shift;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 27 * Cout; i += 256) {
         const int tap = i / Cout, co = i - tap * Cout;
         wl[i] = w_oihw[co * 27 + tap];                      // OIHW: [co][c][kh][kw] -> [c * 9 + kh * 3 + kw][co]
     }
-    __syncthreads();
-    const long long g = blockIdx.x * 256LL + threadIdx.x;
-    if (g >= total) return;
-    const long long p = g >> tpp_shift;
-    const int q = (int)(g & ((1 << tpp_shift) - 1));
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const long long n = b / tiles_y;
     const long long HW = (long long)H * W;
-    const long long n = p / HW;
-    const int r = (int)(p - n * HW);
-    const int yy = r / W, xx = r - yy * W;
+    const float* xn = x + n * 3 * HW;
+    const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+    for (int i = tid; i < 3 * (TH + 2) * (TW + 2); i += 256) {
+        const int c = i / ((TH + 2) * (TW + 2)), r_ = i - c * (TH + 2) * (TW + 2);
+        const int r = r_ / (TW + 2), col = r_ - r * (TW + 2);
+        const int iy = y0 + r, ix = x0 + col;
+        const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        // (unconditional load from a clamped address, masked afterwards: a predicated load serialises on vmcnt(0), NOTES 4.2)
+        const float v = xn[c * HW + (long long)min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1)];
+        xs[(c * 18 + r) * XP + col] = in ? v : 0.f;
+    }
+    __syncthreads();
+    const int lp = tid >> tpp_shift, q = tid & ((1 << tpp_shift) - 1);
+    const int ly = lp >> 4, lx = lp & 15;
+    const int yy = ty * TH + ly, xx = tx * TW + lx;
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    const float* xn = x + n * 3 * HW;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const int iy = yy + kh - 1, ix = xx + kw - 1;
-                const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
-                const float v = in ? xn[c * HW + (long long)iy * W + ix] : 0.f;
+                const float v = xs[(c * 18 + ly + kh) * XP + lx + kw];
                 const float* wr = wl + (c * 9 + kh * 3 + kw) * Cout + q * 8;
                 const f32x4 w0 = *(const f32x4*)wr, w1 = *(const f32x4*)(wr + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { acc[e] = fmaf(v, w0[e], acc[e]); acc[4 + e] = fmaf(v, w1[e], acc[4 + e]); }
             }
+    if (yy >= H || xx >= W) return;
     const int co = q * 8;
     uint32_t hi[4], lo[4];
 #pragma unroll
@@ -251,7 +267,7 @@ __global__ __launch_bounds__(256) void stem_split_kernel(const float* __restrict
         lo[e] = Elem<T>::pack2(a0 - Elem<T>::lo(hi[e]), a1 - Elem<T>::hi(hi[e]));
     }
     const int Cp = round_up(Cout, 32);                      // (a split plane is padded to whole 32-channel chunks; the pad stays as the caller zeroed it)
-    uint16_t* yp = y + p * 2 * Cp + co;
+    uint16_t* yp = y + ((n * H + yy) * W + xx) * 2 * Cp + co;
     *(uint4*)yp = make_uint4(hi[0], hi[1], hi[2], hi[3]);
     *(uint4*)(yp + Cp) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
@@ -265,10 +281,11 @@ extern "C" int yolo_stem_conv_fwd(const float* x_nchw, const float* w_oihw, cons
     if (dtype == YOLO_BF16X3) {
         if (Cout != 8 && Cout != 16 && Cout != 32 && Cout != 64) return YOLO_EUNSUPPORTED;
         const int sh = Cout == 8 ? 0 : Cout == 16 ? 1 : Cout == 32 ? 2 : 3;
-        const long long total = ((long long)N * H * W) << sh;
-        if ((total + 255) / 256 > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
-        YOLO_LAUNCH(stem_split_kernel<bf16x3_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_nchw, w_oihw,
-                    scale, bias, (uint16_t*)y, H, W, Cout, sh, slope, total);
+        const int th = 16 >> sh, tiles_x_ = (W + 15) / 16, tiles_y_ = (H + th - 1) / th;
+        const long long nblk = (long long)N * tiles_x_ * tiles_y_;
+        if (nblk > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
+        YOLO_LAUNCH(stem_split_kernel<bf16x3_t>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x_nchw, w_oihw,
+                    scale, bias, (uint16_t*)y, H, W, Cout, sh, slope, tiles_x_, tiles_y_);
         YOLO_LAUNCH_CHECK();
         return YOLO_OK;
     }
