@@ -45,8 +45,15 @@ CASES = [
     (2, 16, 12, 12, 8, 1, 1, False),
     (2, 48, 13, 13, 64, 1, 1, False),
     (2, 8, 16, 16, 16, 3, 1, True),        # padded input, output and residual
+    # prime widths / tiny maps: no strip of the pipelined kernels fits -- the generic kernel (algo 1; algo 0 falls back to it)
+    (2, 64, 9, 31, 128, 3, 1, True),
+    (3, 32, 21, 37, 64, 3, 1, False),
+    (1, 128, 30, 47, 64, 3, 1, False),
+    (2, 64, 7, 43, 64, 3, 2, False),
+    (2, 40, 5, 11, 24, 1, 1, False),
+    (1, 72, 1, 1, 48, 3, 1, False),
 ]
-ALGOS = [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 27, 28, 36, 37, 38, 39, 40, 41]
+ALGOS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 27, 28, 36, 37, 38, 39, 40, 41]
 
 
 def _mk(case, seed):
@@ -86,13 +93,13 @@ def test_split_conv_auto(lib, cuda, case):
 
 
 def test_split_refusals(lib, cuda):
-    """What the type does not cover fails loudly: channel counts that are not multiples of 8, the generic / streaming / split-K kernels,
+    """What the type does not cover fails loudly: channel counts that are not multiples of 8, the streaming / split-K kernels,
     statistics and fused tails, the training entries."""
     x, w, scale, bias, _ = _mk((1, 64, 13, 13, 20, 1, 1, False), 1)
     run_conv(lib, cuda, x, w, scale, bias, 1, 0.1, 'bf16x3', expect_rc=L.EUNSUPPORTED)      # Cout % 8 (16-byte store pieces)
     assert lib.yolo_packed_weight_bytes(32, 12, 3, L.BF16X3) == L.EUNSUPPORTED
     x, w, scale, bias, _ = _mk((1, 64, 13, 13, 64, 1, 1, False), 1)
-    for algo in (1, 13, 30, 31, 26):
+    for algo in (13, 30, 31, 26):
         run_conv(lib, cuda, x, w, scale, bias, 1, 0.1, 'bf16x3', algo=algo, expect_rc=L.EUNSUPPORTED)
     assert lib.yolo_pack_batch_blocks(64, 64, 3, L.BF16X3) == L.EUNSUPPORTED
     assert lib.yolo_conv_wgrad_workspace_bytes(64, 64, 3, L.BF16X3) == L.EINVAL

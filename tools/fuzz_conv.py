@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 from yolo_amd import lib as L
 from yolo_amd.net import CarNet
-from util import run_conv, ref_conv
+from util import run_conv, ref_conv, ref_conv_split
 lib = L.load(); dev = torch.device('cuda:0')
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 ALGOS = (0,) + tuple(CarNet.ALGOS)
@@ -28,8 +28,13 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 120:
     scale = (0.5 + rng.random(cout)).astype(np.float32); bias = (0.2 * rng.standard_normal(cout)).astype(np.float32)
     pad = k // 2; Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
     r = rng.standard_normal((N, cout, Ho, Wo)).astype(np.float32) if res else None
-    dt = 'f32' if rng.random() < 0.25 else 'bf16'
-    want = ref_conv(x, w, scale, bias, s, slope, residual=r, bf16=(dt == 'bf16'))
+    u = rng.random()
+    dt = 'f32' if u < 0.2 else ('bf16x3' if u < 0.55 else 'bf16')      # (bf16x3, round 6: against the split arithmetic restated on the CPU)
+    if dt == 'bf16x3':
+        if cin % 8 or cout % 8: continue
+        want = ref_conv_split(x, w, scale, bias, s, slope, residual=r)
+    else:
+        want = ref_conv(x, w, scale, bias, s, slope, residual=r, bf16=(dt == 'bf16'))
     ncase += 1
     for algo in ALGOS:
         try:
@@ -42,7 +47,7 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 120:
         nrun += 1
         if np.isnan(got).any():
             bad.append(('NaN (unwritten output)', algo, (N, cin, H, W, cout, k, s, res, slope))); continue
-        err = np.abs(got - want); tol = (0.02 if dt == 'bf16' else 2e-4) * np.maximum(np.abs(want), 1.0)       # ~2 bf16 ulps of the result + slack for order
+        err = np.abs(got - want); tol = {'bf16': 0.02, 'f32': 2e-4, 'bf16x3': 4e-5}[dt] * np.maximum(np.abs(want), 1.0)       # ~2 bf16 ulps of the result + slack for order
         if (err > tol).any():
             bad.append(('mismatch %.3g' % float(err.max()), dt, algo, (N, cin, H, W, cout, k, s, res, slope)))
 print('cases %d, kernel runs %d, problems %d' % (ncase, nrun, len(bad)))

@@ -33,6 +33,7 @@ template <> struct Frag<f16_t> {
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
 };
+template <> struct Frag<bf16x3_t> : Frag<bf16_t> {};      // (split bf16: the bf16 MFMA over three K passes, common.h)
 template <> struct Frag<float> {
     // 16 bytes = 4 f32 per lane half -> four 32x32x2 steps; step s contracts k = {s, 4+s} of
     // the 8 channels in this 32-byte sub-chunk (same mapping on A and B, so any order is exact).
@@ -178,11 +179,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     uint4 xr[XP], wr[WP];
+    // split type: K-chunk c of the three passes [x_hi | x_lo | x_hi] sits at c * 64 + (c >= n ? adj1 : 0) + (c >= 2n ? adj2 : 0) bytes
+    // inside the pixel (conv_args.h); its planes are padded to whole chunks, so no ragged-K test (TS == 1 for the 1x1: launch_shape)
+    static_assert(!IsSplit<T>::value || KS == 3 || TS == 1, "split type: one K chunk per step");
+    auto chunk_byte = [&](int c) -> int {
+        if constexpr (IsSplit<T>::value) return c * 64 + (c >= a.x3_n ? a.x3_adj1 : 0) + (c >= 2 * a.x3_n ? a.x3_adj2 : 0);
+        else return c * 64;
+    };
 #define LOAD_X(chunk_base)                                                                      \
     _Pragma("unroll") for (int j = 0; j < XP; ++j) {                                            \
-        const int byte = (chunk_base) * 64 + xlp[j];                                            \
+        const int byte = chunk_byte(chunk_base) + xlp[j];                                       \
         uint4 v = make_uint4(0, 0, 0, 0);                                                       \
-        if (xoff[j] >= 0 && byte < row_bytes) v = *(const uint4*)(a.x + xoff[j] + byte);        \
+        if (xoff[j] >= 0 && (IsSplit<T>::value || byte < row_bytes)) v = *(const uint4*)(a.x + xoff[j] + byte); \
         xr[j] = v;                                                                              \
     }
     // plane0 = first (chunk*taps + tap) plane of the packed weights for the step
@@ -343,9 +351,13 @@ static int launch_shape(ConvArgs& a, int ks, int stride, hipStream_t st, const N
     if (ks == 3 && stride == 1) return launch_cfg<T, 3, 1, WAVES_P, WAVES_C, MI, NI, XSLOTS_S1, 3>(a, st, nm);
     if (ks == 3 && stride == 2) return launch_cfg<T, 3, 2, WAVES_P, WAVES_C, MI, NI, XSLOTS_S2, 3>(a, st, nm);
     if (ks == 1 && stride == 1) {
-        if (a.nchunks % 4 == 0) return launch_cfg<T, 1, 1, WAVES_P, WAVES_C, MI, NI, BP, 4>(a, st, nm);
-        if (a.nchunks % 2 == 0) return launch_cfg<T, 1, 1, WAVES_P, WAVES_C, MI, NI, BP, 2>(a, st, nm);
-        return launch_cfg<T, 1, 1, WAVES_P, WAVES_C, MI, NI, BP, 1>(a, st, nm);
+        if constexpr (IsSplit<T>::value) {
+            return launch_cfg<T, 1, 1, WAVES_P, WAVES_C, MI, NI, BP, 1>(a, st, nm);      // (one chunk per step: conv_igemm_kernel)
+        } else {
+            if (a.nchunks % 4 == 0) return launch_cfg<T, 1, 1, WAVES_P, WAVES_C, MI, NI, BP, 4>(a, st, nm);
+            if (a.nchunks % 2 == 0) return launch_cfg<T, 1, 1, WAVES_P, WAVES_C, MI, NI, BP, 2>(a, st, nm);
+            return launch_cfg<T, 1, 1, WAVES_P, WAVES_C, MI, NI, BP, 1>(a, st, nm);
+        }
     }
     return YOLO_EUNSUPPORTED;
 }
@@ -561,7 +573,7 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     }
     if (d->dtype == YOLO_BF16) return launch_dtype<bf16_t>(a, d->ksize, d->stride, st, nm);
     if (d->dtype == YOLO_F16) return launch_dtype<f16_t>(a, d->ksize, d->stride, st, nm);
-    if (split) return YOLO_EUNSUPPORTED;                                  // (split types: the pipelined kernels only)
+    if (split) return launch_dtype<bf16x3_t>(a, d->ksize, d->stride, st, nm);      // (ragged widths, maps a pixel or two wide: the generic kernel)
     return launch_dtype<float>(a, d->ksize, d->stride, st, nm);
 }
 
