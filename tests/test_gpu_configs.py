@@ -490,3 +490,35 @@ def test_config1_bs32_measured_plan(cuda, dtype, kernels):
         assert e_hip < 1.5 * e_sim + slack and e_hip < bar, (e_hip, e_sim)
         for k in range(3):                                                              # every image on its own, too
             assert rms(o[sel[k]] - r[k]) / r.std() < bar * 4 / 3
+
+
+def test_tune_plan_is_the_benched_and_tested_kernel_set(cuda):
+    """`CarNet(spec, tune='plan')` -- what INTEGRATION.md section 2 tells a maintainer to write -- launches, for BASELINE configs[1],
+    exactly the kernel instantiations bench.py launches (tune='measure' + the plan file loaded) and the `kernels='plan'` parity
+    tests above compare with the oracle: same launch list, bit-identical logits; nothing is timed, a shape the plan does not
+    hold gets the heuristic's variant (and the Trainer of such a net adopts the plan's gradient-kernel choices)."""
+    from yolo_amd.net import CarNet
+    from yolo_amd.train import Trainer
+    from yolo_amd import plans
+    spec = og.spec_d53()
+    g = og.build_graph(spec)
+    P = og.init_params(g, seed=0, bn='random')
+    x = torch.from_numpy(np.random.default_rng(7).random((32, 3) + SIZE, dtype=np.float32)).to(cuda)
+    state, meta = plans.load(plans.DEFAULT)
+    for dtype in ('bf16', 'bf16x3'):
+        a = CarNet(spec, dtype=dtype, device=cuda, tune='plan').load_params(P)
+        b = CarNet(spec, dtype=dtype, device=cuda, tune='measure').load_params(P)
+        b.load_tuning_state(state)
+        oa = [o.clone() for o in a(x)]
+        ob = b(x)
+        assert a.plan_signature(32, *SIZE) == b.plan_signature(32, *SIZE)
+        assert all(bool((p_ == q_).all()) for p_, q_ in zip(oa, ob))
+        assert plans.new_keys(a.tuning_state(), state) == 0 and a.stale_choices == 0
+    small = CarNet(spec, dtype='bf16', device=cuda, tune='plan').load_params(P)        # B = 2: not in the plan -> heuristic, no timing
+    outs = small(x[:2])
+    assert plans.new_keys(small.tuning_state(), state) == 0
+    ref = CarNet(spec, dtype='bf16', device=cuda, tune='auto').load_params(P)(x[:2])
+    for o, r in zip(outs, ref):
+        assert float((o - r).abs().max()) <= 0.05 * float(r.abs().max())
+    tr = Trainer(CarNet(spec, dtype='bf16', device=cuda, tune='plan').load_params(P), SIZE)
+    assert len(tr._wgrad_algo) == len(state['wgrad']) and len(tr._dgrad_algo) == len(state['dgrad'])

@@ -54,8 +54,17 @@ class CarNet(object):
         self.device = L.resolve_device(device)
         # tune: 'auto' = the library's heuristic picks the conv tile variant; 'measure' = time every
         # variant once per distinct layer shape when a plan is built (HIP events) and pin the fastest
-        if tune not in ('auto', 'measure'):
-            raise ValueError("tune must be 'auto' or 'measure'")
+        # (round 6) 'plan' = launch the kernels of a SHIPPED plan file (yolo_amd/plans.py; default profiles/plan.json -- the set
+        # bench.py runs and the parity tests compare with the oracle): every layer shape the plan holds gets its variant, a shape it
+        # does not hold gets the heuristic's; nothing is ever timed.  What a deployment wants: the same kernels on every box.
+        if tune not in ('auto', 'measure', 'plan'):
+            raise ValueError("tune must be 'auto', 'measure' or 'plan'")
+        self.measure_live = tune == 'measure'      # a shape without a cached choice is timed ('measure') or left to the heuristic ('plan')
+        self._plan_state = None
+        if tune == 'plan':
+            from . import plans
+            self._plan_state, self.plan_meta = plans.load(tune_cache or plans.DEFAULT)
+            tune, tune_cache = 'measure', None       # (from here on: the cached-choice code paths of 'measure', minus the timing)
         self.tune = tune
         # fuse_stem: run the stem and the first down-sampling conv as one kernel where yolo_stem_down_fwd takes the
         # shape (32 -> 64, bf16); the stem's own output is then not materialised (no 'stem' parity tap)
@@ -86,7 +95,7 @@ class CarNet(object):
             self.fuse_tail_note = "fuse_tail=True has no effect under tune='auto' (pairs are only fused where the tuner measured a gain)"
         else:
             self.fuse_tail_note = None
-        self._algo_cache = {}
+        self._algo_cache = dict(self._plan_state['algo']) if self._plan_state is not None else {}
         self.stale_choices = 0      # adopted choices (plan file / rank 0) this library no longer takes: dropped and measured again
         # optional JSON file remembering measured choices (so a profiled run launches only the chosen kernels)
         self._tune_cache = tune_cache
@@ -296,6 +305,8 @@ class CarNet(object):
         key = self._tail_key(d)
         if key in self._algo_cache:
             return bool(self._algo_cache[key])
+        if not self.measure_live:
+            return False                                  # (tune='plan': pairs are fused only where the plan says a measurement found a gain)
         d3 = self._conv_desc(c3, x, xshape, out, residual, False, y_bs, y_ps)
         d3.algo = self._measure_algo(d3)
         d1 = self._conv_desc(c1, out, (N, ho, wo, c3.cout), out1, None, out1_f32, t_bs, t_ps)
@@ -344,6 +355,8 @@ class CarNet(object):
         key = ('res', shp[0], shp[1], shp[2], C_, _LIB_DT[self.dtype])
         if key in self._algo_cache:
             return bool(self._algo_cache[key])
+        if not self.measure_live:
+            return True                                   # (tune='plan', unknown shape: the heuristic's answer, as under tune='auto')
         lib, st, dt = self._lib, L.stream_ptr(), _LIB_DT[self.dtype]
         tdt = _TORCH_DT[self.dtype]
         mid = torch.empty(shp[:3] + (C_ // 2,), dtype=tdt, device=self.device)
@@ -446,6 +459,8 @@ class CarNet(object):
                     self.stale_choices += 1
             if key in self._algo_cache:
                 return cached
+        if not self.measure_live:
+            return 0                                      # (tune='plan', a shape the plan does not hold: the library's heuristic)
         fn = fn or lib.yolo_conv_fwd
 
         def time_algo(algo, n):

@@ -92,6 +92,9 @@ class Trainer(object):
         self._plans = {}
         self._dgrad_algo = {}
         self._wgrad_algo = {}
+        if getattr(net, '_plan_state', None) is not None:      # CarNet(tune='plan'): the plan's data- and weight-gradient choices too
+            self._dgrad_algo.update(net._plan_state['dgrad'])
+            self._wgrad_algo.update(net._plan_state['wgrad'])
         self._fwd_B = None
         cmax = max(c.cout for c in g.convs())
         # two BatchNorm workspaces used alternately (yolo_bn_train_*_pp: a call leaves its own dirty and zeroes the next one's)
@@ -486,6 +489,8 @@ class Trainer(object):
             return 0
         N, Hh, Ww, Cx = xin.shape
         key = (N, Hh, Ww, Cx, c.cout, c.k, c.stride)
+        if key not in self._wgrad_algo and not getattr(self.net, 'measure_live', True):
+            return 0                                      # (tune='plan', a shape the plan does not hold: the library's choice)
         if key not in self._wgrad_algo:
             cands = (0, 2, 3, 4) if (c.k == 3 and c.stride == 1) else (0, 1, 5) if c.k == 1 else (0,)
             best, best_t = 0, float('inf')
