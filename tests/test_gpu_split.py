@@ -53,7 +53,7 @@ CASES = [
     (2, 40, 5, 11, 24, 1, 1, False),
     (1, 72, 1, 1, 48, 3, 1, False),
 ]
-ALGOS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 27, 28, 36, 37, 38, 39, 40, 41]
+ALGOS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 27, 28, 36, 37, 38, 39, 40, 41, 42]
 
 
 def _mk(case, seed):
@@ -82,6 +82,18 @@ def test_split_conv_variants(lib, cuda, case, dtype, algo):
     x, w, scale, bias, r = _mk(case, 4)
     y = run_conv(lib, cuda, x, w, scale, bias, case[6], 0.1, dtype, residual=r, algo=algo, expect_rc=0)
     _check(y, ref_conv_split(x, w, scale, bias, case[6], 0.1, residual=r), ref_conv(x, w, scale, bias, case[6], 0.1, residual=r))
+
+
+@pytest.mark.parametrize('algo', [42, 17, 1])
+def test_split_stride2_full_size_repeated(lib, cuda, algo):
+    """The D53 104x104 -> 52x52 down-sampling layer at its real size, five launches each: the 4-wave 64-cout stride-2 tile (algo 42)
+    stages ten input DMAs per thread and chunk -- its first cut issued one of them in a chunk's last phase, where the counted wait
+    still lets it fly, and computed on a stale unit now and then (caught by the whole-net test, not by the small conv cases)."""
+    case = (2, 128, 104, 104, 256, 3, 2, False)
+    x, w, scale, bias, r = _mk(case, 12)
+    sim, ref = ref_conv_split(x, w, scale, bias, 2, 0.1), ref_conv(x, w, scale, bias, 2, 0.1)
+    for _ in range(5):
+        _check(run_conv(lib, cuda, x, w, scale, bias, 2, 0.1, 'bf16x3', algo=algo, expect_rc=0), sim, ref)
 
 
 @pytest.mark.parametrize('case', CASES)

@@ -248,7 +248,13 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
         const char* src = (xo[jj] != 0xffffffffu) ? ax + ((long long)xo[jj] + chunk_off(cc)) : zero_page;
         glds16_m0(src, wave_lds + buf * X_STAGE + kc * X_STAGE1 + jj * NT * 16);
     };
-    static_assert(KS == 1 || XL <= PPC, "3x3: at most one input DMA per phase");
+    // Input DMAs per phase of a 3x3: one (phase q issues j = q) -- or, for a tile with more input DMAs per thread than phases (round 6: the
+    // 4-wave stride-2 tile of the split type), XPP per phase in the FIRST phases, so that the last two phases of a chunk issue none:
+    // the counted wait at the end of a phase leaves that phase's and the previous phase's DMAs in flight, and the next chunk's first
+    // phase reads the buffer they fill.  (The first cut of that tile issued j = q, q + PPC -- input DMAs in phase 8 -- and computed
+    // on a stale unit now and then: found by tests/test_gpu_split.py::test_split_d53_logits_vs_fp32_oracle[measure].)
+    constexpr int XPP = (KS != 1 && XL > PPC) ? (XL + PPC - 3) / (PPC - 2) : 1;
+    static_assert(KS == 1 || XL <= PPC || (KS == 3 && S == 2 && XPP * (PPC - 2) >= XL), "more input DMAs than phases: stride-2 tiles only");
     static_assert(BC * 4 >= NT, "one weight DMA covers rows of a single tap plane");
 
     // ---- prologue: the first weight DMAs go out before the (division-heavy) input address set-up, and the
@@ -339,13 +345,13 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv_pipe_kernel(ConvAr
     constexpr int NM = 2 * KC * MI * NI;                // MFMA "steps" per phase (one 16-byte operand pair each)
     auto phase = [&](auto shift_c, int c, int q, int gp) {
         constexpr int SHIFT = decltype(shift_c)::value;
-        const int nx = (KS != 1) ? (q < XL ? 1 : 0) : XL;          // input DMAs of this phase
+        const int nx = (KS != 1) ? (XPP == 1 ? (q < XL ? 1 : 0) : (XL - q * XPP < 0 ? 0 : (XL - q * XPP < XPP ? XL - q * XPP : XPP))) : XL;      // input DMAs of this phase
         const int nd = nx + WL;
         const int stride = (NM - SHIFT) / (nd > 0 ? nd : 1) > 0 ? (NM - SHIFT) / (nd > 0 ? nd : 1) : 1;
         auto issue_item = [&](int k) {
             __builtin_amdgcn_sched_barrier(0);
             if (k < nx) {
-                if constexpr (KS != 1) issue_x(q, c + 1, (c + 1) & 1);
+                if constexpr (KS != 1) issue_x(XPP == 1 ? q : q * XPP + k, c + 1, (c + 1) & 1);
                 else issue_x(k, gp + R1 - 1, (gp + R1 - 1) % R1);
             } else {
                 issue_w1(gp + WR - 1, k - nx);
@@ -899,6 +905,9 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
             case 16: return launch_pipe<T, 3, 2, 4, 2, 2, 640, 2>(a, st, nm);
             case 17: return launch_pipe<T, 3, 2, 4, 1, 2, 640, 2>(a, st, nm);
             case 18: return launch_pipe<T, 3, 2, 4, 2, 2, 768, 2>(a, st, nm);    // (768 slots: tiles that cross image boundaries)
+            case 42:                                                              // (split type: a 64-cout tile, see algo 40; ten input DMAs per thread and chunk: two in phase 0)
+                if constexpr (IsSplit<T>::value) return launch_pipe<T, 3, 4, 1, 2, 1, 640, 2>(a, st, nm);   // 4 waves, 128 px x 64 cout
+                break;
         }
         return YOLO_EUNSUPPORTED;
     }
@@ -982,8 +991,7 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
             // (round 6, split type only) 64-cout tiles for the first stages' 32- / 64-channel layers: every other variant stages >= 128
             // weight rows per phase, and on the split path -- where these layers are not covered by the fused stem / residual-block /
             // streaming kernels of the 2-byte paths -- a 1x1 64 -> 32 at 208x208 moved twice its input bytes in zero weight rows
-            // (567 us against an HBM floor of ~120).  41: the 3x3 stride-1 sibling (a stride-2 one would need more than one input DMA per
-            // phase: the halo of 128 output pixels does not fit the 576 slots four waves can stage).
+            // (567 us against an HBM floor of ~120).  41 / 42: the 3x3 stride-1 / stride-2 siblings.
             case 40:
                 if constexpr (IsSplit<T>::value) YOLO_PIPE1(4, 1, 2, 2, 256)        // 4 waves, 256 px x 64 cout
                 break;

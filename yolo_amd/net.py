@@ -38,7 +38,7 @@ class _Plan(object):
 
 
 class CarNet(object):
-    ALGOS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 35, 36, 37, 38, 39, 40, 41)     # yolo_conv_desc.algo ids tried by tune='measure' (40, 41: split type only)
+    ALGOS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 35, 36, 37, 38, 39, 40, 41, 42)     # yolo_conv_desc.algo ids tried by tune='measure' (40-42: split type only)
 
     def __init__(self, spec, num_sync_bn_devices=-1, dtype='bf16', device='cuda:0', tune='auto', tune_cache=None,
                  fuse_stem=True, side_stream=True, fuse_res=True, fuse_concat=True, fuse_tail=True):
