@@ -211,3 +211,15 @@ def test_launch_plan_round_trip_and_committed_file():
     state, meta = plans.load(plans.DEFAULT)
     assert all(len(state[s]) > 20 for s in plans.SECTIONS), {s: len(state[s]) for s in plans.SECTIONS}
     assert meta['md5'] == plans.md5(state) and meta.get('commit')
+
+
+def test_bench_host_probes():
+    """bench.py's cpu_baseline placement inputs: the physical-core map covers only CPUs this process may use, one hardware thread per
+    core; the CPU quota is None (unlimited) or a positive number of CPUs."""
+    import bench
+    topo = bench.host_topology()
+    allowed = set(os.sched_getaffinity(0))
+    cores = [c for v in topo.values() for c in v]
+    assert cores and set(cores) <= allowed and len(cores) == len(set(cores))
+    q = bench.cpu_quota()
+    assert q is None or q > 0
