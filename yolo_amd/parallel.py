@@ -130,8 +130,9 @@ class GradBuckets(object):
     dtype='bf16' (last row): a bucket is cast to bf16 into a staging buffer, the staging buffer is
     SUM-reduced, and the sum is cast back into the fp32 gradients when the exchange is joined -- half the bytes per xGMI
     link (246 MB instead of 492), at the price of one bf16 rounding per rank's contribution and one per partial sum inside
-    the collective: |error| <= ~2^-8 * sum_r |g_r| per element (bounded by tests/test_dist_cpu.py against the fp32
-    exchange).  `exact_tail` elements at the end of the flat buffer (the shard-size slot of yolo_amd/train.py: an integer
+    the collective -- a ring of N ranks rounds a partial sum at each of its N - 1 hops: |error| <= ~(N - 1) * 2^-8 * sum_r |g_r| per
+    element (2^-8 * sum at N = 2, ~7x that at N = 8: small gradients added to a large partial sum lose their low bits); bounded
+    against the fp32 exchange at world 2 and 4 by tests/test_dist_cpu.py.  `exact_tail` elements at the end of the flat buffer (the shard-size slot of yolo_amd/train.py: an integer
     that trainer.step divides by) always travel in fp32.  The reference's KVStore reduce is fp32 (car/YOLO.py:160,396):
     'f32' stays the default."""
 
