@@ -970,7 +970,7 @@ def main():
             Bt = 64 if world == 1 else max(256 // world, 1)
             keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'preheat_s', 'sustained_s', 'ms_per_step', 'net_tflops',
                     'net_frac', 'final_losses', 'exchange', 'sclk_mhz', 'power_w', 'telemetry_samples', 'telemetry_source',
-                    'per_rank_ms_per_step', 'tuning_identical_across_ranks', 'plan')
+                    'per_rank_ms_per_step', 'tuning_identical_across_ranks', 'plan', 'roofline')
             t = train_pass(args, spec, size, Bt, rank, world, dev, dist, kt, wt, preheat_s=heat,
                            telemetry=Telemetry(local) if (rank == 0 and sustain) else None)
             out['train_416_bs64'] = {k: t[k] for k in keep if k in t}
