@@ -39,7 +39,7 @@ import numpy as np
 import torch
 
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3,       # /opt/skills/guides/MI355X_MICROARCH.md (dense)
-                    'bf16x3': 2500.0 / 3}      # split bf16: three bf16 MFMAs per algorithmic product
+                    'bf16x3': 2500.0 / 3, 'f16x3': 2500.0 / 3}      # split bf16 / f16: three 2-byte MFMAs per algorithmic product
 
 
 class Telemetry(object):
@@ -257,7 +257,7 @@ def cpu_baseline(size, seconds=6.0, batch=32, dev=None, plan_state=None, plan_ba
         # (the two images repeated: eval-mode images are independent); without a plan the variants are measured on this box
         rep = max(1, (plan_batch or 2) // 2)
         parity['kernels'] = 'committed plan, batch %d (images 0-1 repeated)' % (2 * rep) if plan_state is not None else 'measured on this box'
-        for dt in ('f32', 'bf16x3', 'f16', 'bf16'):
+        for dt in ('f32', 'f16x3', 'bf16x3', 'f16', 'bf16'):
             net = CarNet(spec, dtype=dt, device=dev, tune='measure').load_params(P)
             if plan_state is not None:
                 net.load_tuning_state(plan_state)
@@ -607,7 +607,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (default 32; 64 in --mode train)')
     ap.add_argument('--size', type=int, default=416)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32', 'bf16x3'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32', 'bf16x3', 'f16x3'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-fuse-stem', action='store_true', help='run the stem and the first down-sampling conv as two kernels (A/B)')
@@ -771,6 +771,7 @@ def main():
                                           'the number INSIDE the 1e-3 tolerance is `parity_path` (dtype bf16x3)',
                                   'f16': "IEEE half (the reference's use_fp16): boxes 1.6e-2 max / 6e-4 RMS of the fp32 oracle",
                                   'bf16x3': 'split bf16, three bf16 MFMAs per product: decoded boxes <= 1e-3 of the fp32 oracle (3e-4 observed), top-1 indices identical',
+                                  'f16x3': 'split f16, three f16 MFMAs per product: decoded boxes <= 1e-3 of the fp32 oracle (6e-5 observed: the fp32 path\'s own), top-1 indices identical',
                                   'f32': 'exact-fp32 MFMA: decoded boxes <= 1e-3 of the fp32 oracle (7e-5 observed), indices bit-exact'}[args.dtype]},
     }
     out['value_median'] = round(float(np.median(reps)), 2)

@@ -36,6 +36,11 @@ extern "C" {
  * 3 * Cp / 32 K-chunks; Cin % 8 == 0), yolo_conv_fwd (pipelined kernels; Cout % 8 == 0 unless out_f32; no stats / tail),
  * yolo_stem_conv_fwd.  Everything else returns YOLO_EUNSUPPORTED / YOLO_EINVAL for it. */
 #define YOLO_BF16X3 3
+/* The same scheme on IEEE-half pairs (22 significant bits; the dropped term is 2^-22 of a product): decoded boxes indistinguishable from
+ * the fp32 path's (6e-5 on the D53 random-BN nets, where YOLO_BF16X3 measures 3e-4) at the same three MFMAs per product -- for data inside
+ * half's range (|v| < 65504; the lo planes live in the subnormals, which v_mfma_f32_32x32x16_f16 honours: tools/probes/f16_denorm_probe.py).
+ * Same entry points, layout and restrictions as YOLO_BF16X3. */
+#define YOLO_F16X3 4
 
 #define YOLO_OK 0
 #define YOLO_EINVAL (-1)

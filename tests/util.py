@@ -7,9 +7,9 @@ import torch.nn.functional as F
 
 from yolo_amd import lib as L
 
-TDT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16, 'bf16x3': torch.bfloat16}
-LDT = {'f32': L.F32, 'bf16': L.BF16, 'f16': L.F16, 'bf16x3': L.BF16X3}
-SPLIT = ('bf16x3',)
+TDT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16, 'bf16x3': torch.bfloat16, 'f16x3': torch.float16}
+LDT = {'f32': L.F32, 'bf16': L.BF16, 'f16': L.F16, 'bf16x3': L.BF16X3, 'f16x3': L.F16X3}
+SPLIT = ('bf16x3', 'f16x3')
 
 
 def split_planes(t, rdt=torch.bfloat16):

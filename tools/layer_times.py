@@ -41,7 +41,7 @@ for (kind, payload, name), (_, kname, fl) in zip(plan.ops, kern):
     byt = d.N * d.H * d.W * d.Cin * es + d.N * ho * wo * d.Cout * (4 if d.out_f32 else es) + d.Cout * d.Cin * d.ksize ** 2 * es
     if d.residual: byt += d.N * ho * wo * d.Cout * es
     hbm_us = byt / 6.3e12 * 1e6
-    mf_us = fl / {'bf16': 2.5e15, 'f16': 2.5e15, 'bf16x3': 2.5e15 / 3}.get(a.dtype, 157e12) * 1e6
+    mf_us = fl / {'bf16': 2.5e15, 'f16': 2.5e15, 'bf16x3': 2.5e15 / 3, 'f16x3': 2.5e15 / 3}.get(a.dtype, 157e12) * 1e6
     roof = max(hbm_us, mf_us)
     sum_us += us; sum_roof += roof
     print('%-22s %-14s %5d %5d %4d %4d %8.1f %8.1f %8.1f %6s %5.0f%% a%d' % (name, '%dx%dx%d' % (d.N, d.H, d.W), d.Cin, d.Cout, d.ksize, d.stride,

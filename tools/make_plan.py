@@ -30,7 +30,7 @@ base_workloads = []
 if a.base:
     bstate, bmeta = plans.load(a.base)
     from yolo_amd import lib as L_
-    drop = {{'f32': L_.F32, 'bf16': L_.BF16, 'f16': L_.F16, 'bf16x3': L_.BF16X3}[d_] for d_ in a.remeasure.split(',') if d_}
+    drop = {{'f32': L_.F32, 'bf16': L_.BF16, 'f16': L_.F16, 'bf16x3': L_.BF16X3, 'f16x3': L_.F16X3}[d_] for d_ in a.remeasure.split(',') if d_}
     # (a forward conv key is (N, H, W, Cin, Cout, ksize, stride, out_f32, residual, dtype, ...): plans of net.py _measure_algo)
     bstate['algo'] = {k: v for k, v in bstate['algo'].items() if not (isinstance(k[0], int) and len(k) >= 10 and k[9] in drop)}
     states.append(bstate)
@@ -57,7 +57,7 @@ if not a.no_f32:
     print(shapes[-1], '%.0f s' % (time.time() - t0), flush=True)
     del net
     torch.cuda.empty_cache()
-for dt in ('f16', 'bf16x3'):              # (bf16x3: the split bf16 parity path, bench.py's `parity_path` key and --dtype bf16x3)
+for dt in ('f16', 'bf16x3', 'f16x3'):     # (bf16x3: the split bf16 parity path, bench.py's `parity_path` key and --dtype bf16x3; f16x3: its IEEE-half sibling)
     net = CarNet(spec, dtype=dt, device=dev, tune='measure').initialize(seed=1234)
     net.load_tuning_state(plans.merge(*states))
     net.prepare()

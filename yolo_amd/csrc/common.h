@@ -97,8 +97,14 @@ template <> struct Elem<bf16x3_t> : Elem<bf16_t> {
     static constexpr const char* name = "bf16x3_t";
     static constexpr int dtype = YOLO_BF16X3;
 };
+struct f16x3_t { uint16_t bits; };        // (YOLO_F16X3: the same scheme on IEEE-half pairs, 22 significant bits)
+template <> struct Elem<f16x3_t> : Elem<f16_t> {
+    static constexpr const char* name = "f16x3_t";
+    static constexpr int dtype = YOLO_F16X3;
+};
 template <typename T> struct IsSplit { static constexpr bool value = false; };
 template <> struct IsSplit<bf16x3_t> { static constexpr bool value = true; };
+template <> struct IsSplit<f16x3_t> { static constexpr bool value = true; };
 // one 32x32x16 MFMA step on 2-byte operands (A, B: 8 elements per lane as a uint4)
 template <typename T> __device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, const f32x16& c);
 template <> __device__ __forceinline__ f32x16 mfma16<bf16_t>(const uint4& a, const uint4& b, const f32x16& c) {
@@ -108,16 +114,17 @@ template <> __device__ __forceinline__ f32x16 mfma16<f16_t>(const uint4& a, cons
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 template <> __device__ __forceinline__ f32x16 mfma16<bf16x3_t>(const uint4& a, const uint4& b, const f32x16& c) { return mfma16<bf16_t>(a, b, c); }
+template <> __device__ __forceinline__ f32x16 mfma16<f16x3_t>(const uint4& a, const uint4& b, const f32x16& c) { return mfma16<f16_t>(a, b, c); }
 template <typename T> struct IsBf16 { static constexpr bool value = false; };
 template <> struct IsBf16<bf16_t> { static constexpr bool value = true; };
 
 // bytes of one stored element; 0 for an unknown dtype (every entry point checks dtype_valid first: a garbage dtype must not be
 // sized as a 2-byte type)
-static inline int elem_size(int dtype) { return dtype == YOLO_F32 ? 4 : (dtype == YOLO_BF16 || dtype == YOLO_F16 || dtype == YOLO_BF16X3) ? 2 : 0; }
-static inline bool dtype_valid(int dtype) { return dtype == YOLO_F32 || dtype == YOLO_BF16 || dtype == YOLO_F16 || dtype == YOLO_BF16X3; }
+static inline int elem_size(int dtype) { return dtype == YOLO_F32 ? 4 : (dtype == YOLO_BF16 || dtype == YOLO_F16 || dtype == YOLO_BF16X3 || dtype == YOLO_F16X3) ? 2 : 0; }
+static inline bool dtype_valid(int dtype) { return dtype == YOLO_F32 || dtype == YOLO_BF16 || dtype == YOLO_F16 || dtype == YOLO_BF16X3 || dtype == YOLO_F16X3; }
 // the single-plane dtypes (what the training / fused / streaming entries take)
 static inline bool dtype_plain(int dtype) { return dtype == YOLO_F32 || dtype == YOLO_BF16 || dtype == YOLO_F16; }
-static inline bool dtype_split(int dtype) { return dtype == YOLO_BF16X3; }
+static inline bool dtype_split(int dtype) { return dtype == YOLO_BF16X3 || dtype == YOLO_F16X3; }
 // stored planes per activation element (split types: hi + lo) and K passes of a convolution over the input channels
 static inline int dtype_planes(int dtype) { return dtype_split(dtype) ? 2 : 1; }
 static inline int dtype_kpasses(int dtype) { return dtype_split(dtype) ? 3 : 1; }

@@ -34,6 +34,7 @@ template <> struct Frag<f16_t> {
     }
 };
 template <> struct Frag<bf16x3_t> : Frag<bf16_t> {};      // (split bf16: the bf16 MFMA over three K passes, common.h)
+template <> struct Frag<f16x3_t> : Frag<f16_t> {};
 template <> struct Frag<float> {
     // 16 bytes = 4 f32 per lane half -> four 32x32x2 steps; step s contracts k = {s, 4+s} of
     // the 8 channels in this 32-byte sub-chunk (same mapping on A and B, so any order is exact).
@@ -573,7 +574,8 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     }
     if (d->dtype == YOLO_BF16) return launch_dtype<bf16_t>(a, d->ksize, d->stride, st, nm);
     if (d->dtype == YOLO_F16) return launch_dtype<f16_t>(a, d->ksize, d->stride, st, nm);
-    if (split) return launch_dtype<bf16x3_t>(a, d->ksize, d->stride, st, nm);      // (ragged widths, maps a pixel or two wide: the generic kernel)
+    if (d->dtype == YOLO_BF16X3) return launch_dtype<bf16x3_t>(a, d->ksize, d->stride, st, nm);      // (ragged widths, maps a pixel or two wide: the generic kernel)
+    if (d->dtype == YOLO_F16X3) return launch_dtype<f16x3_t>(a, d->ksize, d->stride, st, nm);
     return launch_dtype<float>(a, d->ksize, d->stride, st, nm);
 }
 
@@ -872,6 +874,9 @@ static int pack_impl(const float* w_oihw, void* packed, int Cout, int Cin, int k
     else if (dtype == YOLO_BF16X3)
         YOLO_LAUNCH(pack_weights_kernel<bf16x3_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
                            (bf16x3_t*)packed, Cout, Cin, ksize, Cout_pad, nchunks, dgrad);
+    else if (dtype == YOLO_F16X3)
+        YOLO_LAUNCH(pack_weights_kernel<f16x3_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                           (f16x3_t*)packed, Cout, Cin, ksize, Cout_pad, nchunks, dgrad);
     else
         YOLO_LAUNCH(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
                            (float*)packed, Cout, Cin, ksize, Cout_pad, nchunks, dgrad);

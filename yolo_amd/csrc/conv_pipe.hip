@@ -32,10 +32,11 @@
 //                  4: 3x3 stride-2 kernels, bf16 (conv_pipe_dispatch_e)
 //                  5: 3x3 stride-1 kernels, bf16, the second half of the tile variants (conv_pipe_dispatch_f)
 //                  6: 3x3 kernels, split bf16 (YOLO_BF16X3; conv_pipe_dispatch_g)      7: 1x1 kernels, split bf16 (conv_pipe_dispatch_h)
-#define YOLO_PIPE_3X3 (YOLO_PIPE_PART == 0 || YOLO_PIPE_PART == 2 || YOLO_PIPE_PART == 4 || YOLO_PIPE_PART == 5 || YOLO_PIPE_PART == 6)
+//                  8 / 9: the same for split f16 (YOLO_F16X3; conv_pipe_dispatch_i / _j)
+#define YOLO_PIPE_3X3 (YOLO_PIPE_PART == 0 || YOLO_PIPE_PART == 2 || YOLO_PIPE_PART == 4 || YOLO_PIPE_PART == 5 || YOLO_PIPE_PART == 6 || YOLO_PIPE_PART == 8)
 // (which stride-1 3x3 variants a unit holds: bf16 is split over units 0 and 5)
-#define YOLO_PIPE_S1A (YOLO_PIPE_PART == 0 || YOLO_PIPE_PART == 2 || YOLO_PIPE_PART == 6)
-#define YOLO_PIPE_S1B (YOLO_PIPE_PART == 5 || YOLO_PIPE_PART == 2 || YOLO_PIPE_PART == 6)
+#define YOLO_PIPE_S1A (YOLO_PIPE_PART == 0 || YOLO_PIPE_PART == 2 || YOLO_PIPE_PART == 6 || YOLO_PIPE_PART == 8)
+#define YOLO_PIPE_S1B (YOLO_PIPE_PART == 5 || YOLO_PIPE_PART == 2 || YOLO_PIPE_PART == 6 || YOLO_PIPE_PART == 8)
 namespace { __device__ __attribute__((aligned(64))) unsigned int yolo_zero_page[16]; }
 
 typedef __attribute__((address_space(3))) char lds_char;
@@ -84,6 +85,7 @@ template <> struct FragP<f16_t> {
     }
 };
 template <> struct FragP<bf16x3_t> : FragP<bf16_t> {};
+template <> struct FragP<f16x3_t> : FragP<f16_t> {};
 template <> struct FragP<float> {
     static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16& c) {
         c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
@@ -888,13 +890,15 @@ int conv_pipe_dispatch_e(ConvArgs& a, int algo, hipStream_t st, const NameOut* n
 int conv_pipe_dispatch_f(ConvArgs& a, int algo, hipStream_t st, const NameOut* nm);                                    // (unit 5)
 int conv_pipe_dispatch_g(ConvArgs& a, int ks, int stride, int algo, hipStream_t st, const NameOut* nm);                // (unit 6)
 int conv_pipe_dispatch_h(ConvArgs& a, int ks, int algo, hipStream_t st, const NameOut* nm);                            // (unit 7)
+int conv_pipe_dispatch_i(ConvArgs& a, int ks, int stride, int algo, hipStream_t st, const NameOut* nm);                // (unit 8)
+int conv_pipe_dispatch_j(ConvArgs& a, int ks, int algo, hipStream_t st, const NameOut* nm);                            // (unit 9)
 
 template <typename T>
 static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_t st, const NameOut* nm) {
 #if YOLO_PIPE_PART == 0
     if (ks == 3 && stride == 2) return conv_pipe_dispatch_e(a, algo, st, nm);      // (bf16: a unit of its own)
 #endif
-#if YOLO_PIPE_PART == 2 || YOLO_PIPE_PART == 4 || YOLO_PIPE_PART == 6
+#if YOLO_PIPE_PART == 2 || YOLO_PIPE_PART == 4 || YOLO_PIPE_PART == 6 || YOLO_PIPE_PART == 8
     if (ks == 3 && stride == 2) {
         // stride 2: the input footprint is ~4x the output tile, so tiles are 128 output pixels
         switch (algo) {
@@ -954,6 +958,8 @@ static int pipe_dispatch_t(ConvArgs& a, int ks, int stride, int algo, hipStream_
     return conv_pipe_dispatch_b(a, ks, Elem<T>::dtype, algo, st, nm);
 #elif YOLO_PIPE_PART == 6
     return conv_pipe_dispatch_h(a, ks, algo, st, nm);
+#elif YOLO_PIPE_PART == 8
+    return conv_pipe_dispatch_j(a, ks, algo, st, nm);
 #else
     return conv_pipe_dispatch_d(a, ks, Elem<T>::dtype, algo, st, nm);
 #endif
@@ -1034,6 +1040,10 @@ int conv_pipe_dispatch_d(ConvArgs& a, int ks, int dtype, int algo, hipStream_t s
 int conv_pipe_dispatch_g(ConvArgs& a, int ks, int stride, int algo, hipStream_t st, const NameOut* nm) { return pipe_dispatch_t<bf16x3_t>(a, ks, stride, algo, st, nm); }
 #elif YOLO_PIPE_PART == 7
 int conv_pipe_dispatch_h(ConvArgs& a, int ks, int algo, hipStream_t st, const NameOut* nm) { return pipe_dispatch_t<bf16x3_t>(a, ks, 1, algo, st, nm); }
+#elif YOLO_PIPE_PART == 8
+int conv_pipe_dispatch_i(ConvArgs& a, int ks, int stride, int algo, hipStream_t st, const NameOut* nm) { return pipe_dispatch_t<f16x3_t>(a, ks, stride, algo, st, nm); }
+#elif YOLO_PIPE_PART == 9
+int conv_pipe_dispatch_j(ConvArgs& a, int ks, int algo, hipStream_t st, const NameOut* nm) { return pipe_dispatch_t<f16x3_t>(a, ks, 1, algo, st, nm); }
 #elif YOLO_PIPE_PART == 2
 int conv_pipe_dispatch_c(ConvArgs& a, int ks, int stride, int dtype, int algo, hipStream_t st, const NameOut* nm) {
     if (dtype == YOLO_F16) return pipe_dispatch_t<f16_t>(a, ks, stride, algo, st, nm);
@@ -1048,6 +1058,7 @@ int conv_pipe_dispatch(ConvArgs& a, int ks, int stride, int dtype, int algo, hip
     if ((long long)a.N * a.H * a.W * a.x_ps * elem_size(dtype) >= 0xffffff00LL) return YOLO_EUNSUPPORTED;
     if (dtype == YOLO_BF16) return pipe_dispatch_t<bf16_t>(a, ks, stride, algo, st, nm);
     if (dtype == YOLO_BF16X3) return ks == 2 ? YOLO_EUNSUPPORTED : conv_pipe_dispatch_g(a, ks, stride, algo, st, nm);
+    if (dtype == YOLO_F16X3) return ks == 2 ? YOLO_EUNSUPPORTED : conv_pipe_dispatch_i(a, ks, stride, algo, st, nm);
     return conv_pipe_dispatch_c(a, ks, stride, dtype, algo, st, nm);
 }
 #endif

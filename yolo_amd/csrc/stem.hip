@@ -278,14 +278,18 @@ extern "C" int yolo_stem_conv_fwd(const float* x_nchw, const float* w_oihw, cons
     if (!x_nchw || !w_oihw || !scale || !bias || !y || N <= 0 || H <= 0 || W <= 0) return YOLO_EINVAL;
     if (!(slope >= 0.f && slope <= 1.f)) return YOLO_EINVAL;
     if (Cin != 3 || Cout <= 0 || (Cout % 4) || Cout > 64) return YOLO_EUNSUPPORTED;
-    if (dtype == YOLO_BF16X3) {
+    if (dtype == YOLO_BF16X3 || dtype == YOLO_F16X3) {
         if (Cout != 8 && Cout != 16 && Cout != 32 && Cout != 64) return YOLO_EUNSUPPORTED;
         const int sh = Cout == 8 ? 0 : Cout == 16 ? 1 : Cout == 32 ? 2 : 3;
         const int th = 16 >> sh, tiles_x_ = (W + 15) / 16, tiles_y_ = (H + th - 1) / th;
         const long long nblk = (long long)N * tiles_x_ * tiles_y_;
         if (nblk > 0x7fffffffLL) return YOLO_EUNSUPPORTED;
-        YOLO_LAUNCH(stem_split_kernel<bf16x3_t>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x_nchw, w_oihw,
-                    scale, bias, (uint16_t*)y, H, W, Cout, sh, slope, tiles_x_, tiles_y_);
+        if (dtype == YOLO_BF16X3)
+            YOLO_LAUNCH(stem_split_kernel<bf16x3_t>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x_nchw, w_oihw,
+                        scale, bias, (uint16_t*)y, H, W, Cout, sh, slope, tiles_x_, tiles_y_);
+        else
+            YOLO_LAUNCH(stem_split_kernel<f16x3_t>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x_nchw, w_oihw,
+                        scale, bias, (uint16_t*)y, H, W, Cout, sh, slope, tiles_x_, tiles_y_);
         YOLO_LAUNCH_CHECK();
         return YOLO_OK;
     }

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('YOLO_AMD_LIB') or os.path.join(CSRC, 'libyolo_amd.so')   # override: experiment builds
 
-F32, BF16, F16, BF16X3 = 0, 1, 2, 3
+F32, BF16, F16, BF16X3, F16X3 = 0, 1, 2, 3, 4
 ABI_VERSION = 4            # include/yolo_amd.h: YOLO_ABI_VERSION (the struct layouts below are revision 4's)
 OK, EINVAL, EUNSUPPORTED = 0, -1, -2
 

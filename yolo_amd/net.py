@@ -15,13 +15,15 @@ import torch
 from . import lib as L
 from .spec import NetGraph, BN_EPS, LEAKY_SLOPE, xavier_bound
 
-_TORCH_DT = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32, 'bf16x3': torch.bfloat16}
-_LIB_DT = {'bf16': L.BF16, 'f16': L.F16, 'f32': L.F32, 'bf16x3': L.BF16X3}
+_TORCH_DT = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32, 'bf16x3': torch.bfloat16, 'f16x3': torch.float16}
+_LIB_DT = {'bf16': L.BF16, 'f16': L.F16, 'f32': L.F32, 'bf16x3': L.BF16X3, 'f16x3': L.F16X3}
 # 'bf16x3' (round 6): SPLIT bf16 -- every activation and weight is a (hi, lo) pair of bf16 numbers, every product three bf16 MFMAs
 # (include/yolo_amd.h: YOLO_BF16X3).  The path on which the north-star tolerance and the MFMA rate meet: decoded boxes within
 # 1e-3 of the fp32 oracle (~3e-4 on the random-BN D53 nets, tests/test_gpu_boxes.py) at ~1/3 of the bf16 path's speed, where
 # the exact-fp32 MFMA of dtype 'f32' runs at ~1/8.  A split activation is a (N, H, W, 2, C) bf16 tensor: plane 0 = hi, 1 = lo.
-_SPLIT = ('bf16x3',)
+# 'f16x3': the same with IEEE-half pairs (22 significant bits): boxes as close to the fp32 oracle as the fp32 path's own (6e-5), for nets whose
+# activations stay inside half's range (as dtype 'f16' needs); same speed minus the ~4 % half multiplies cost at the power cap.
+_SPLIT = ('bf16x3', 'f16x3')
 
 
 class _Plan(object):
@@ -45,7 +47,7 @@ class CarNet(object):
         # num_sync_bn_devices is accepted for signature parity; the reference always passes -1
         # (no SyncBN, car/YOLO.py:94-96).
         if dtype not in _TORCH_DT:
-            raise ValueError('dtype must be bf16, f16, f32 or bf16x3')
+            raise ValueError('dtype must be bf16, f16, f32, bf16x3 or f16x3')
         self.graph = NetGraph(spec)
         # 'f16' = the reference's own reduced precision (use_fp16 -> net.cast('float16'), car/YOLO.py:98-100; the executor's fp16
         # flag, yolo_gluon.py:204-214): fp16 activations and weights on v_mfma_f32_32x32x16_f16 -- the bf16 MFMA rate with three more
@@ -195,7 +197,7 @@ class CarNet(object):
             raw_stem = self.dtype in _SPLIT and c is self.graph.stem and c.cin == 3
             nbytes = 0 if raw_stem else lib.yolo_packed_weight_bytes(c.cout, c.cin, c.k, dt)
             if nbytes < 0:
-                raise L.YoloError('unsupported conv %s%s' % (c.name, " (dtype 'bf16x3' needs channel counts in multiples of 8)"
+                raise L.YoloError('unsupported conv %s%s' % (c.name, " (the split dtypes need channel counts in multiples of 8)"
                                                              if self.dtype in _SPLIT else ''))
             cp = lib.yolo_padded_channels(c.cout)
             if c.name in self._prepared:
@@ -577,7 +579,7 @@ class CarNet(object):
                                       L.ptr(x), B, H, W, 3, g.stem.cout), g.stem.name))
             plan.act[g.stem.name] = (x, shp)
         elif self.dtype in _SPLIT:
-            raise L.YoloError("dtype 'bf16x3' needs a 3 -> 8 / 16 / 32 / 64-channel 3x3 stem (use dtype='f32' for this spec)")
+            raise L.YoloError("dtype '%s' needs a 3 -> 8 / 16 / 32 / 64-channel 3x3 stem (use dtype='f32' for this spec)" % self.dtype)
         else:
             plan.x_nhwc = torch.empty((B, H, W, 8), dtype=tdt, device=self.device)
             x, shp = self._conv_op(plan, g.stem, plan.x_nhwc, (B, H, W, 8), cin=8)
@@ -662,7 +664,7 @@ class CarNet(object):
                 x, shp = cat, tuple(cat.shape[:3]) + (cat.shape[-1],)
                 continue
             if self.dtype in _SPLIT:
-                raise L.YoloError("dtype 'bf16x3' needs fuse_concat=True (the up-sample + concat copy kernel takes single-plane types)")
+                raise L.YoloError("dtype '%s' needs fuse_concat=True (the up-sample + concat copy kernel takes single-plane types)" % self.dtype)
             x, shp = self._conv_op(plan, g.transitions[i], route, rshp)
             cat = torch.empty((rs[0], rs[1], rs[2], shp[3] + rs[3]), dtype=tdt, device=self.device)
             plan.buffers.append(cat)
@@ -823,7 +825,7 @@ class CarNet(object):
         self.plan_kernels(B, H, W)
         plan = self._plans[(B, H, W)]
         by_name = {c.name: c for c in self.graph.convs()}
-        es = 2 if self.dtype in ('bf16', 'f16') else 4       # (bf16x3: two 2-byte planes per value, weights as a hi + lo pair)
+        es = 2 if self.dtype in ('bf16', 'f16') else 4       # (split types: two 2-byte planes per value, weights as a hi + lo pair)
         out = {}
         for kind, d, name in plan.ops:
             if kind != 'conv':
