@@ -919,6 +919,16 @@ def main():
                                                        'net_tflops': round(fl6x * v6x / 1e12, 1),
                                                        'frac_of_bf16_peak_executed': round(3 * fl6x * v6x / 1e12 / MFMA_PEAK_TFLOPS['bf16'], 4)}
             del x6x, det6x
+        # ... and the IEEE-half sibling of the split path (dtype 'f16x3': boxes at the fp32 path's own distance from the oracle)
+        del netx3
+        torch.cuda.empty_cache()
+        netx3 = CarNet(spec, dtype='f16x3', device=dev, tune='measure').initialize(seed=1234)
+        if args.plan_state is not None:
+            netx3.load_tuning_state(args.plan_state)
+        netx3.prepare()
+        elh = min(timed_pass(netx3, det, x32, 'top1_blocking', kx3, 3, fence)[0] for _ in range(2))
+        out['parity_path']['f16x3'] = {'value': round(B * kx3 / elh, 2), 'unit': 'images/s', 'ms_per_step': round(elh / kx3 * 1e3, 4),
+                                       'note': 'split f16 (22 significant bits): decoded boxes ~9e-5 of the fp32 oracle; needs activations inside IEEE half range'}
         net32 = netx3
         # ... and the reference's own reduced precision (use_fp16, car/YOLO.py:98-100) on the same workload: the bf16 MFMA rate minus
         # what the power cap takes, 12x closer to the fp32 oracle on the decoded boxes (cpu_baseline.box_parity)
