@@ -29,10 +29,10 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 120:
     pad = k // 2; Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
     r = rng.standard_normal((N, cout, Ho, Wo)).astype(np.float32) if res else None
     u = rng.random()
-    dt = 'f32' if u < 0.2 else ('bf16x3' if u < 0.55 else 'bf16')      # (bf16x3, round 6: against the split arithmetic restated on the CPU)
-    if dt == 'bf16x3':
+    dt = 'f32' if u < 0.15 else ('bf16x3' if u < 0.4 else 'f16x3' if u < 0.65 else 'bf16')      # (split types, round 6: against the split arithmetic restated on the CPU)
+    if dt in ('bf16x3', 'f16x3'):
         if cin % 8 or cout % 8: continue
-        want = ref_conv_split(x, w, scale, bias, s, slope, residual=r)
+        want = ref_conv_split(x, w, scale, bias, s, slope, residual=r, rdt=torch.bfloat16 if dt == 'bf16x3' else torch.float16)
     else:
         want = ref_conv(x, w, scale, bias, s, slope, residual=r, bf16=(dt == 'bf16'))
     ncase += 1
@@ -47,7 +47,7 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 120:
         nrun += 1
         if np.isnan(got).any():
             bad.append(('NaN (unwritten output)', algo, (N, cin, H, W, cout, k, s, res, slope))); continue
-        err = np.abs(got - want); tol = {'bf16': 0.02, 'f32': 2e-4, 'bf16x3': 4e-5}[dt] * np.maximum(np.abs(want), 1.0)       # ~2 bf16 ulps of the result + slack for order
+        err = np.abs(got - want); tol = {'bf16': 0.02, 'f32': 2e-4, 'bf16x3': 4e-5, 'f16x3': 4e-5}[dt] * np.maximum(np.abs(want), 1.0)       # ~2 bf16 ulps of the result + slack for order
         if (err > tol).any():
             bad.append(('mismatch %.3g' % float(err.max()), dt, algo, (N, cin, H, W, cout, k, s, res, slope)))
 print('cases %d, kernel runs %d, problems %d' % (ncase, nrun, len(bad)))

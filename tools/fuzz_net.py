@@ -23,20 +23,20 @@ while time.time() - t0 < budget:
     B = int(rng.choice([1, 2, 3, 5]))
     if B * H * W * channels[1] > 4e7: continue
     u_ = rng.random()
-    dtype = 'f32' if u_ < 0.2 else ('bf16x3' if u_ < 0.55 else 'bf16')      # (bf16x3, round 6: held to the fp32 bar)
+    dtype = 'f32' if u_ < 0.15 else ('bf16x3' if u_ < 0.4 else 'f16x3' if u_ < 0.65 else 'bf16')      # (split types, round 6: held to the fp32 bar)
     try:
         g = og.build_graph(spec)
         P = og.init_params(g, seed=int(rng.integers(1000)), bn='random')
         x = rng.random((B, 3, H, W), dtype=np.float32)
         kw = dict(fuse_stem=bool(rng.random() < 0.7), fuse_res=bool(rng.random() < 0.7), fuse_concat=bool(rng.random() < 0.7), side_stream=bool(rng.random() < 0.5))
-        if dtype == 'bf16x3':
+        if dtype in ('bf16x3', 'f16x3'):
             kw['fuse_concat'] = True                 # (the split type has no up-sample + concat copy kernel: the fused form only)
         net = CarNet(spec, dtype=dtype, device=dev, **kw).load_params(P)
         outs = [o.cpu().numpy() for o in net(torch.from_numpy(x).to(dev))]
         ref = [r.numpy() for r in of.forward_torch(g, P, x)]
         ctx = (dtype, layers, channels, ncls, (H, W), B, kw)
         ncase += 1
-        if dtype in ('f32', 'bf16x3'):
+        if dtype in ('f32', 'bf16x3', 'f16x3'):
             e = max(float(np.abs(o - r).max()) for o, r in zip(outs, ref))
             if not e < 1e-3: bad.append(('%s logits' % dtype, e, ctx))
         else:
