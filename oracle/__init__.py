@@ -14,4 +14,14 @@ fp32 in ``forward.forward_torch``) that must agree, analytic known answers
 (zero logits -> score 0.5, boxes = anchors at cell centres; IoU(self) = 1), and
 the structural cross-check against the shapes the reference author recorded
 in comments (car/YOLO.py:135, :661-662).
+
+PINNED, since round 6, are the few rows whose reference code runs without mxnet:
+``detect.predict_LP`` (licence_plate/LP_detection.py:147-162, its numpy branch),
+``detect.sigmoid`` / ``train.inv_sigmoid`` (yolo_gluon.py:370-377) and
+``render.project_plate`` (ProjectRectangle6D, licence_plate_render/__init__.py:336-377)
+are held to outputs of the reference's OWN functions, executed in the build
+container by tests/golden/make_reference_vectors.py (it reads their definitions
+from /root/reference and runs them on numpy; the committed vectors are data) --
+tests/test_reference_vectors.py.  Everything that needs mxnet / gluoncv -- the
+network, decode, losses, Adam -- stays unpinned.
 """

@@ -87,3 +87,15 @@ def test_lp_branch_vs_golden(cuda):
     g = dl.cpu().numpy()
     np.testing.assert_allclose(np.abs(g).sum(), z['grad_sum'][0], rtol=1e-4)
     np.testing.assert_allclose(g.reshape(-1)[::37], z['grad_sel'], rtol=1e-3, atol=1e-7)
+
+
+def test_predict_lp_vs_the_reference_itself(cuda):
+    """SURVEY row a21 against outputs of the reference's OWN `predict_LP` (numpy branch, licence_plate/LP_detection.py:147-162), run in
+    the build container by tests/golden/make_reference_vectors.py: the HIP kernel picks the same cell (first index among ties) and
+    returns the same pose row (device expf against numpy's: a few float32 ulps)."""
+    from yolo_amd.detect import predict_LP
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_vectors.npz'))
+    for k in range(int(G['lp_cases'])):
+        x, want, r_max = G['lp_in_%d' % k], G['lp_out_%d' % k], [float(v) for v in G['lp_rmax_%d' % k]]
+        got = predict_LP(torch.from_numpy(x).to(cuda), r_max)
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-7, err_msg='case %d' % k)
