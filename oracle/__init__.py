@@ -17,8 +17,11 @@ in comments (car/YOLO.py:135, :661-662).
 
 PINNED, since round 6, are the few rows whose reference code runs without mxnet:
 ``detect.predict_LP`` (licence_plate/LP_detection.py:147-162, its numpy branch),
-``detect.sigmoid`` / ``train.inv_sigmoid`` (yolo_gluon.py:370-377) and
-``render.project_plate`` (ProjectRectangle6D, licence_plate_render/__init__.py:336-377)
+``detect.init_steps`` / ``init_area`` (car/YOLO.py:112-121),
+``detect.sigmoid`` / ``train.inv_sigmoid`` (yolo_gluon.py:370-377),
+``render.project_plate`` (ProjectRectangle6D, licence_plate_render/__init__.py:336-377),
+``render.draw_plate`` (LPGenerator.draw_LP, :60-77) and ``render.enhance``
+(yolo_cv.PILImageEnhance, yolo_cv.py:97-157)
 are held to outputs of the reference's OWN functions, executed in the build
 container by tests/golden/make_reference_vectors.py (it reads their definitions
 from /root/reference and runs them on numpy; the committed vectors are data) --

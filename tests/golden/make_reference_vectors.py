@@ -10,6 +10,12 @@ The functions used here do not touch mxnet on the path exercised:
   * `np_sigmoid`, `np_inv_sigmoid`                                        yolo_modules/yolo_gluon.py:370-377       (used by a21 / a15)
   * `ProjectRectangle6D.__call__` / `.projection_matrix`                  yolo_modules/licence_plate_render/__init__.py:336-377  (row f2)
   * the camera calibration the projection reads                          camera_parameter/C310_4.yaml
+  * `LPGenerator.draw_LP` (PIL + numpy.random) with the statements of `LPGenerator.__init__` that set up what it uses (plate sizes,
+    glyph columns, the glyph / dot images and their resizing), on a SYNTHETIC glyph set (tests/test_render.py:_fonts -- the
+    reference's glyph PNGs stay with the reference) and `yolo_cv._color`           licence_plate_render/__init__.py:23-40,60-77,
+                                                                                  yolo_modules/yolo_cv.py:11-20   (row f2)
+  * `YOLO._init_step`, `YOLO._init_area` (the anchor grid's strides and cell counts)      car/YOLO.py:112-121 (row a10)
+  * `yolo_cv.PILImageEnhance` (random rotate / blur / noise) and `RenderCar._resize`      yolo_modules/yolo_cv.py:97-157, car/render_car.py:379-407 (row f2)
 
 Their DEFINITIONS are read from the reference's files where they lie under /root/reference -- located with `ast` (or, in the Python-2
 file, by their `def` line and indentation) -- and executed with their real dependencies (numpy, math).  Nothing of mxnet is stubbed
@@ -106,6 +112,81 @@ def main():
     out['proj_poses'] = poses
     out['proj_points'] = np.stack([proj(list(q)) for q in poses])
     out['proj_camera'] = np.array([cam['image_width'], cam['image_height'], P[0], P[5], P[2], P[6]], np.float64)
+    # ---- LPGenerator.draw_LP: the random draw sequence and the paste geometry of a plate -----------------------------------------------
+    import sys
+    import tempfile
+    import PIL.Image
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+    from test_render import _fonts                       # the synthetic glyph set the repo's own render tests use
+    lsrc = open(os.path.join(REF, 'yolo_modules/licence_plate_render/__init__.py')).read()
+    ltree = ast.parse(lsrc)
+    lcls = next(n for n in ltree.body if isinstance(n, ast.ClassDef) and n.name == 'LPGenerator')
+    init = next(n for n in lcls.body if isinstance(n, ast.FunctionDef) and n.name == '__init__')
+    seg = lambda n: textwrap.dedent('\n'.join(lsrc.split('\n')[n.lineno - 1:n.end_lineno]))
+    # the statements of __init__ that prepare what draw_LP reads; the ones that need mxnet / yolo_cv objects / the module's own
+    # directory are left out (fonts_dir is bound to the synthetic set instead)
+    keep = [seg(n) for n in init.body if not any(w in seg(n) for w in ('mxnet', 'yolo_cv', 'ProjectRectangle6D', 'module_dir'))]
+    csrc = open(os.path.join(REF, 'yolo_modules/yolo_cv.py')).read()
+    cnode = next(n for n in ast.parse(csrc).body if isinstance(n, ast.Assign) and getattr(n.targets[0], 'id', '') == '_color')
+    colors = ast.literal_eval(cnode.value)
+    with tempfile.TemporaryDirectory() as tmp:
+        fonts_dir = os.path.join(tmp, 'fonts')
+        _fonts(fonts_dir)
+        gen = types.SimpleNamespace()
+        ns2 = {'np': np, 'PIL': PIL, 'os': os, 'self': gen, 'fonts_dir': fonts_dir, 'img_h': 96, 'img_w': 160, 'class_index': 1,
+               'yolo_cv': types.SimpleNamespace(_color=colors)}
+        for stmt in keep:
+            _exec(stmt, ns2)
+        _exec(_module_function('yolo_modules/licence_plate_render/__init__.py', 'draw_LP', cls='LPGenerator'), ns2)
+        for k, seed in enumerate((0, 8, 2026)):
+            np.random.seed(seed)
+            plate, lp_type, label = ns2['draw_LP'](gen)
+            out['plate_seed_%d' % k] = np.array(seed)
+            out['plate_rgba_%d' % k] = np.asarray(plate).copy()
+            out['plate_label_%d' % k] = np.array(label, np.float64)
+            out['plate_type_%d' % k] = np.array(lp_type)
+    out['plate_cases'] = np.array(3)
+    # ---- yolo_cv.PILImageEnhance (rotate / blur / noise: PIL + numpy.random; the module imports cv2, the class does not use it) and
+    #      RenderCar._resize, on a synthetic RGBA sprite ------------------------------------------------------------------------------
+    import PIL.ImageFilter
+    cnode = next(n for n in ast.parse(csrc).body if isinstance(n, ast.ClassDef) and n.name == 'PILImageEnhance')
+    ens = {'np': np, 'PIL': PIL}
+    _exec(textwrap.dedent('\n'.join(csrc.split('\n')[cnode.lineno - 1:cnode.end_lineno])), ens)
+    rns = {'np': np, 'PIL': PIL}
+    _exec(_module_function('car/render_car.py', '_resize', cls='RenderCar'), rns)
+    yy, xx = np.mgrid[0:48, 0:80]
+    sprite = np.zeros((48, 80, 4), np.uint8)
+    sprite[..., 0], sprite[..., 1], sprite[..., 2] = (xx * 3) % 256, (yy * 5) % 256, ((xx + yy) * 2) % 256
+    sprite[8:40, 10:70, 3] = 255
+    out['sprite'] = sprite
+    enh = [(30.0, 0.3, 0.0), (0.0, 1.0, 10.0), (0.0, 1.0, 5.0), (30.0, 0.0, 0.0), (15.0, 0.5, 3.0)]      # (R, G, noise_var): RenderCar :43-44, LPGenerator :46-47 / :124
+    for k, (R_, G_, nv) in enumerate(enh):
+        np.random.seed(100 + k)
+        img, r = ens['PILImageEnhance'](M=0., N=0., R=R_, G=G_, noise_var=nv)(PIL.Image.fromarray(sprite))
+        out['enh_args_%d' % k], out['enh_img_%d' % k], out['enh_r_%d' % k] = np.array([R_, G_, nv]), np.asarray(img).copy(), np.array(r, np.float64)
+    out['enh_cases'] = np.array(len(enh))
+    for k, (lo, hi, r1) in enumerate([(0.2, 1.0, 1.0), (0.5, 0.6, 0.8), (1.0, 2.0, 1.3)]):
+        np.random.seed(200 + k)
+        resize, rw, rh, img = rns['_resize'](None, PIL.Image.fromarray(sprite), lo, hi, r1)
+        out['rsz_args_%d' % k], out['rsz_out_%d' % k], out['rsz_img_%d' % k] = np.array([lo, hi, r1]), np.array([resize, rw, rh], np.float64), np.asarray(img).copy()
+    out['rsz_cases'] = np.array(3)
+    # ---- YOLO._init_step / _init_area (car/YOLO.py:112-121, SURVEY row a10: plain Python arithmetic) -----------------------------------
+    gns = {}
+    _exec(_method_by_lines('car/YOLO.py', '_init_step'), gns)
+    _exec(_method_by_lines('car/YOLO.py', '_init_area'), gns)
+    car_v1 = yaml.safe_load(open(os.path.join(REF, 'car/v1/spec.yaml')))
+    test_y = yaml.safe_load(open(os.path.join(REF, 'yolo_modules/test.yaml')))
+    grid_cases = [(car_v1['layers'], car_v1['all_anchors'], (320, 512)), (test_y['layers'], test_y['all_anchors'], (192, 256)),
+                  ([1, 2, 8, 8, 4], car_v1['all_anchors'], (416, 416)), ([1, 2, 8, 8, 4], car_v1['all_anchors'], (608, 608)),
+                  ([1, 1, 2, 1, 1], car_v1['all_anchors'], (64, 96))]
+    for k, (layers, anchors, size) in enumerate(grid_cases):
+        obj = types.SimpleNamespace(layers=layers, all_anchors=anchors, size=list(size))
+        gns['_init_step'](obj)
+        gns['_init_area'](obj)
+        out['grid_layers_%d' % k], out['grid_nscale_%d' % k], out['grid_size_%d' % k] = np.array(layers), np.array(len(anchors)), np.array(size)
+        out['grid_steps_%d' % k], out['grid_area_%d' % k] = np.array(obj.steps), np.array(obj.area)
+    out['grid_cases'] = np.array(len(grid_cases))
     np.savez_compressed(OUT, **out)
     print('wrote %s: %d arrays, %d bytes' % (OUT, len(out), os.path.getsize(OUT)))
 

@@ -6,6 +6,11 @@ runs them on numpy; the vectors are data: inputs + the reference's outputs):
   * `np_sigmoid` / `np_inv_sigmoid` (yolo_modules/yolo_gluon.py:370-377)                -> oracle.detect.sigmoid, oracle.train.inv_sigmoid
   * `ProjectRectangle6D` (licence_plate_render/__init__.py:336-377, row f2)             -> oracle.render.project_plate,
                                                                                             yolo_amd.render.PlateCamera.corners / centre
+  * `LPGenerator.draw_LP` (:60-77), `yolo_cv.PILImageEnhance` (yolo_cv.py:97-157),
+    `RenderCar._resize` (render_car.py:379-407), all row f2                              -> oracle.render.draw_plate / enhance,
+                                                                                            yolo_amd.render.LPGenerator / RenderCar
+  * `YOLO._init_step` / `_init_area` (car/YOLO.py:112-121, row a10)                     -> oracle.detect.init_steps / init_area,
+                                                                                            NetGraph.steps, make_grid
 These rows of the oracle are PINNED; everything else stays "parity unpinned" (oracle/__init__.py).  The HIP `predict_LP` kernel is
 held to the same vectors by tests/test_gpu_golden.py::test_predict_lp_vs_the_reference_itself.
 """
@@ -50,3 +55,73 @@ def test_plate_projection_matches_the_reference():
     # the frontal pose at 3 m: a 399 x 168 mm plate, centred on the optical axis
     p0 = G['proj_points'][0]
     assert abs((p0[0, 0] - p0[1, 0]) - fx * 399.0 / 3000.0) < 1e-3 and abs((p0[0, 1] - p0[3, 1]) - fy * 168.0 / 3000.0) < 1e-3
+
+
+def test_plate_drawing_matches_the_reference(tmp_path):
+    """`LPGenerator.draw_LP` (licence_plate_render/__init__.py:60-77) run from the reference with numpy's global seed set, on the
+    synthetic glyph set: the product's `LPGenerator.draw_LP` and the oracle's `draw_plate` draw the same letters and digits (the same
+    `np.random` sequence: three of 10..33, four of 0..8 with 4 -> 9), paste them at the same columns -- the same RGBA plate, pixel
+    for pixel -- and return the same glyph labels."""
+    from PIL import Image
+    from test_render import _fonts, CAMERA
+    from yolo_amd import render
+    _fonts(str(tmp_path / 'fonts'))
+    gen = render.LPGenerator(96, 160, str(tmp_path / 'fonts'), CAMERA, augment=False)
+    font = [Image.open(str(tmp_path / 'fonts' / ('%d.png' % k))).resize((45, 90), Image.BILINEAR) for k in range(34)]
+    dot = Image.open(str(tmp_path / 'fonts' / '34.png')).resize((10, 70), Image.BILINEAR)
+    for k in range(int(G['plate_cases'])):
+        seed = int(G['plate_seed_%d' % k])
+        np.random.seed(seed)
+        plate, lp_type, glyphs = gen.draw_LP()
+        assert lp_type == int(G['plate_type_%d' % k])
+        assert np.array_equal(np.asarray(plate), G['plate_rgba_%d' % k]), 'seed %d: the plate differs from the reference\'s' % seed
+        np.testing.assert_allclose(np.array(glyphs, np.float64), G['plate_label_%d' % k], rtol=1e-12)
+        np.random.seed(seed)
+        assert np.array_equal(np.asarray(orr.draw_plate(font, dot)), G['plate_rgba_%d' % k])
+
+
+def test_enhance_and_resize_match_the_reference():
+    """`yolo_cv.PILImageEnhance.__call__` (random rotate by U(-R, R) with expand, Gaussian blur of radius rand() * G, N(0, noise_var)
+    noise; yolo_cv.py:97-157) and `RenderCar._resize` (render_car.py:379-407), run from the reference under numpy's global seed on a
+    synthetic RGBA sprite: the oracle's `enhance` and the product's `RenderCar._enhance` / `_resize` consume the random stream in the
+    same order and return the same pixels."""
+    from PIL import Image
+    from yolo_amd import render
+    sprite = Image.fromarray(G['sprite'])
+    for k in range(int(G['enh_cases'])):
+        R_, G_, nv = [float(v) for v in G['enh_args_%d' % k]]
+        np.random.seed(100 + k)
+        img, r = orr.enhance(sprite, R=R_, G=G_, noise_var=nv)
+        assert np.array_equal(np.asarray(img), G['enh_img_%d' % k]) and abs(r - float(G['enh_r_%d' % k])) < 1e-15, 'oracle, case %d' % k
+        if nv == 0.0:                                      # (RenderCar's enhancer: noise_var = 0, render_car.py:43-44)
+            rc = object.__new__(render.RenderCar)
+            rc.R, rc.G = R_, G_
+            np.random.seed(100 + k)
+            img, r = rc._enhance(sprite)
+            assert np.array_equal(np.asarray(img), G['enh_img_%d' % k]) and abs(r - float(G['enh_r_%d' % k])) < 1e-15, 'product, case %d' % k
+    rc = object.__new__(render.RenderCar)
+    for k in range(int(G['rsz_cases'])):
+        lo, hi, r1 = [float(v) for v in G['rsz_args_%d' % k]]
+        np.random.seed(200 + k)
+        resize, rw, rh, img = rc._resize(sprite, lo, hi, r1)
+        np.testing.assert_allclose([resize, rw, rh], G['rsz_out_%d' % k], rtol=1e-15)
+        assert np.array_equal(np.asarray(img), G['rsz_img_%d' % k])
+
+
+def test_grid_steps_and_areas_match_the_reference():
+    """`YOLO._init_step` / `_init_area` (car/YOLO.py:112-121, row a10) run from the reference for its own car/v1 and test.yaml specs and
+    the D53 / micro specs: the oracle's `init_steps` / `init_area`, the product's `NetGraph.steps()` and the grid descriptor the HIP
+    decode reads (`make_grid`: cells per scale) give the same strides and cell counts."""
+    from yolo_amd.spec import NetGraph
+    from yolo_amd.detect import make_grid
+    anchors3 = [[[0.1, 0.1]] * 3] * 3
+    for k in range(int(G['grid_cases'])):
+        layers, nscale, size = [int(v) for v in G['grid_layers_%d' % k]], int(G['grid_nscale_%d' % k]), tuple(int(v) for v in G['grid_size_%d' % k])
+        steps, area = [int(v) for v in G['grid_steps_%d' % k]], [int(v) for v in G['grid_area_%d' % k]]
+        anchors = anchors3[:nscale]
+        assert od.init_steps(layers, anchors) == steps
+        assert od.init_area(size, steps) == area
+        spec = dict(layers=layers, channels=[8 * 2 ** i for i in range(len(layers) + 1)], all_anchors=anchors, slice_point=[1, 3, 5, 6, 30])
+        assert NetGraph(spec).steps() == steps
+        g, nbox = make_grid(anchors, size, steps)
+        assert [g.gh[i] * g.gw[i] for i in range(nscale)] == area and nbox == 3 * sum(area) and [g.step[i] for i in range(nscale)] == steps
