@@ -73,7 +73,9 @@ while time.time() - t0 < budget:
         close(form + ' running_var', rv, 0.9 + 0.1 * var.detach(), 1e-4, 1e-6, ctx)
         if not bool(chan_ok.any()):
             continue
-        gscale = float(yf.grad[:, chan_ok].abs().max()) + 1e-6
+        # (a batch of two pixels normalises to +-1: its true dy is ~0 and everything left is rounding noise of O(eps * dz) -- the
+        #  scale of the comparison does not go below that; found by seed 61 in round 6)
+        gscale = max(float(yf.grad[:, chan_ok].abs().max()), 1e-4 * float(dz.float().abs().max())) + 1e-6
         close(form + ' dy', dyd[:, chan_ok], yf.grad[:, chan_ok], tol[0] * 10, tol[1] * gscale * (1 if dtype == 'bf16' else 10), ctx)
         close(form + ' dgamma', dg[chan_ok], gam.grad[chan_ok], 2e-3, 2e-3 * (float(gam.grad[chan_ok].abs().max()) + 1e-6), ctx)
         close(form + ' dbeta', db[chan_ok], bet.grad[chan_ok], 2e-3, 2e-3 * (float(bet.grad[chan_ok].abs().max()) + 1e-6), ctx)
