@@ -250,6 +250,7 @@ def cpu_baseline(size, seconds=6.0, batch=32, dev=None, plan_state=None, plan_ba
             ref = [o.numpy() for o in of.forward_torch(g, Pt, x)]
         ref_rows = od.decode_all(ref, spec['slice_point'], size, syxhw)
         _, ref_idx = od.predict(ref, spec['slice_point'], size, syxhw)
+        ref_kept = [[int(v) for v in od.nms(ref_rows[i], mode='class')[0]] for i in range(2)]
         det = Detector(spec, size, steps, device=dev)
         parity = {'sample': 'images 0-1 of the cpu_baseline sample (D53 spec, identity BN, Xavier weights seed 0), decoded rows vs the fp32 oracle',
                   'measure': 'max / RMS of |a - b| / (1 + |b|) over [l,t,r,b] of all %d boxes' % ref_rows.shape[1]}
@@ -266,9 +267,16 @@ def cpu_baseline(size, seconds=6.0, batch=32, dev=None, plan_state=None, plan_ba
             _, idx = det.predict_device(outs)
             idx = idx[:2]
             e = (rows[..., 1:5].astype(np.float64) - ref_rows[..., 1:5]) / (1.0 + np.abs(ref_rows[..., 1:5]))
+            # per-class NMS end to end: this path's logits through the HIP decode + NMS against the oracle's logits through the oracle's
+            # own decode + NMS (north_star: "kept indices")
+            rows_d = det.decode(outs)
+            kept, _, cnt = det.nms(rows_d, 'class', scores=det.nms_scores(rows_d, 'class'))
+            kept, cnt = kept.cpu().numpy()[:2], cnt.cpu().numpy()[:2]
+            same = [[int(v) for v in kept[i, :int(cnt[i])]] == ref_kept[i] for i in range(2)]
             parity[dt] = {'box_max': float(np.abs(e).max()), 'box_rms': float(np.sqrt(np.mean(e * e))),
                           'score_max': float(np.abs(rows[..., 0] - ref_rows[..., 0]).max()),
-                          'top1_index_agreement': float(np.mean(idx.cpu().numpy() == ref_idx))}
+                          'top1_index_agreement': float(np.mean(idx.cpu().numpy() == ref_idx)),
+                          'nms_kept_lists_identical': float(np.mean(same))}
             del net
         torch.cuda.empty_cache()
     flops_img = 113.26e9 * (size[0] * size[1]) / (416.0 * 416.0)          # 113.26 GFLOP per 416x416 image, ~ pixels
