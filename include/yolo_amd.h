@@ -9,7 +9,7 @@
  * unsupported shape, >0 = hipError_t from the launch.  Nothing throws across the ABI.
  *
  * Layout: activations are NHWC ("pixel-major, channel-contiguous") in HBM, dtype
- * YOLO_F32 or YOLO_BF16; images enter as NCHW float32 exactly as the reference feeds them
+ * YOLO_F32, YOLO_BF16, YOLO_F16 or a split type (YOLO_BF16X3 / YOLO_F16X3: two planes per pixel, below); images enter as NCHW float32 exactly as the reference feeds them
  * (car/YOLO.py:381, yolo_gluon.py:354) and head logits leave as (B, sum HW, A, C) float32
  * exactly as CarNet returns them (car/utils.py:95, basic_yolo.py:102-103).
  */
@@ -99,7 +99,7 @@ typedef struct yolo_conv_desc {
     void* y;               /* (N,Ho,Wo,Cout) dtype, or float32 when out_f32                   */
     int N, H, W, Cin, Cout;
     int ksize, stride;
-    int dtype;             /* YOLO_F32 | YOLO_BF16 | YOLO_F16: activations and weights        */
+    int dtype;             /* YOLO_F32 | YOLO_BF16 | YOLO_F16 | YOLO_BF16X3 | YOLO_F16X3: activations and weights */
     int out_f32;           /* 1: y is float32 (head logits)                                   */
     float slope;           /* LeakyReLU negative slope in [0, 1]; 1.0f = linear               */
     long long y_batch_stride; /* elements between images in y; 0 = dense Ho*Wo*Cout           */
@@ -146,7 +146,7 @@ typedef struct yolo_conv_desc {
     float tail_slope;
     long long tail_y_batch_stride;
     long long tail_y_pixel_stride;
-    /* YOLO_BF16X3 only (ignored otherwise): elements between a pixel's hi plane and its lo plane in x and in y; 0 = dense
+    /* split types only (YOLO_BF16X3 / YOLO_F16X3; ignored otherwise): elements between a pixel's hi plane and its lo plane in x and in y; 0 = dense
      * (round_up(Cin, 32), round_up(Cout, 32)).  A channel slice of a wider split buffer of Ctot channels (the halves of a concat
      * buffer, car/utils.py:93) has pixel stride 2 * Ctot and lo offset Ctot.  Dense strides of a split tensor count both padded
      * planes (pixel stride 2 * round_up(C, 32)); the residual is dense; y_lo_offset is not used when out_f32. */
@@ -165,7 +165,7 @@ int yolo_conv_kernel_name(const yolo_conv_desc* d, char* buf, int len);
 /* The network's first _conv2d (basic_yolo.py:20) fused with the image layout change: Conv3x3 s1 p1 over
  * the (N,3,H,W) float32 NCHW image exactly as the reference feeds it (car/YOLO.py:381) + folded BN +
  * LeakyReLU -> (N,H,W,Cout) bf16 NHWC.  w_oihw: (Cout,3,3,3) float32 (unpacked); Cout % 4 == 0, <= 64;
- * dtype YOLO_BF16 / YOLO_F16 (YOLO_F32 callers use yolo_nchw_to_nhwc + yolo_conv_fwd: EUNSUPPORTED here), or YOLO_BF16X3: a direct
+ * dtype YOLO_BF16 / YOLO_F16 (YOLO_F32 callers use yolo_nchw_to_nhwc + yolo_conv_fwd: EUNSUPPORTED here), or YOLO_BF16X3 / YOLO_F16X3: a direct
  * fp32 convolution on the vector pipe (K = 27: nothing for the matrix pipe to win) whose output is stored split, dense
  * (N,H,W,[hi Cout | lo Cout]); Cout % 8 == 0 there. */
 int yolo_stem_conv_fwd(const float* x_nchw, const float* w_oihw, const float* scale, const float* bias,
