@@ -384,6 +384,14 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
 // between the variants' inner loops.  The per-variant factors are measured (tools/conv_bench.py).
 static int conv_auto_algo(const ConvArgs& a, int ks, int stride, int dtype, bool px_heavy = true) {
     if ((!dtype_split(dtype) && (a.Cin * elem_size(dtype)) % 64) || (ks == 1 && a.nchunks < 2)) return 1;      // (split planes are padded to whole chunks)
+    if (dtype_split(dtype)) {
+        // split types (round 6, measured at 416x416 bs 32, tools/layer_times.py --dtype bf16x3): the first stages' narrow layers are not
+        // covered by fused / streaming kernels there -- the 64-cout tiles for them (1x1 64 -> 32 at 208^2: 129 us against 567 on a
+        // 256-cout tile), the generic kernel for the large-map stride-2 layers (32 -> 64 at 416^2: 432 us against 602)
+        if (ks == 1 && a.Cout <= 64) return 40;
+        if (ks == 3 && stride == 1 && a.Cout <= 64) return 41;
+        if (ks == 3 && stride == 2 && a.Cin <= 64) return 1;
+    }
     if (stride == 2) return ks == 3 ? (a.Cout > 128 ? 18 : 9) : 1;      // (18 = 10 with the 4-slot weight ring)
     struct V { int algo, bp, bc, bpc; float f; bool k1; };
     // (round 5: the pixel-heavy 3x3 tiles 27 / 28 -- ~40 % less L2 -> LDS weight stream per output, measured 0.5-3.4 % faster than
