@@ -22,6 +22,7 @@ PINNED, since round 6, are the few rows whose reference code runs without mxnet:
 ``render.project_plate`` (ProjectRectangle6D, licence_plate_render/__init__.py:336-377),
 ``render.draw_plate`` (LPGenerator.draw_LP, :60-77) and ``render.enhance``
 (yolo_cv.PILImageEnhance, yolo_cv.py:97-157)
+(and, product only, the box row's azimuth: RadarProb.cls2ang, yolo_cv.py:85-95)
 are held to outputs of the reference's OWN functions, executed in the build
 container by tests/golden/make_reference_vectors.py (it reads their definitions
 from /root/reference and runs them on numpy; the committed vectors are data) --

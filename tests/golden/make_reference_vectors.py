@@ -15,6 +15,7 @@ The functions used here do not touch mxnet on the path exercised:
     reference's glyph PNGs stay with the reference) and `yolo_cv._color`           licence_plate_render/__init__.py:23-40,60-77,
                                                                                   yolo_modules/yolo_cv.py:11-20   (row f2)
   * `YOLO._init_step`, `YOLO._init_area` (the anchor grid's strides and cell counts)      car/YOLO.py:112-121 (row a10)
+  * `RadarProb.cls2ang` / `_numpy_softmax` (azimuth of the published box row)           yolo_modules/yolo_cv.py:85-95, 234-236 (row f4)
   * `yolo_cv.PILImageEnhance` (random rotate / blur / noise) and `RenderCar._resize`      yolo_modules/yolo_cv.py:97-157, car/render_car.py:379-407 (row f2)
 
 Their DEFINITIONS are read from the reference's files where they lie under /root/reference -- located with `ast` (or, in the Python-2
@@ -187,6 +188,21 @@ def main():
         out['grid_layers_%d' % k], out['grid_nscale_%d' % k], out['grid_size_%d' % k] = np.array(layers), np.array(len(anchors)), np.array(size)
         out['grid_steps_%d' % k], out['grid_area_%d' % k] = np.array(obj.steps), np.array(obj.area)
     out['grid_cases'] = np.array(len(grid_cases))
+    # ---- RadarProb.cls2ang + _numpy_softmax (yolo_cv.py:85-95, 234-236): the azimuth of the /YOLO/box row = atan2 of the softmax-weighted
+    #      mean direction of the 24 azimuth classes -- the arithmetic car/video_node.py:244-251 repeats inline (row f4).  The direction
+    #      tables are INPUT here (cos / sin of k * 15 degrees): the reference builds them with Python-2 integer division (:24-26)
+    ans = {'np': np, 'math': math}
+    _exec(_module_function('yolo_modules/yolo_cv.py', '_numpy_softmax'), ans)
+    _exec(_module_function('yolo_modules/yolo_cv.py', 'cls2ang', cls='RadarProb'), ans)
+    radar = types.SimpleNamespace(cos_offset=np.array([math.cos(k * 15 * math.pi / 180) for k in range(24)]),
+                                  sin_offset=np.array([math.sin(k * 15 * math.pi / 180) for k in range(24)]))
+    logits = (rng.standard_normal((16, 24)) * 3).astype(np.float32)
+    logits[0] = 0.0
+    logits[1, 5] = 30.0
+    res = [ans['cls2ang'](radar, 0.75, logits[k].copy()) for k in range(len(logits))]
+    out['azi_logits'] = logits
+    out['azi_angle'] = np.array([r_[0] for r_ in res], np.float64)
+    out['azi_radius'] = np.array([r_[1] for r_ in res], np.float64)
     np.savez_compressed(OUT, **out)
     print('wrote %s: %d arrays, %d bytes' % (OUT, len(out), os.path.getsize(OUT)))
 

@@ -125,3 +125,15 @@ def test_grid_steps_and_areas_match_the_reference():
         assert NetGraph(spec).steps() == steps
         g, nbox = make_grid(anchors, size, steps)
         assert [g.gh[i] * g.gw[i] for i in range(nscale)] == area and nbox == 3 * sum(area) and [g.step[i] for i in range(nscale)] == steps
+
+
+def test_box_row_azimuth_matches_the_reference():
+    """`RadarProb.cls2ang` (yolo_cv.py:85-95) run from the reference: the azimuth `deploy.car_box_row` writes into element 5 of the
+    published /YOLO/box row (car/video_node.py:244-251 repeats the same arithmetic inline) is the reference's angle."""
+    from yolo_amd.deploy import car_box_row
+    for logits, want in zip(G['azi_logits'], G['azi_angle']):
+        pred = np.zeros((1, 30), np.float32)
+        pred[0, 6:] = logits
+        got = car_box_row(pred)[5]
+        assert abs(float(got) - float(want)) < 2e-6 or abs(abs(float(got) - float(want)) - 2 * np.pi) < 2e-6, (got, want)
+    assert abs(G['azi_radius'][0] - 0.0) < 1e-9                           # uniform classes: no direction (radius 0)
