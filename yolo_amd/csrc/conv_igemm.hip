@@ -478,7 +478,7 @@ static int conv_dispatch(const yolo_conv_desc* d, void* stream, const NameOut* n
     if (split) {
         const long long xlo = d->x_lo_offset ? d->x_lo_offset : cin_p;
         const long long ylo = d->y_lo_offset ? d->y_lo_offset : cout_p;
-        if (xlo < cin_p || xlo + d->Cin > a.x_ps || (xlo * es) % 16) return YOLO_EINVAL;
+        if (xlo < cin_p || xlo + d->Cin > a.x_ps || (xlo * es) % 16 || xlo * es > 0x3fffffffLL) return YOLO_EINVAL;      // (the plane offsets are 32-bit byte adjustments in the kernels)
         if (!d->out_f32 && (ylo < d->Cout || (ylo * es) % 16)) return YOLO_EINVAL;      // (fp32 logits are not split: y_lo unused)
         a.x3_n = cin_p * es / 64;
         a.x3_adj1 = (int)(xlo * es) - a.x3_n * 64;
