@@ -65,7 +65,7 @@ def _exec(src, ns):
     return ns
 
 
-def main():
+def main(out_path=OUT):
     out = {}
     # ---- np_sigmoid / np_inv_sigmoid (the reference's module calls numpy `numpy`) ----------------------------------------------
     g = {'numpy': np}
@@ -203,8 +203,8 @@ def main():
     out['azi_logits'] = logits
     out['azi_angle'] = np.array([r_[0] for r_ in res], np.float64)
     out['azi_radius'] = np.array([r_[1] for r_ in res], np.float64)
-    np.savez_compressed(OUT, **out)
-    print('wrote %s: %d arrays, %d bytes' % (OUT, len(out), os.path.getsize(OUT)))
+    np.savez_compressed(out_path, **out)
+    print('wrote %s: %d arrays, %d bytes' % (out_path, len(out), os.path.getsize(out_path)))
 
 
 if __name__ == '__main__':

@@ -137,3 +137,22 @@ def test_box_row_azimuth_matches_the_reference():
         got = car_box_row(pred)[5]
         assert abs(float(got) - float(want)) < 2e-6 or abs(abs(float(got) - float(want)) - 2 * np.pi) < 2e-6, (got, want)
     assert abs(G['azi_radius'][0] - 0.0) < 1e-9                           # uniform classes: no direction (radius 0)
+
+
+def test_the_vectors_regenerate_from_the_reference(tmp_path):
+    """Where the reference is present (the build container; it never travels to the GPU box), running the generator again -- i.e. the
+    reference's own functions, read from /root/reference and executed -- reproduces the committed vectors array for array."""
+    import importlib.util
+    import pytest
+    if not os.path.isdir('/root/reference/yolo_modules'):
+        pytest.skip('the reference is not present here')
+    spec = importlib.util.spec_from_file_location('make_reference_vectors', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',
+                                                                                          'make_reference_vectors.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = str(tmp_path / 'again.npz')
+    mod.main(out)
+    again = np.load(out)
+    assert sorted(again.files) == sorted(G.files)
+    for k in G.files:
+        assert np.array_equal(again[k], G[k]), k
