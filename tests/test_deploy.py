@@ -115,9 +115,11 @@ def test_export_and_init_executor(cuda, tmp_path):
     for o, s_, r in zip(out2, sim, f32):
         e_hip, e_sim = rms(o.cpu().numpy() - r) / r.std(), rms(s_ - r) / r.std()
         assert e_hip < 1.5 * e_sim + 1e-3 and e_hip < 0.015, (e_hip, e_sim)
-    ex32 = deploy.init_executor(str(tmp_path), None, size, device=cuda, step=3, dtype='f32')
-    for o, r in zip(ex32.forward(is_train=False, data=x), f32):
-        np.testing.assert_allclose(o.cpu().numpy(), r, rtol=0, atol=1e-3)
+    # the executors inside the north-star tolerance: exact fp32 and the two split paths (dtype is the executor's `fp16` flag's seam)
+    for dt in ('f32', 'bf16x3', 'f16x3'):
+        ex = deploy.init_executor(str(tmp_path), None, size, device=cuda, step=3, dtype=dt)
+        for o, r in zip(ex.forward(is_train=False, data=x), f32):
+            np.testing.assert_allclose(o.cpu().numpy(), r, rtol=0, atol=1e-3)
 
 
 @pytest.mark.gpu
